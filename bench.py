@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py -- graph-construction throughput on MI355X (BASELINE.json metric).
+
+A step = one pass of the hot path over the workload's reads, already resident in HBM and 2-bit
+packed: k-mer counting with Bloom admission, coverage histogram, edge bitmaps (the three slave modes
+RAY_SLAVE_MODE_ADD_VERTICES / SEND_DISTRIBUTION / ADD_EDGES).  N=1 runs BASELINE.json configs[1]
+(100 Mbp genome, 150 bp reads at 60x, k=31).  N>1 (one rank per GPU under torch.distributed.run) keeps
+the per-GPU read count fixed and grows the genome with N (weak scaling); ranks exchange per-owner
+buckets with one all-to-all over RCCL/xGMI per step.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="C2_100Mbp_60x_150bp_k31")
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink genome and read count (development only)")
+    ap.add_argument("--cpu-sample-reads", type=int, default=60000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(packed, offsets, lengths, k, n_sample):
+    """the oracle ("port" of the reference's per-k-mer work), one core, on the first n_sample reads"""
+    import numpy as np
+    from oracle import ray_oracle as ro
+    bpr = int(offsets[1].item()) if len(offsets) > 1 else 0
+    n = min(n_sample, len(lengths))
+    h_packed = packed[: n * bpr + 16].cpu().numpy()
+    h_off = offsets[:n].cpu().numpy().astype(np.uint64)
+    h_len = lengths[:n].cpu().numpy().astype(np.uint32)
+    g = ro.Graph(k, nranks=1)
+    g.set_reads(h_packed, h_off, h_len)
+    t0 = time.perf_counter()
+    g.count_kmers()
+    g.histogram()
+    g.add_edges()
+    dt = time.perf_counter() - t0
+    occ = g.occurrences()
+    stored = g.size() // 2
+    g.close()
+    return {"value": occ / dt, "unit": "k-mer occurrences/s", "cores": 1, "kind": "port",
+            "sample": "first %d reads of the same workload (%d occurrences, %d vertices stored), %.1f s: "
+                      "count + histogram + edges" % (n, occ, stored, dt),
+            "distinct_kmers_per_s": stored / dt}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import ray_amd
+    from ray_amd import synth
+    from ray_amd.exchange import exchange_owner_buckets, reduce_histogram
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+
+    cfg = dict(synth.CONFIGS[args.workload])
+    k = cfg["k"]
+    genome = max(2000, int(cfg["genome"] * args.scale)) * world
+    n_reads = synth.n_reads_for(int(cfg["genome"] * args.scale), cfg["read_len"], cfg["coverage"])
+    t0 = time.perf_counter()
+    # same genome on every rank (same seed), different reads per rank
+    packed, offsets, lengths = synth.make_reads_torch(genome, cfg["read_len"], n_reads, cfg["seed"], cfg["error"],
+                                                      device=dev, read_seed=cfg["seed"] * 1000 + rank)
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    gen_s = time.perf_counter() - t0
+    first_read_id = rank * n_reads
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def one_step(profile=False):
+        b = ray_amd.GraphBuilder(k, rank=rank, size=world, device=local_rank, first_read_id=first_read_id, stream=stream)
+        if profile:
+            b.set_profiling(True)
+        b.add_reads_device(packed.data_ptr(), n_reads * ((cfg["read_len"] + 3) // 4), offsets.data_ptr(),
+                           lengths.data_ptr(), n_reads, cfg["read_len"])
+        if world == 1:
+            b.count_kmers()                      # RAY_SLAVE_MODE_ADD_VERTICES
+        else:
+            b.count_local()
+            exchange_owner_buckets(b, device=dev)
+            b.resolve_admission(n_reads)
+        cov, cnt = b.histogram()                 # RAY_SLAVE_MODE_SEND_DISTRIBUTION
+        if world > 1:
+            cov, cnt = reduce_histogram(cov, cnt, device=dev, size=world)
+        b.add_edges()                            # RAY_SLAVE_MODE_ADD_EDGES
+        st = b.stats()
+        sweep = b.sweep_time() if profile else (0.0, 0)
+        b.close()
+        return st, sweep, (cov, cnt)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    t0 = time.perf_counter()
+    sweep_ms, sweep_launches = 0.0, 0
+    for _ in range(args.steps):
+        st, sweep, hist = one_step(profile=True)
+        sweep_ms += sweep[0]
+        sweep_launches += sweep[1]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        tot = torch.tensor([st["stored_pairs"], st["occurrences"], st["candidates"]], dtype=torch.int64, device=dev)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        stored, occ, cand = [int(x) for x in tot.tolist()]
+    else:
+        stored, occ, cand = st["stored_pairs"], st["occurrences"], st["candidates"]
+
+    if rank == 0:
+        per_step = elapsed / args.steps
+        # dominant kernel: the k-mer sweep (k_count).  Algorithmic bytes per k-mer occurrence (SURVEY.md 8d,
+        # W=1): L/(4n) B of packed read + 16 B table (8 B key compare + 8 B count read-modify-write).
+        L = cfg["read_len"]
+        n_per_read = L - k + 1
+        Kb = 8 * (1 if k <= 31 else 2)
+        bytes_per_occ = L / (4.0 * n_per_read) + Kb + 8
+        occ_rank0 = st["occurrences"]
+        kernel_s = (sweep_ms / 1e3) / args.steps if sweep_ms else float("nan")
+        achieved = bytes_per_occ * occ_rank0 / kernel_s / 1e9 if sweep_ms else None
+        out = {
+            "metric": "distinct k-mers inserted/sec (whole node)",
+            "value": stored / per_step,
+            "unit": "distinct canonical k-mers/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": per_step * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": args.workload + ("" if args.scale == 1.0 else "@scale=%g" % args.scale), "k": k,
+                       "read_len": L, "reads_per_gpu": n_reads, "genome_bp": genome,
+                       "parallelism": "owner-partitioned x%d" % world, "bloom": "default 16*k*reads cap 2^33"},
+            "occurrences_per_s": occ / per_step,
+            "kmer_occurrences": occ, "distinct_candidates": cand, "vertices_stored": stored,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                         "kernel": "k_count", "bytes_per_occurrence": bytes_per_occ,
+                         "kernel_ms_per_step": kernel_s * 1e3 if sweep_ms else None,
+                         "launches_per_step": sweep_launches / args.steps},
+            "setup_s": gen_s,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(packed, offsets, lengths, k, args.cpu_sample_reads)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

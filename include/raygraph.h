@@ -1,0 +1,168 @@
+/*
+ * raygraph.h -- C ABI of the MI355X (gfx950) de Bruijn graph construction path.
+ *
+ * This is the drop-in boundary for Ray's graph-construction plugins.  Ray keeps its three
+ * CorePlugin classes, their slave-mode symbols and completion tags; only the handler bodies
+ * change and call the functions below (INTEGRATION.md shows the glue).  Plain C: opaque handle,
+ * int status codes, plain pointers and sizes, no C++/torch types.  One host thread per handle
+ * (a Ray rank is a single-threaded event loop, application_core/Machine.cpp:560).
+ *
+ * Citations (file:line) are relative to /root/reference/code/ and name the reference interface
+ * each entry point replaces.
+ */
+#ifndef RAYGRAPH_H
+#define RAYGRAPH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* status codes: 0 = ok, negative = error (glue maps non-zero to Ray's abort route,
+ * MachineHelper/MachineHelper.cpp:261-268) */
+#define RG_OK 0
+#define RG_ERR_ARG (-1)      /* bad argument / configuration */
+#define RG_ERR_HIP (-2)      /* a HIP runtime call failed; rg_last_error() has the text */
+#define RG_ERR_NOMEM (-3)    /* device or host allocation failed */
+#define RG_ERR_STATE (-4)    /* call made in the wrong phase */
+#define RG_ERR_CAPACITY (-5) /* caller buffer too small / internal limit hit */
+
+/* bloom_bits: size the filter like VerticesExtractor::getDefaultNumberOfBitsForBloomFilter
+ * (VerticesExtractor/VerticesExtractor.cpp:276-320): 16*k*localReads capped at 2^33 */
+#define RG_BLOOM_DEFAULT (~(uint64_t)0)
+
+typedef struct rg_handle rg_handle;
+
+/* What Parameters hands the plugins (Mock/Parameters.cpp: getWordSize, getSize, getRank;
+ * MessageProcessor/MessageProcessor.cpp:890-893 for -bloom-filter-bits). */
+typedef struct rg_config {
+	int32_t k;              /* -k, odd; 1 <= k <= 32*kmer_words-1 (Ray itself enforces >= 15, Parameters.cpp:892-907) */
+	int32_t kmer_words;     /* KMER_U64_ARRAY_SIZE: 1 (MAXKMERLENGTH=32) or 2 (=64); 0 = 1 if k<=31 else 2 (Kmer.h:46-61) */
+	int32_t rank;           /* MPI rank == GPU owner index */
+	int32_t size;           /* number of ranks */
+	int32_t device;         /* HIP device ordinal */
+	int32_t reserved0;
+	uint64_t bloom_bits;    /* RG_BLOOM_DEFAULT, 0 = Bloom filter off, else -bloom-filter-bits */
+	uint64_t table_slots;   /* initial open-addressing capacity hint (like -hash-table-buckets); 0 = auto */
+	uint64_t first_read_id; /* global id of this rank's first read (SequencesLoader.cpp:287-297) */
+	void *stream;           /* hipStream_t to launch on; NULL = the library creates its own */
+} rg_config;
+
+/* ---- life cycle ----------------------------------------------------------------------- */
+/* replaces the constructors KmerAcademyBuilder.cpp:217-246, VerticesExtractor.cpp:322-341,
+ * GridTable.cpp:34-66 */
+int rg_create(const rg_config *cfg, rg_handle **out);
+int rg_destroy(rg_handle *h);
+/* text of the last error on this handle ("" if none); h may be NULL for rg_create failures */
+const char *rg_last_error(const rg_handle *h);
+
+/* ---- input: ArrayOfReads (SequencesLoader/Read.cpp:176-204 getRawSequence()/length()) ------- */
+/* packed: the reads' 2-bit buffers back to back (base i of a read = bits 2(i%4).. of byte i/4,
+ * Read.cpp:135-141); byte_offsets[i] = start of read i in `packed`; lengths[i] in bases
+ * (<= 65535).  The library copies; the caller keeps ownership.  May be called repeatedly
+ * (appends, read ids continue).  Host pointers. */
+int rg_add_reads(rg_handle *h, const uint8_t *packed, uint64_t packed_bytes,
+                 const uint64_t *byte_offsets, const uint32_t *lengths, uint64_t n_reads);
+/* same, but the three arrays already live in this device's memory and are used in place
+ * (they must stay valid until rg_destroy; `packed` must be 8-byte aligned and have 16 readable
+ * bytes after packed_bytes). */
+int rg_add_reads_device(rg_handle *h, const void *d_packed, uint64_t packed_bytes,
+                        const void *d_byte_offsets, const void *d_lengths, uint64_t n_reads,
+                        uint32_t max_length);
+
+/* ---- pass 1: RAY_SLAVE_MODE_ADD_VERTICES ------------------------------------------------- */
+/* size == 1: the whole of KmerAcademyBuilder::call_RAY_SLAVE_MODE_ADD_VERTICES
+ * (KmerAcademyBuilder.cpp:43-211) + call_RAY_MPI_TAG_VERTICES_DATA (MessageProcessor.cpp:692-809)
+ * + Bloom sizing (MessageProcessor.cpp:886-899).  Equivalent to rg_count_local +
+ * rg_resolve_admission. */
+int rg_count_kmers(rg_handle *h);
+
+/* size >= 1, decomposed so that the host can run the owner exchange (an all-to-all) between:
+ *  1. rg_count_local        sender half (KmerAcademyBuilder.cpp:143-205): encode, canonical pick,
+ *                           aggregate this rank's k-mers per canonical key
+ *  2. rg_owner_counts       entries per owner rank, owner = hash1(lower) % size (Kmer.cpp:165-170)
+ *  3. rg_export_owner_buckets  32-byte entries grouped by owner into a device buffer
+ *  4. (host) all-to-all of the buckets -- replaces RAY_MPI_TAG_VERTICES_DATA messages
+ *  5. rg_merge_entries      receiver half: merge incoming entries into this rank's partition
+ *  6. rg_resolve_admission  Bloom admission + coverage (MessageProcessor.cpp:741-804) */
+int rg_count_local(rg_handle *h);
+int rg_owner_counts(rg_handle *h, uint64_t *counts /* [size] */);
+/* d_out: device buffer of sum(counts)*RG_ENTRY_BYTES bytes; bucket r starts at entry
+ * sum(counts[0..r)) */
+#define RG_ENTRY_BYTES 32
+int rg_export_owner_buckets(rg_handle *h, void *d_out, uint64_t capacity_entries);
+int rg_merge_entries(rg_handle *h, const void *d_entries, uint64_t n_entries);
+/* local_reads_for_bloom: this rank's read count for RG_BLOOM_DEFAULT sizing
+ * (VerticesExtractor.cpp:298-300); pass UINT64_MAX to use the reads added to this handle */
+int rg_resolve_admission(rg_handle *h, uint64_t local_reads_for_bloom);
+
+/* ---- RAY_SLAVE_MODE_SEND_DISTRIBUTION ----------------------------------------------------- */
+/* local part of CoverageGatherer::call_RAY_SLAVE_MODE_SEND_DISTRIBUTION
+ * (CoverageGatherer/CoverageGatherer.cpp:124-190): (coverage, count) pairs ascending, count = 2
+ * per stored pair (GridTableIterator.cpp:41-54).  *n = pairs available; fills min(*n, cap). */
+int rg_histogram(rg_handle *h, uint32_t *coverage, uint64_t *count, uint64_t cap, uint64_t *n);
+
+/* ---- pass 2: RAY_SLAVE_MODE_ADD_EDGES ------------------------------------------------------ */
+/* VerticesExtractor::call_RAY_SLAVE_MODE_ADD_EDGES (VerticesExtractor.cpp:40-274) +
+ * call_RAY_MPI_TAG_OUT_EDGES_DATA / IN_EDGES_DATA (MessageProcessor.cpp:858-968).  Edge bits
+ * travel with the pass-1 entries (they are order-free ORs), so this call only publishes them. */
+int rg_add_edges(rg_handle *h);
+
+/* ---- next row: RAY_SLAVE_MODE_PURGE_NULL_EDGES (EdgePurger/EdgePurgerWorker.cpp:28-102) ------- */
+/* size == 1 only in this version: clears edge bits whose neighbour is not stored */
+int rg_purge_edges(rg_handle *h);
+
+/* ---- the store: GridTable / Vertex ---------------------------------------------------------- */
+/* GridTable::size (GridTable.cpp:80-82): 2 per stored pair */
+int rg_size(rg_handle *h, uint64_t *size);
+/* Vertex::dump records (VerticesExtractor/Vertex.cpp:438-454): kmer_words*8 bytes lower key,
+ * 4 bytes coverage, 1 byte edge bitmap = 13 or 21 bytes each, in table order.  host_buf holds
+ * cap_records records; *n_records = records available. */
+int rg_export(rg_handle *h, void *host_buf, uint64_t cap_records, uint64_t *n_records);
+/* bulk GridTable::find (GridTable.cpp:84-109) + Vertex::getCoverage/getEdges (Vertex.cpp:98-100,
+ * 169-173): kmers = n * kmer_words words, either strand; coverage 0 = absent; edges in the
+ * orientation of the queried k-mer.  Host pointers. */
+int rg_find(rg_handle *h, const uint64_t *kmers, uint64_t n, uint32_t *coverage, uint8_t *edges);
+/* call_RAY_SLAVE_MODE_WRITE_KMERS degree table (MachineHelper/MachineHelper.cpp:548-578):
+ * out[parents*5+children] over both strands of every stored vertex */
+int rg_degree_distribution(rg_handle *h, uint64_t out[25]);
+
+/* ---- statistics (the "Rank r ..." log lines, MessageProcessor.cpp:984-1037) ------------------ */
+typedef struct rg_stats {
+	uint64_t reads;            /* reads added */
+	uint64_t occurrences;      /* k-mer occurrences streamed in pass 1 */
+	uint64_t candidates;       /* distinct canonical k-mers seen by this rank's partition */
+	uint64_t stored_pairs;     /* retained after admission */
+	uint64_t bloom_bits;       /* m_bloomBits */
+	uint64_t bloom_insertions; /* BloomFilter::getNumberOfInsertions */
+	uint64_t bloom_set_bits;   /* BloomFilter::getNumberOfSetBits */
+	uint64_t table_slots;      /* current open-addressing capacity */
+} rg_stats;
+int rg_get_stats(rg_handle *h, rg_stats *out);
+
+/* ---- profiling (the reference's MACRO_COLLECT_PROFILING_INFORMATION probes,
+ * KmerAcademyBuilder.cpp:50,73,116,...) ------------------------------------------------------- */
+/* when enabled, every launch of the k-mer sweep kernel (the dominant kernel) is bracketed by HIP
+ * events on the launch stream */
+int rg_set_profiling(rg_handle *h, int enable);
+/* sum of the bracketed sweep launches in milliseconds and their number (synchronises the stream) */
+int rg_get_sweep_time(rg_handle *h, double *total_ms, uint64_t *launches);
+
+/* ---- host-side master-mode helpers (no GPU needed) ------------------------------------------- */
+/* CoverageDistribution::CoverageDistribution (CoverageGatherer/CoverageDistribution.cpp:33-112):
+ * writes CoverageDistribution.txt to `path` (NULL = no file) and returns minimum / peak / repeat
+ * coverage.  n == 0 -> RG_ERR_ARG ("no k-mers found", MachineHelper.cpp:261-268). */
+int rg_coverage_distribution(const uint32_t *coverage, const uint64_t *count, uint64_t n,
+                             const char *path, int32_t *minimum, int32_t *peak, int32_t *repeat);
+/* Read::constructor packing incl. trimming (SequencesLoader/Read.cpp:31-159): returns the stored
+ * length; packed needs (strlen(sequence)+3)/4 bytes */
+int rg_pack_read(const char *sequence, int trim, uint8_t *packed);
+
+/* library version string */
+const char *rg_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,82 @@
+"""Loader of the in-tree HIP library (ray_amd/libraygraph.so).
+
+There is no fallback: if the library is missing or does not load, importing the product path
+raises.  The library itself refuses to work without a HIP device (rg_create -> RG_ERR_HIP).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libraygraph.so")
+
+RG_OK = 0
+RG_ERR_ARG, RG_ERR_HIP, RG_ERR_NOMEM, RG_ERR_STATE, RG_ERR_CAPACITY = -1, -2, -3, -4, -5
+RG_BLOOM_DEFAULT = (1 << 64) - 1
+RG_ENTRY_BYTES = 32
+UINT64_MAX = (1 << 64) - 1
+
+
+class RgConfig(C.Structure):
+    _fields_ = [("k", C.c_int32), ("kmer_words", C.c_int32), ("rank", C.c_int32), ("size", C.c_int32),
+                ("device", C.c_int32), ("reserved0", C.c_int32), ("bloom_bits", C.c_uint64),
+                ("table_slots", C.c_uint64), ("first_read_id", C.c_uint64), ("stream", C.c_void_p)]
+
+
+class RgStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("reads", "occurrences", "candidates", "stored_pairs", "bloom_bits",
+                                         "bloom_insertions", "bloom_set_bits", "table_slots")]
+
+
+# every symbol include/raygraph.h declares
+SYMBOLS = ["rg_create", "rg_destroy", "rg_last_error", "rg_add_reads", "rg_add_reads_device", "rg_count_kmers",
+           "rg_count_local", "rg_owner_counts", "rg_export_owner_buckets", "rg_merge_entries",
+           "rg_resolve_admission", "rg_histogram", "rg_add_edges", "rg_purge_edges", "rg_size", "rg_export",
+           "rg_find", "rg_degree_distribution", "rg_get_stats", "rg_set_profiling", "rg_get_sweep_time", "rg_coverage_distribution", "rg_pack_read",
+           "rg_version"]
+
+_lib = None
+
+
+def load():
+    """dlopen libraygraph.so and bind the C ABI; raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s is missing: build it with `make -C ray_amd/csrc` (or __graft_entry__.build()); "
+                          "ray_amd has no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, u64, u32 = C.c_void_p, C.c_uint64, C.c_uint32
+    u64p, u32p, u8p = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)
+    i32p = C.POINTER(C.c_int32)
+    sig = {
+        "rg_create": ([C.POINTER(RgConfig), C.POINTER(vp)], C.c_int),
+        "rg_destroy": ([vp], C.c_int),
+        "rg_last_error": ([vp], C.c_char_p),
+        "rg_add_reads": ([vp, vp, u64, vp, vp, u64], C.c_int),
+        "rg_add_reads_device": ([vp, vp, u64, vp, vp, u64, u32], C.c_int),
+        "rg_count_kmers": ([vp], C.c_int),
+        "rg_count_local": ([vp], C.c_int),
+        "rg_owner_counts": ([vp, u64p], C.c_int),
+        "rg_export_owner_buckets": ([vp, vp, u64], C.c_int),
+        "rg_merge_entries": ([vp, vp, u64], C.c_int),
+        "rg_resolve_admission": ([vp, u64], C.c_int),
+        "rg_histogram": ([vp, u32p, u64p, u64, u64p], C.c_int),
+        "rg_add_edges": ([vp], C.c_int),
+        "rg_purge_edges": ([vp], C.c_int),
+        "rg_size": ([vp, u64p], C.c_int),
+        "rg_export": ([vp, vp, u64, u64p], C.c_int),
+        "rg_find": ([vp, u64p, u64, u32p, u8p], C.c_int),
+        "rg_degree_distribution": ([vp, u64p], C.c_int),
+        "rg_get_stats": ([vp, C.POINTER(RgStats)], C.c_int),
+        "rg_set_profiling": ([vp, C.c_int], C.c_int),
+        "rg_get_sweep_time": ([vp, C.POINTER(C.c_double), u64p], C.c_int),
+        "rg_coverage_distribution": ([u32p, u64p, u64, C.c_char_p, i32p, i32p, i32p], C.c_int),
+        "rg_pack_read": ([C.c_char_p, C.c_int, u8p], C.c_int),
+        "rg_version": ([], C.c_char_p),
+    }
+    for name in SYMBOLS:
+        f = getattr(L, name)  # AttributeError if the library does not export it
+        f.argtypes, f.restype = sig[name]
+    _lib = L
+    return L

@@ -1,0 +1,1164 @@
+// raygraph.hip -- kernels and C ABI of the gfx950 graph-construction path (include/raygraph.h).
+//
+// Path: A0 packed reads -> A1-A4 encode / reverse complement / canonical /
+// owner hash -> A5+A7+A8 count into the vertex table (+A9-A11 edge bits in the same sweep) -> A6+A7
+// Bloom admission resolved from arrival stamps -> A12 histogram -> export.  All arithmetic is
+// 64-bit integer; the kernels are bound by random 32-byte sector traffic and atomics, not by
+// ALU, and there is no dense contraction anywhere (no MFMA).
+//
+// No CPU fallback exists: every entry point needs a HIP device and fails with RG_ERR_HIP otherwise.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/raygraph.h"
+#include "rg_device.h"
+
+using namespace rg;
+
+// ================================================================================ kernels
+
+static constexpr int BLOCK = 256;
+static constexpr int TILE_READS = 32;  // reads per workgroup tile in the k-mer sweep
+
+enum Counter {
+	C_FILL = 0,     // claimed slots (main table)
+	C_ERR,          // probe limit hit
+	C_OCC,          // k-mer occurrences streamed
+	C_RETAINED,     // stored pairs after admission
+	C_INSERTIONS,   // Bloom insertions (distinct keys whose first sight was not a false positive)
+	C_SETBITS,      // Bloom bits set
+	C_OVF,          // histogram overflow entries
+	C_FILL_LOCAL,   // claimed slots (local aggregation table)
+	C_EXPORT,       // export cursor
+	C_NUM = 32
+};
+
+__global__ void k_init_table(Slot *tab, uint64_t cap) {
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	for (; i < cap; i += stride) {
+		ulonglong2 a = make_ulonglong2(EMPTY, EMPTY), b = make_ulonglong2(INF_STAMP, 0);
+		*reinterpret_cast<ulonglong2 *>(&tab[i].k0) = a;
+		*reinterpret_cast<ulonglong2 *>(&tab[i].stamp) = b;
+	}
+}
+
+// A1-A5, A7 (count part), A8, A9-A11: one sweep over a range of reads.
+// A workgroup takes TILE_READS reads at a time, prefix-sums their k-mer counts in LDS and deals the
+// tile's k-mer positions round-robin to its 256 lanes, so every wavefront stays full whatever the
+// read lengths are (ragged and short reads included).  Each lane funnel-shifts its forward k-mer
+// out of the packed read, derives the reverse complement with bit reversal, keeps the lower of
+// the two (Kmer.cpp:38-47), folds the neighbouring bases into an edge mask in the lower k-mer's
+// orientation (Vertex.cpp:110-173) and merges (stamp, +1, mask) into the table.
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_count(const uint64_t *__restrict__ P, const uint64_t *__restrict__ offsets,
+                                                 const uint32_t *__restrict__ lengths, uint64_t read_begin, uint64_t read_end,
+                                                 uint64_t stamp_base, int k, Slot *__restrict__ tab, uint64_t mask,
+                                                 unsigned long long *__restrict__ counters, int fill_counter) {
+	__shared__ uint32_t s_pre[TILE_READS + 1];
+	__shared__ uint64_t s_off[TILE_READS];
+	__shared__ uint32_t s_claimed;
+	const uint8_t *P8 = reinterpret_cast<const uint8_t *>(P);
+	const uint64_t mask0 = (2 * k >= 64) ? ~0ull : ((1ull << (2 * k)) - 1);
+	const uint64_t mask1 = (k > 32) ? ((1ull << (2 * k - 64)) - 1) : 0ull;
+	const uint64_t nreads = read_end - read_begin;
+	const uint64_t ntiles = (nreads + TILE_READS - 1) / TILE_READS;
+	uint32_t claimed = 0;
+	bool failed = false;
+	unsigned long long occ = 0;
+	if (threadIdx.x == 0) s_claimed = 0;
+
+	for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+		__syncthreads();
+		if (threadIdx.x < TILE_READS) {
+			uint64_t r = read_begin + tile * TILE_READS + threadIdx.x;
+			uint32_t n = 0;
+			uint64_t off = 0;
+			if (r < read_end) {
+				uint32_t L = lengths[r];
+				n = (L >= (uint32_t)k) ? (L - (uint32_t)k + 1) : 0;  // KmerAcademyBuilder.cpp:130-137
+				off = offsets[r];
+			}
+			s_off[threadIdx.x] = off;
+			// inclusive scan over the 32 lanes of the tile header
+			uint32_t v = n;
+			for (int d = 1; d < TILE_READS; d <<= 1) {
+				uint32_t t = __shfl_up(v, d, TILE_READS);
+				if ((int)threadIdx.x >= d) v += t;
+			}
+			s_pre[threadIdx.x + 1] = v;
+			if (threadIdx.x == 0) s_pre[0] = 0;
+		}
+		__syncthreads();
+		const uint32_t total = s_pre[TILE_READS];
+		if (threadIdx.x == 0) occ += total;
+		for (uint32_t t = threadIdx.x; t < total; t += BLOCK) {
+			// read index: largest i with s_pre[i] <= t
+			int lo = 0, hi = TILE_READS;
+#pragma unroll
+			for (int step = 0; step < 5; ++step) {
+				int mid = (lo + hi) >> 1;
+				if (s_pre[mid] <= t) lo = mid;
+				else hi = mid;
+			}
+			const uint32_t p = t - s_pre[lo];
+			const uint32_t n = s_pre[lo + 1] - s_pre[lo];
+			const uint64_t off = s_off[lo];
+			const uint64_t bit = off * 8 + 2ull * p;
+			uint64_t f0 = ext64(P, bit) & mask0;
+			uint64_t f1 = 0;
+			if (W == 2 && k > 32) f1 = ext64(P, bit + 64) & mask1;
+			uint64_t r0, r1;
+			revcomp<W>(f0, f1, k, r0, r1);
+			const bool use_rc = kmer_less<W>(r0, r1, f0, f1);  // KmerAcademyBuilder.cpp:162-165
+			const uint64_t K0 = use_rc ? r0 : f0, K1 = use_rc ? r1 : f1;
+			// edge bits this occurrence contributes (VerticesExtractor.cpp:169-253): the previous k-mer's
+			// first base is an ingoing edge, the next k-mer's last base an outgoing edge
+			uint32_t em = 0;
+			if (p > 0) {
+				uint32_t f = base_at(P8, off, p - 1);
+				em |= use_rc ? (1u << (7 - f)) : (1u << f);
+			}
+			if (p + 1 < n) {
+				uint32_t c = base_at(P8, off, p + (uint32_t)k);
+				em |= use_rc ? (1u << (3 - c)) : (1u << (4 + c));
+			}
+			uint64_t i0, i1;
+			to_internal<W>(K0, K1, i0, i1);
+			const uint64_t stamp = ((stamp_base + tile * TILE_READS + (uint64_t)lo) << 16) | p;
+			if (!upsert<W>(tab, mask, i0, i1, stamp, 1ull, em, claimed)) failed = true;
+		}
+	}
+	if (claimed) atomicAdd(&s_claimed, claimed);
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		if (s_claimed) atomicAdd(&counters[fill_counter], (unsigned long long)s_claimed);
+		if (occ) atomicAdd(&counters[C_OCC], occ);
+	}
+	if (failed) atomicAdd(&counters[C_ERR], 1ull);
+}
+
+// re-insert every entry of an old table into a bigger one (keys are unique: plain payload stores)
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_rehash(const Slot *__restrict__ old, uint64_t oldcap, Slot *__restrict__ tab, uint64_t mask,
+                                                  unsigned long long *__restrict__ counters) {
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	bool failed = false;
+	for (; i < oldcap; i += stride) {
+		Slot v = old[i];
+		if (v.k0 == EMPTY) continue;
+		uint32_t dummy = 0;
+		uint64_t s = slot_hash<W>(v.k0, v.k1) & mask;
+		bool done = false;
+		for (uint32_t probe = 0; probe < MAX_PROBE && !done; ++probe) {
+			Slot *p = tab + s;
+			uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long *>(&p->k0), EMPTY, v.k0);
+			if (prev == EMPTY) {
+				p->k1 = v.k1;
+				p->stamp = v.stamp;
+				p->meta = v.meta;
+				done = true;
+			}
+			s = (s + 1) & mask;
+		}
+		(void)dummy;
+		if (!done) failed = true;
+	}
+	if (failed) atomicAdd(&counters[C_ERR], 1ull);
+}
+
+// receiver half of the owner exchange: merge 32-byte entries (same layout as Slot) into the table
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_merge(const Slot *__restrict__ in, uint64_t n, Slot *__restrict__ tab, uint64_t mask,
+                                                 unsigned long long *__restrict__ counters) {
+	__shared__ uint32_t s_claimed;
+	if (threadIdx.x == 0) s_claimed = 0;
+	__syncthreads();
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	uint32_t claimed = 0;
+	bool failed = false;
+	for (; i < n; i += stride) {
+		Slot v = in[i];
+		uint64_t add = v.meta & COUNT_MASK;
+		uint32_t em = (uint32_t)(v.meta >> PEND_SHIFT) & 0xFFu;
+		if (!upsert<W>(tab, mask, v.k0, W == 2 ? v.k1 : 0, v.stamp, add, em, claimed)) failed = true;
+	}
+	if (claimed) atomicAdd(&s_claimed, claimed);
+	__syncthreads();
+	if (threadIdx.x == 0 && s_claimed) atomicAdd(&counters[C_FILL], (unsigned long long)s_claimed);
+	if (failed) atomicAdd(&counters[C_ERR], 1ull);
+}
+
+// owner = hash1(lower) % size (Kmer.cpp:165-170, Mock/Parameters.cpp:2116-2118)
+template <int W>
+__device__ __forceinline__ uint32_t owner_of(const Slot &v, uint32_t size) {
+	uint64_t K0, K1;
+	from_internal<W>(v.k0, v.k1, K0, K1);
+	return (uint32_t)(hash1<W>(K0, K1) % (uint64_t)size);
+}
+
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_owner_counts(const Slot *__restrict__ tab, uint64_t cap, uint32_t size,
+                                                        unsigned long long *__restrict__ counts) {
+	extern __shared__ uint32_t s_cnt[];
+	for (uint32_t j = threadIdx.x; j < size; j += blockDim.x) s_cnt[j] = 0;
+	__syncthreads();
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	for (; i < cap; i += stride) {
+		Slot v = tab[i];
+		if (v.k0 == EMPTY) continue;
+		atomicAdd(&s_cnt[owner_of<W>(v, size)], 1u);
+	}
+	__syncthreads();
+	for (uint32_t j = threadIdx.x; j < size; j += blockDim.x)
+		if (s_cnt[j]) atomicAdd(&counts[j], (unsigned long long)s_cnt[j]);
+}
+
+// scatter entries into per-owner buckets; cursors[r] starts at the bucket's first entry
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_owner_scatter(const Slot *__restrict__ tab, uint64_t cap, uint32_t size,
+                                                         unsigned long long *__restrict__ cursors, Slot *__restrict__ out) {
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	for (; i < cap; i += stride) {
+		Slot v = tab[i];
+		if (v.k0 == EMPTY) continue;
+		unsigned long long pos = atomicAdd(&cursors[owner_of<W>(v, size)], 1ull);
+		out[pos] = v;
+	}
+}
+
+// A6: first-touch stamps of the Bloom bits.  bit_i = (hash2(lower) ^ M_i) % m_bits
+// (BloomFilter.cpp:124-200).  A bit is set at the first arrival of any key that touches it, so
+// stamp[bit] = min over touching keys of their first-arrival stamp.
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_bloom_touch(const Slot *__restrict__ tab, uint64_t cap, uint64_t m_bits,
+                                                       unsigned long long *__restrict__ bitstamp,
+                                                       unsigned long long *__restrict__ counters) {
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	uint32_t newly = 0;
+	for (; i < cap; i += stride) {
+		Slot v = tab[i];
+		if (v.k0 == EMPTY) continue;
+		uint64_t K0, K1;
+		from_internal<W>(v.k0, v.k1, K0, K1);
+		const uint64_t origin = hash2<W>(K0, K1);
+#pragma unroll
+		for (int j = 0; j < 8; ++j) {
+			uint64_t b = (origin ^ BLOOM_MAGIC[j]) % m_bits;
+			if (bitstamp[b] > v.stamp) {
+				unsigned long long old = atomicMin(&bitstamp[b], (unsigned long long)v.stamp);
+				if (old == INF_STAMP) newly++;
+			}
+		}
+	}
+	// wave-level reduction of the set-bit count
+	for (int d = 32; d > 0; d >>= 1) newly += __shfl_down(newly, d);
+	if ((threadIdx.x & 63) == 0 && newly) atomicAdd(&counters[C_SETBITS], (unsigned long long)newly);
+}
+
+// A7: admission + coverage (MessageProcessor.cpp:741-804).  With the filter on, a key whose first
+// sight found all 8 bits already set (a false positive) is stored from its first sight: coverage
+// 1 + N.  Otherwise the first sight only feeds the filter: stored iff N >= 2, coverage N.  With
+// the filter off every sight counts: coverage N.  Coverage saturates at 2^32-1 (Vertex.cpp:83-88).
+template <int W, bool BLOOM>
+__global__ __launch_bounds__(BLOCK) void k_admit(Slot *__restrict__ tab, uint64_t cap, uint64_t m_bits,
+                                                 const unsigned long long *__restrict__ bitstamp,
+                                                 unsigned long long *__restrict__ counters) {
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	uint32_t retained = 0, inserted = 0;
+	for (; i < cap; i += stride) {
+		Slot v = tab[i];
+		if (v.k0 == EMPTY) continue;
+		const uint64_t N = v.meta & COUNT_MASK;
+		uint64_t cov;
+		if (BLOOM) {
+			uint64_t K0, K1;
+			from_internal<W>(v.k0, v.k1, K0, K1);
+			const uint64_t origin = hash2<W>(K0, K1);
+			bool fp = true;  // all 8 bits were set before this key first arrived
+#pragma unroll
+			for (int j = 0; j < 8; ++j) {
+				uint64_t b = (origin ^ BLOOM_MAGIC[j]) % m_bits;
+				if (bitstamp[b] == v.stamp) fp = false;  // this key's first arrival set the bit
+			}
+			if (fp) cov = N + 1;
+			else {
+				inserted++;
+				cov = (N >= 2) ? N : 0;
+			}
+		} else {
+			cov = N;
+		}
+		if (cov > 0xFFFFFFFFull) cov = 0xFFFFFFFFull;
+		if (cov) retained++;
+		tab[i].meta = (v.meta & ~COUNT_MASK) | cov;
+	}
+	for (int d = 32; d > 0; d >>= 1) {
+		retained += __shfl_down(retained, d);
+		inserted += __shfl_down(inserted, d);
+	}
+	if ((threadIdx.x & 63) == 0) {
+		if (retained) atomicAdd(&counters[C_RETAINED], (unsigned long long)retained);
+		if (inserted) atomicAdd(&counters[C_INSERTIONS], (unsigned long long)inserted);
+	}
+}
+
+// A12: coverage histogram of the stored pairs.  Low coverages are binned in LDS per workgroup.
+static constexpr uint32_t HIST_LDS = 4096;
+static constexpr uint32_t HIST_DENSE = 65536;
+static constexpr uint32_t HIST_OVF_CAP = 1u << 20;
+__global__ __launch_bounds__(BLOCK) void k_histogram(const Slot *__restrict__ tab, uint64_t cap,
+                                                     unsigned long long *__restrict__ dense, uint32_t *__restrict__ ovf,
+                                                     unsigned long long *__restrict__ counters) {
+	__shared__ uint32_t s_h[HIST_LDS];
+	for (uint32_t j = threadIdx.x; j < HIST_LDS; j += blockDim.x) s_h[j] = 0;
+	__syncthreads();
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	for (; i < cap; i += stride) {
+		ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(&tab[i].k0);
+		if (a.x == EMPTY) continue;
+		uint64_t cov = tab[i].meta & COUNT_MASK;
+		if (cov == 0) continue;
+		if (cov < HIST_LDS) atomicAdd(&s_h[cov], 1u);
+		else if (cov < HIST_DENSE) atomicAdd(&dense[cov], 1ull);
+		else {
+			unsigned long long pos = atomicAdd(&counters[C_OVF], 1ull);
+			if (pos < HIST_OVF_CAP) ovf[pos] = (uint32_t)cov;
+		}
+	}
+	__syncthreads();
+	for (uint32_t j = threadIdx.x; j < HIST_LDS; j += blockDim.x)
+		if (s_h[j]) atomicAdd(&dense[j], (unsigned long long)s_h[j]);
+}
+
+// pass 2 publication: the edge bits gathered during the sweep become the vertex's edge bitmap
+__global__ __launch_bounds__(BLOCK) void k_publish_edges(Slot *__restrict__ tab, uint64_t cap) {
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	for (; i < cap; i += stride) {
+		uint64_t m = tab[i].meta;
+		if (tab[i].k0 == EMPTY || (m & COUNT_MASK) == 0) continue;
+		uint64_t pend = (m >> PEND_SHIFT) & 0xFFull;
+		tab[i].meta = (m & ~(0xFFull << PUB_SHIFT)) | (pend << PUB_SHIFT);
+	}
+}
+
+// multiword helpers in the reference key form
+template <int W>
+__device__ __forceinline__ void canonical_internal(uint64_t f0, uint64_t f1, int k, uint64_t &i0, uint64_t &i1, bool &is_rc) {
+	uint64_t r0, r1;
+	revcomp<W>(f0, f1, k, r0, r1);
+	is_rc = kmer_less<W>(r0, r1, f0, f1);
+	to_internal<W>(is_rc ? r0 : f0, is_rc ? r1 : f1, i0, i1);
+}
+
+// EdgePurgerWorker::work (EdgePurger/EdgePurgerWorker.cpp:28-102): drop an edge bit when the
+// neighbour it names is not stored.  Neighbours as Kmer::getIngoingEdges/getOutgoingEdges
+// (Kmer.cpp:176-282).  Reads only coverage of other slots, writes only its own edge byte.
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_purge(Slot *__restrict__ tab, uint64_t cap, int k) {
+	const uint64_t mask = cap - 1;
+	const uint64_t mask0 = (2 * k >= 64) ? ~0ull : ((1ull << (2 * k)) - 1);
+	const uint64_t mask1 = (k > 32) ? ((1ull << (2 * k - 64)) - 1) : 0ull;
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	for (; i < cap; i += stride) {
+		Slot v = tab[i];
+		if (v.k0 == EMPTY || (v.meta & COUNT_MASK) == 0) continue;
+		uint32_t e = (uint32_t)(v.meta >> PUB_SHIFT) & 0xFFu;
+		if (!e) continue;
+		uint64_t K0, K1;
+		from_internal<W>(v.k0, v.k1, K0, K1);
+		uint32_t keep = e;
+		for (uint32_t c = 0; c < 4; ++c) {
+			if (e & (1u << c)) {  // parent: shift left one base, base c enters at position 0
+				uint64_t n0 = ((K0 << 2) | c) & mask0;
+				uint64_t n1 = (W == 2) ? (((K1 << 2) | (K0 >> 62)) & mask1) : 0;
+				uint64_t i0, i1;
+				bool rc;
+				canonical_internal<W>(n0, n1, k, i0, i1, rc);
+				const Slot *q = lookup<W>(tab, mask, i0, i1);
+				if (!q || (q->meta & COUNT_MASK) == 0) keep &= ~(1u << c);
+			}
+			if (e & (1u << (4 + c))) {  // child: shift right one base, base c enters at position k-1
+				uint64_t n0 = K0 >> 2, n1 = 0;
+				if (W == 2) {
+					n0 |= K1 << 62;
+					n1 = K1 >> 2;
+				}
+				int pos = 2 * (k - 1);
+				if (pos < 64) n0 |= (uint64_t)c << pos;
+				else n1 |= (uint64_t)c << (pos - 64);
+				uint64_t i0, i1;
+				bool rc;
+				canonical_internal<W>(n0, n1, k, i0, i1, rc);
+				const Slot *q = lookup<W>(tab, mask, i0, i1);
+				if (!q || (q->meta & COUNT_MASK) == 0) keep &= ~(1u << (4 + c));
+			}
+		}
+		if (keep != e) tab[i].meta = (v.meta & ~(0xFFull << PUB_SHIFT)) | ((uint64_t)keep << PUB_SHIFT);
+	}
+}
+
+// bulk GridTable::find + Vertex::getCoverage/getEdges
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_find(const Slot *__restrict__ tab, uint64_t cap, int k, const uint64_t *__restrict__ q,
+                                                uint64_t n, uint32_t *__restrict__ cov, uint8_t *__restrict__ edges) {
+	const uint64_t mask = cap - 1;
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	for (; i < n; i += stride) {
+		uint64_t f0 = q[i * W], f1 = (W == 2) ? q[i * W + 1] : 0;
+		uint64_t i0, i1;
+		bool rc;
+		canonical_internal<W>(f0, f1, k, i0, i1, rc);
+		const Slot *s = lookup<W>(tab, mask, i0, i1);
+		uint32_t c = 0, e = 0;
+		if (s) {
+			c = (uint32_t)(s->meta & COUNT_MASK);
+			if (c) {
+				e = (uint32_t)(s->meta >> PUB_SHIFT) & 0xFFu;
+				if (rc) e = convert_bitmap(e);
+			}
+		}
+		cov[i] = c;
+		edges[i] = (uint8_t)e;
+	}
+}
+
+// 5x5 in/out-degree table over both strands (MachineHelper.cpp:548-578)
+__global__ __launch_bounds__(BLOCK) void k_degrees(const Slot *__restrict__ tab, uint64_t cap, unsigned long long *__restrict__ out) {
+	__shared__ uint32_t s_d[25];
+	if (threadIdx.x < 25) s_d[threadIdx.x] = 0;
+	__syncthreads();
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	for (; i < cap; i += stride) {
+		uint64_t m = tab[i].meta;
+		if (tab[i].k0 == EMPTY || (m & COUNT_MASK) == 0) continue;
+		uint32_t e = (uint32_t)(m >> PUB_SHIFT) & 0xFFu;
+		uint32_t parents = __popc(e & 0xFu), children = __popc(e >> 4);
+		atomicAdd(&s_d[parents * 5 + children], 1u);
+		atomicAdd(&s_d[children * 5 + parents], 1u);  // the reverse complement swaps the roles
+	}
+	__syncthreads();
+	if (threadIdx.x < 25 && s_d[threadIdx.x]) atomicAdd(&out[threadIdx.x], (unsigned long long)s_d[threadIdx.x]);
+}
+
+// export, step 1: stored pairs per chunk of slots
+__global__ __launch_bounds__(BLOCK) void k_export_count(const Slot *__restrict__ tab, uint64_t cap, uint64_t chunk,
+                                                        unsigned long long *__restrict__ per_chunk) {
+	__shared__ uint32_t s_n;
+	if (threadIdx.x == 0) s_n = 0;
+	__syncthreads();
+	uint64_t begin = (uint64_t)blockIdx.x * chunk, end = begin + chunk < cap ? begin + chunk : cap;
+	uint32_t n = 0;
+	for (uint64_t i = begin + threadIdx.x; i < end; i += blockDim.x)
+		if (tab[i].k0 != EMPTY && (tab[i].meta & COUNT_MASK)) n++;
+	if (n) atomicAdd(&s_n, n);
+	__syncthreads();
+	if (threadIdx.x == 0) per_chunk[blockIdx.x] = s_n;
+}
+
+// export, step 2: Vertex::dump records (Vertex.cpp:438-454) in slot order, deterministic
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_export_write(const Slot *__restrict__ tab, uint64_t cap, uint64_t chunk,
+                                                        const unsigned long long *__restrict__ chunk_start, uint8_t *__restrict__ out) {
+	constexpr int REC = W * 8 + 5;
+	__shared__ uint32_t s_wave[BLOCK / 64];
+	__shared__ uint32_t s_base;
+	uint64_t begin = (uint64_t)blockIdx.x * chunk, end = begin + chunk < cap ? begin + chunk : cap;
+	if (threadIdx.x == 0) s_base = 0;
+	__syncthreads();
+	const uint64_t out0 = chunk_start[blockIdx.x];
+	for (uint64_t base = begin; base < end; base += blockDim.x) {
+		uint64_t i = base + threadIdx.x;
+		Slot v;
+		bool keep = false;
+		if (i < end) {
+			v = tab[i];
+			keep = v.k0 != EMPTY && (v.meta & COUNT_MASK);
+		}
+		unsigned long long ballot = __ballot(keep);
+		uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+		uint32_t before = __popcll(ballot & ((1ull << lane) - 1));
+		if (lane == 0) s_wave[wave] = __popcll(ballot);
+		__syncthreads();
+		uint32_t wbase = 0, tot = 0;
+		for (uint32_t w = 0; w < BLOCK / 64; ++w) {
+			if (w < wave) wbase += s_wave[w];
+			tot += s_wave[w];
+		}
+		uint32_t blockbase = s_base;
+		if (keep) {
+			uint64_t K0, K1;
+			from_internal<W>(v.k0, v.k1, K0, K1);
+			uint8_t *p = out + (out0 + blockbase + wbase + before) * REC;
+			uint32_t cov = (uint32_t)(v.meta & COUNT_MASK);
+			uint8_t e = (uint8_t)(v.meta >> PUB_SHIFT);
+			for (int b = 0; b < 8; ++b) p[b] = (uint8_t)(K0 >> (8 * b));
+			if (W == 2)
+				for (int b = 0; b < 8; ++b) p[8 + b] = (uint8_t)(K1 >> (8 * b));
+			for (int b = 0; b < 4; ++b) p[W * 8 + b] = (uint8_t)(cov >> (8 * b));
+			p[W * 8 + 4] = e;
+		}
+		__syncthreads();
+		if (threadIdx.x == 0) s_base = blockbase + tot;
+		__syncthreads();
+	}
+}
+
+// ================================================================================ host side
+
+struct Table {
+	Slot *slots = nullptr;
+	uint64_t cap = 0;
+	uint64_t fill_known = 0;    // claimed slots at the last synchronisation
+	uint64_t fill_pending = 0;  // upper bound of claims launched since
+};
+
+struct ReadBatch {
+	const uint64_t *d_packed = nullptr;
+	const uint64_t *d_off = nullptr;
+	const uint32_t *d_len = nullptr;
+	uint64_t n = 0;
+	uint64_t first_id = 0;  // global id of the batch's first read
+	uint32_t maxlen = 0;
+	bool owned = false;
+};
+
+enum Phase { PH_CREATED = 0, PH_COUNTED_LOCAL, PH_MERGING, PH_RESOLVED, PH_EDGES, PH_PURGED };
+
+struct rg_handle {
+	rg_config cfg;
+	int W = 1;
+	hipStream_t stream = nullptr;
+	bool own_stream = false;
+	std::vector<ReadBatch> reads;
+	uint64_t n_reads = 0;
+	Table tab;    // this rank's partition of the vertex store
+	Table local;  // size > 1: aggregation of this rank's own reads before the exchange
+	unsigned long long *d_counters = nullptr;
+	unsigned long long *h_counters = nullptr;  // pinned
+	unsigned long long *d_owner = nullptr;     // [size] counts, [size] cursors
+	std::vector<uint64_t> owner_counts;
+	Phase phase = PH_CREATED;
+	rg_stats stats{};
+	std::string err;
+	// optional per-kernel timing with HIP events on the launch stream (rg_set_profiling)
+	bool profiling = false;
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> sweep_events;
+};
+
+static thread_local std::string g_create_error;
+
+static int fail(rg_handle *h, int code, const char *fmt, ...) {
+	char buf[512];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof buf, fmt, ap);
+	va_end(ap);
+	if (h) h->err = buf;
+	else g_create_error = buf;
+	return code;
+}
+
+#define HIP_TRY(h, call)                                                                                   \
+	do {                                                                                                   \
+		hipError_t e_ = (call);                                                                            \
+		if (e_ != hipSuccess) return fail(h, e_ == hipErrorOutOfMemory ? RG_ERR_NOMEM : RG_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+	} while (0)
+
+static int grid_for(uint64_t items) {
+	uint64_t b = (items + BLOCK - 1) / BLOCK;
+	if (b < 1) b = 1;
+	if (b > 256 * 8) b = 256 * 8;  // 256 CUs x 8 workgroups, grid-stride the rest
+	return (int)b;
+}
+
+static uint64_t next_pow2(uint64_t x) {
+	uint64_t p = 1;
+	while (p < x) p <<= 1;
+	return p;
+}
+
+static int sync_counters(rg_handle *h) {
+	HIP_TRY(h, hipMemcpyAsync(h->h_counters, h->d_counters, sizeof(unsigned long long) * C_NUM, hipMemcpyDeviceToHost, h->stream));
+	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	if (h->h_counters[C_ERR]) return fail(h, RG_ERR_CAPACITY, "table probe limit reached (table full?)");
+	return RG_OK;
+}
+
+static int table_alloc(rg_handle *h, Table &t, uint64_t cap) {
+	HIP_TRY(h, hipMalloc((void **)&t.slots, cap * sizeof(Slot)));
+	t.cap = cap;
+	hipLaunchKernelGGL(k_init_table, dim3(grid_for(cap)), dim3(BLOCK), 0, h->stream, t.slots, cap);
+	HIP_TRY(h, hipGetLastError());
+	return RG_OK;
+}
+
+static void table_free(Table &t) {
+	if (t.slots) (void)hipFree(t.slots);
+	t = Table();
+}
+
+// make room for `need` more keys at a load factor of at most 0.7
+static int table_reserve(rg_handle *h, Table &t, uint64_t need, int fill_counter) {
+	const double LF = 0.7;
+	if (!t.slots) {
+		uint64_t cap = next_pow2((uint64_t)((double)need / LF) + 1);
+		if (cap < 1024) cap = 1024;
+		if (h->cfg.table_slots && &t == &h->tab && cap < next_pow2(h->cfg.table_slots)) cap = next_pow2(h->cfg.table_slots);
+		int rc = table_alloc(h, t, cap);
+		if (rc) return rc;
+		t.fill_known = t.fill_pending = 0;
+		return RG_OK;
+	}
+	if ((double)(t.fill_known + t.fill_pending + need) <= LF * (double)t.cap) return RG_OK;
+	int rc = sync_counters(h);
+	if (rc) return rc;
+	t.fill_known = h->h_counters[fill_counter];
+	t.fill_pending = 0;
+	if ((double)(t.fill_known + need) <= LF * (double)t.cap) return RG_OK;
+	uint64_t cap = next_pow2((uint64_t)((double)(t.fill_known + need) / LF) + 1);
+	Table bigger;
+	rc = table_alloc(h, bigger, cap);
+	if (rc) return rc;
+	if (h->W == 1) hipLaunchKernelGGL(k_rehash<1>, dim3(grid_for(t.cap)), dim3(BLOCK), 0, h->stream, t.slots, t.cap, bigger.slots, cap - 1, h->d_counters);
+	else hipLaunchKernelGGL(k_rehash<2>, dim3(grid_for(t.cap)), dim3(BLOCK), 0, h->stream, t.slots, t.cap, bigger.slots, cap - 1, h->d_counters);
+	HIP_TRY(h, hipGetLastError());
+	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	(void)hipFree(t.slots);
+	t.slots = bigger.slots;
+	t.cap = cap;
+	return RG_OK;
+}
+
+extern "C" {
+
+const char *rg_version(void) { return "raygraph-mi355x 0.1 (gfx950)"; }
+
+const char *rg_last_error(const rg_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int rg_create(const rg_config *cfg, rg_handle **out) {
+	if (!cfg || !out) return fail(nullptr, RG_ERR_ARG, "null argument");
+	*out = nullptr;
+	int W = cfg->kmer_words;
+	if (W == 0) W = cfg->k <= 31 ? 1 : 2;
+	if (W != 1 && W != 2) return fail(nullptr, RG_ERR_ARG, "kmer_words must be 0, 1 or 2");
+	if (cfg->k < 1 || (cfg->k % 2) == 0 || cfg->k > 32 * W - 1)
+		return fail(nullptr, RG_ERR_ARG, "k=%d must be odd and within 1..%d for %d-word k-mers", cfg->k, 32 * W - 1, W);
+	if (cfg->size < 1 || cfg->rank < 0 || cfg->rank >= cfg->size) return fail(nullptr, RG_ERR_ARG, "bad rank/size %d/%d", cfg->rank, cfg->size);
+	int ndev = 0;
+	hipError_t e = hipGetDeviceCount(&ndev);
+	if (e != hipSuccess || ndev <= 0) return fail(nullptr, RG_ERR_HIP, "no HIP device available (%s); this library has no CPU path", hipGetErrorString(e));
+	if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, RG_ERR_ARG, "device %d out of range (have %d)", cfg->device, ndev);
+	e = hipSetDevice(cfg->device);
+	if (e != hipSuccess) return fail(nullptr, RG_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+	rg_handle *h = new rg_handle();
+	h->cfg = *cfg;
+	h->W = W;
+	if (cfg->stream) h->stream = (hipStream_t)cfg->stream;
+	else {
+		e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+		if (e != hipSuccess) {
+			delete h;
+			return fail(nullptr, RG_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+		}
+		h->own_stream = true;
+	}
+	if (hipMalloc((void **)&h->d_counters, sizeof(unsigned long long) * C_NUM) != hipSuccess ||
+	    hipHostMalloc((void **)&h->h_counters, sizeof(unsigned long long) * C_NUM) != hipSuccess ||
+	    hipMalloc((void **)&h->d_owner, sizeof(unsigned long long) * 2 * (size_t)cfg->size) != hipSuccess) {
+		rg_destroy(h);
+		return fail(nullptr, RG_ERR_NOMEM, "allocating counters failed");
+	}
+	(void)hipMemsetAsync(h->d_counters, 0, sizeof(unsigned long long) * C_NUM, h->stream);
+	h->owner_counts.assign((size_t)cfg->size, 0);
+	*out = h;
+	return RG_OK;
+}
+
+int rg_destroy(rg_handle *h) {
+	if (!h) return RG_OK;
+	(void)hipSetDevice(h->cfg.device);
+	if (h->stream) (void)hipStreamSynchronize(h->stream);
+	for (auto &p : h->sweep_events) {
+		(void)hipEventDestroy(p.first);
+		(void)hipEventDestroy(p.second);
+	}
+	for (auto &b : h->reads)
+		if (b.owned) {
+			(void)hipFree((void *)b.d_packed);
+			(void)hipFree((void *)b.d_off);
+			(void)hipFree((void *)b.d_len);
+		}
+	table_free(h->tab);
+	table_free(h->local);
+	if (h->d_counters) (void)hipFree(h->d_counters);
+	if (h->h_counters) (void)hipHostFree(h->h_counters);
+	if (h->d_owner) (void)hipFree(h->d_owner);
+	if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+	delete h;
+	return RG_OK;
+}
+
+int rg_add_reads(rg_handle *h, const uint8_t *packed, uint64_t packed_bytes, const uint64_t *byte_offsets,
+                 const uint32_t *lengths, uint64_t n_reads) {
+	if (!h) return RG_ERR_ARG;
+	if (h->phase != PH_CREATED) return fail(h, RG_ERR_STATE, "reads must be added before counting");
+	if (n_reads == 0) return RG_OK;
+	if (!packed || !byte_offsets || !lengths) return fail(h, RG_ERR_ARG, "null read arrays");
+	uint32_t maxlen = 0;
+	for (uint64_t i = 0; i < n_reads; ++i) {
+		if (lengths[i] > 65535u) return fail(h, RG_ERR_ARG, "read %llu longer than 65535", (unsigned long long)i);
+		if (byte_offsets[i] + (lengths[i] + 3) / 4 > packed_bytes) return fail(h, RG_ERR_ARG, "read %llu outside the packed buffer", (unsigned long long)i);
+		maxlen = std::max(maxlen, lengths[i]);
+	}
+	HIP_TRY(h, hipSetDevice(h->cfg.device));
+	ReadBatch b;
+	uint64_t padded = ((packed_bytes + 7) / 8) * 8 + 16;
+	void *dp = nullptr, *dof = nullptr, *dl = nullptr;
+	HIP_TRY(h, hipMalloc(&dp, padded));
+	HIP_TRY(h, hipMalloc(&dof, n_reads * sizeof(uint64_t)));
+	HIP_TRY(h, hipMalloc(&dl, n_reads * sizeof(uint32_t)));
+	HIP_TRY(h, hipMemsetAsync((uint8_t *)dp + (padded - 24), 0, 24, h->stream));
+	HIP_TRY(h, hipMemcpyAsync(dp, packed, packed_bytes, hipMemcpyHostToDevice, h->stream));
+	HIP_TRY(h, hipMemcpyAsync(dof, byte_offsets, n_reads * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
+	HIP_TRY(h, hipMemcpyAsync(dl, lengths, n_reads * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	b.d_packed = (const uint64_t *)dp;
+	b.d_off = (const uint64_t *)dof;
+	b.d_len = (const uint32_t *)dl;
+	b.n = n_reads;
+	b.first_id = h->cfg.first_read_id + h->n_reads;
+	b.maxlen = maxlen;
+	b.owned = true;
+	h->reads.push_back(b);
+	h->n_reads += n_reads;
+	return RG_OK;
+}
+
+int rg_add_reads_device(rg_handle *h, const void *d_packed, uint64_t packed_bytes, const void *d_byte_offsets,
+                        const void *d_lengths, uint64_t n_reads, uint32_t max_length) {
+	if (!h) return RG_ERR_ARG;
+	if (h->phase != PH_CREATED) return fail(h, RG_ERR_STATE, "reads must be added before counting");
+	if (n_reads == 0) return RG_OK;
+	if (!d_packed || !d_byte_offsets || !d_lengths) return fail(h, RG_ERR_ARG, "null read arrays");
+	if (((uintptr_t)d_packed & 7) != 0) return fail(h, RG_ERR_ARG, "device packed buffer must be 8-byte aligned");
+	if (max_length > 65535u) return fail(h, RG_ERR_ARG, "max_length above 65535");
+	(void)packed_bytes;
+	ReadBatch b;
+	b.d_packed = (const uint64_t *)d_packed;
+	b.d_off = (const uint64_t *)d_byte_offsets;
+	b.d_len = (const uint32_t *)d_lengths;
+	b.n = n_reads;
+	b.first_id = h->cfg.first_read_id + h->n_reads;
+	b.maxlen = max_length;
+	b.owned = false;
+	h->reads.push_back(b);
+	h->n_reads += n_reads;
+	return RG_OK;
+}
+
+int rg_count_local(rg_handle *h) {
+	if (!h) return RG_ERR_ARG;
+	if (h->phase != PH_CREATED) return fail(h, RG_ERR_STATE, "rg_count_local called twice");
+	HIP_TRY(h, hipSetDevice(h->cfg.device));
+	const bool single = h->cfg.size == 1;
+	Table &T = single ? h->tab : h->local;
+	const int fill_counter = single ? C_FILL : C_FILL_LOCAL;
+	const int k = h->cfg.k;
+	const uint64_t LAUNCH_OCC = 1ull << 27;  // k-mer occurrences per launch (bounds table growth)
+	for (const ReadBatch &b : h->reads) {
+		if (b.maxlen < (uint32_t)k) continue;
+		const uint64_t per_read = (uint64_t)b.maxlen - (uint64_t)k + 1;
+		uint64_t reads_per_launch = std::max<uint64_t>(TILE_READS, LAUNCH_OCC / per_read);
+		reads_per_launch = (reads_per_launch / TILE_READS) * TILE_READS;
+		for (uint64_t r0 = 0; r0 < b.n; r0 += reads_per_launch) {
+			uint64_t r1 = std::min(b.n, r0 + reads_per_launch);
+			uint64_t bound = (r1 - r0) * per_read;
+			int rc = table_reserve(h, T, bound, fill_counter);
+			if (rc) return rc;
+			uint64_t ntiles = (r1 - r0 + TILE_READS - 1) / TILE_READS;
+			int grid = (int)std::min<uint64_t>(ntiles, 256 * 8);
+			hipEvent_t ev0 = nullptr, ev1 = nullptr;
+			if (h->profiling) {
+				HIP_TRY(h, hipEventCreate(&ev0));
+				HIP_TRY(h, hipEventCreate(&ev1));
+				HIP_TRY(h, hipEventRecord(ev0, h->stream));
+			}
+			if (h->W == 1)
+				hipLaunchKernelGGL(k_count<1>, dim3(grid), dim3(BLOCK), 0, h->stream, b.d_packed, b.d_off, b.d_len, r0, r1,
+				                   b.first_id + r0, k, T.slots, T.cap - 1, h->d_counters, fill_counter);
+			else
+				hipLaunchKernelGGL(k_count<2>, dim3(grid), dim3(BLOCK), 0, h->stream, b.d_packed, b.d_off, b.d_len, r0, r1,
+				                   b.first_id + r0, k, T.slots, T.cap - 1, h->d_counters, fill_counter);
+			HIP_TRY(h, hipGetLastError());
+			if (h->profiling) {
+				HIP_TRY(h, hipEventRecord(ev1, h->stream));
+				h->sweep_events.emplace_back(ev0, ev1);
+			}
+			T.fill_pending += bound;
+		}
+	}
+	if (!T.slots) {  // no read long enough: keep an empty table so later phases work
+		int rc = table_reserve(h, T, 1, fill_counter);
+		if (rc) return rc;
+	}
+	int rc = sync_counters(h);
+	if (rc) return rc;
+	T.fill_known = h->h_counters[fill_counter];
+	T.fill_pending = 0;
+	h->stats.reads = h->n_reads;
+	h->stats.occurrences = h->h_counters[C_OCC];
+	h->phase = PH_COUNTED_LOCAL;
+	return RG_OK;
+}
+
+int rg_owner_counts(rg_handle *h, uint64_t *counts) {
+	if (!h || !counts) return RG_ERR_ARG;
+	if (h->phase != PH_COUNTED_LOCAL) return fail(h, RG_ERR_STATE, "rg_owner_counts needs rg_count_local first");
+	HIP_TRY(h, hipSetDevice(h->cfg.device));
+	const uint32_t size = (uint32_t)h->cfg.size;
+	Table &T = size == 1 ? h->tab : h->local;
+	HIP_TRY(h, hipMemsetAsync(h->d_owner, 0, sizeof(unsigned long long) * 2 * size, h->stream));
+	if (h->W == 1) hipLaunchKernelGGL(k_owner_counts<1>, dim3(grid_for(T.cap)), dim3(BLOCK), size * sizeof(uint32_t), h->stream, T.slots, T.cap, size, h->d_owner);
+	else hipLaunchKernelGGL(k_owner_counts<2>, dim3(grid_for(T.cap)), dim3(BLOCK), size * sizeof(uint32_t), h->stream, T.slots, T.cap, size, h->d_owner);
+	HIP_TRY(h, hipGetLastError());
+	std::vector<unsigned long long> tmp(size);
+	HIP_TRY(h, hipMemcpyAsync(tmp.data(), h->d_owner, sizeof(unsigned long long) * size, hipMemcpyDeviceToHost, h->stream));
+	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	for (uint32_t r = 0; r < size; ++r) h->owner_counts[r] = counts[r] = tmp[r];
+	return RG_OK;
+}
+
+int rg_export_owner_buckets(rg_handle *h, void *d_out, uint64_t capacity_entries) {
+	if (!h) return RG_ERR_ARG;
+	if (h->phase != PH_COUNTED_LOCAL) return fail(h, RG_ERR_STATE, "rg_export_owner_buckets needs rg_count_local first");
+	HIP_TRY(h, hipSetDevice(h->cfg.device));
+	const uint32_t size = (uint32_t)h->cfg.size;
+	Table &T = size == 1 ? h->tab : h->local;
+	std::vector<unsigned long long> cursors(size);
+	uint64_t total = 0;
+	for (uint32_t r = 0; r < size; ++r) {
+		cursors[r] = total;
+		total += h->owner_counts[r];
+	}
+	if (total > capacity_entries) return fail(h, RG_ERR_CAPACITY, "bucket buffer holds %llu entries, need %llu", (unsigned long long)capacity_entries, (unsigned long long)total);
+	if (total == 0) return RG_OK;
+	if (!d_out) return fail(h, RG_ERR_ARG, "null bucket buffer");
+	HIP_TRY(h, hipMemcpyAsync(h->d_owner + size, cursors.data(), sizeof(unsigned long long) * size, hipMemcpyHostToDevice, h->stream));
+	if (h->W == 1) hipLaunchKernelGGL(k_owner_scatter<1>, dim3(grid_for(T.cap)), dim3(BLOCK), 0, h->stream, T.slots, T.cap, size, h->d_owner + size, (Slot *)d_out);
+	else hipLaunchKernelGGL(k_owner_scatter<2>, dim3(grid_for(T.cap)), dim3(BLOCK), 0, h->stream, T.slots, T.cap, size, h->d_owner + size, (Slot *)d_out);
+	HIP_TRY(h, hipGetLastError());
+	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	return RG_OK;
+}
+
+int rg_merge_entries(rg_handle *h, const void *d_entries, uint64_t n_entries) {
+	if (!h) return RG_ERR_ARG;
+	if (h->phase != PH_COUNTED_LOCAL && h->phase != PH_MERGING) return fail(h, RG_ERR_STATE, "rg_merge_entries needs rg_count_local first");
+	if (h->cfg.size == 1) return fail(h, RG_ERR_STATE, "rg_merge_entries is for size > 1 (the local table is already the partition)");
+	HIP_TRY(h, hipSetDevice(h->cfg.device));
+	if (h->phase == PH_COUNTED_LOCAL) {
+		table_free(h->local);  // the buckets hold everything the local table knew
+		h->phase = PH_MERGING;
+	}
+	if (n_entries == 0) return RG_OK;
+	if (!d_entries) return fail(h, RG_ERR_ARG, "null entries");
+	int rc = table_reserve(h, h->tab, n_entries, C_FILL);
+	if (rc) return rc;
+	if (h->W == 1) hipLaunchKernelGGL(k_merge<1>, dim3(grid_for(n_entries)), dim3(BLOCK), 0, h->stream, (const Slot *)d_entries, n_entries, h->tab.slots, h->tab.cap - 1, h->d_counters);
+	else hipLaunchKernelGGL(k_merge<2>, dim3(grid_for(n_entries)), dim3(BLOCK), 0, h->stream, (const Slot *)d_entries, n_entries, h->tab.slots, h->tab.cap - 1, h->d_counters);
+	HIP_TRY(h, hipGetLastError());
+	h->tab.fill_pending += n_entries;
+	HIP_TRY(h, hipStreamSynchronize(h->stream));  // the caller may now reuse d_entries
+	return RG_OK;
+}
+
+int rg_resolve_admission(rg_handle *h, uint64_t local_reads_for_bloom) {
+	if (!h) return RG_ERR_ARG;
+	if (h->cfg.size == 1) {
+		if (h->phase != PH_COUNTED_LOCAL) return fail(h, RG_ERR_STATE, "rg_resolve_admission needs rg_count_local first");
+	} else {
+		if (h->phase != PH_MERGING && h->phase != PH_COUNTED_LOCAL) return fail(h, RG_ERR_STATE, "rg_resolve_admission needs rg_merge_entries first");
+		if (h->phase == PH_COUNTED_LOCAL) table_free(h->local);
+	}
+	HIP_TRY(h, hipSetDevice(h->cfg.device));
+	Table &T = h->tab;
+	if (!T.slots) {
+		int rc = table_reserve(h, T, 1, C_FILL);
+		if (rc) return rc;
+	}
+	// MessageProcessor.cpp:886-899 + VerticesExtractor.cpp:276-320
+	uint64_t m_bits = h->cfg.bloom_bits;
+	if (m_bits == RG_BLOOM_DEFAULT) {
+		uint64_t reads = local_reads_for_bloom == ~(uint64_t)0 ? h->n_reads : local_reads_for_bloom;
+		m_bits = 4ull * ((uint64_t)h->cfg.k * 2 * 2) * reads;
+		const uint64_t maximumBits = 1024ull * 1024 * 1024 * 8;
+		if (m_bits > maximumBits) m_bits = maximumBits;
+	}
+	h->stats.bloom_bits = m_bits;
+	const int grid = grid_for(T.cap);
+	if (m_bits > 0) {
+		unsigned long long *bitstamp = nullptr;
+		HIP_TRY(h, hipMalloc((void **)&bitstamp, m_bits * sizeof(unsigned long long)));
+		hipError_t e = hipMemsetAsync(bitstamp, 0xFF, m_bits * sizeof(unsigned long long), h->stream);
+		if (e == hipSuccess) {
+			if (h->W == 1) {
+				hipLaunchKernelGGL(k_bloom_touch<1>, dim3(grid), dim3(BLOCK), 0, h->stream, T.slots, T.cap, m_bits, bitstamp, h->d_counters);
+				hipLaunchKernelGGL((k_admit<1, true>), dim3(grid), dim3(BLOCK), 0, h->stream, T.slots, T.cap, m_bits, bitstamp, h->d_counters);
+			} else {
+				hipLaunchKernelGGL(k_bloom_touch<2>, dim3(grid), dim3(BLOCK), 0, h->stream, T.slots, T.cap, m_bits, bitstamp, h->d_counters);
+				hipLaunchKernelGGL((k_admit<2, true>), dim3(grid), dim3(BLOCK), 0, h->stream, T.slots, T.cap, m_bits, bitstamp, h->d_counters);
+			}
+			e = hipGetLastError();
+		}
+		hipError_t e2 = hipStreamSynchronize(h->stream);
+		(void)hipFree(bitstamp);  // the reference destroys its filter here too (MessageProcessor.cpp:1010)
+		if (e != hipSuccess) return fail(h, RG_ERR_HIP, "Bloom resolution failed: %s", hipGetErrorString(e));
+		if (e2 != hipSuccess) return fail(h, RG_ERR_HIP, "Bloom resolution failed: %s", hipGetErrorString(e2));
+	} else {
+		if (h->W == 1) hipLaunchKernelGGL((k_admit<1, false>), dim3(grid), dim3(BLOCK), 0, h->stream, T.slots, T.cap, 0ull, (const unsigned long long *)nullptr, h->d_counters);
+		else hipLaunchKernelGGL((k_admit<2, false>), dim3(grid), dim3(BLOCK), 0, h->stream, T.slots, T.cap, 0ull, (const unsigned long long *)nullptr, h->d_counters);
+		HIP_TRY(h, hipGetLastError());
+	}
+	int rc = sync_counters(h);
+	if (rc) return rc;
+	T.fill_known = h->h_counters[C_FILL];
+	T.fill_pending = 0;
+	h->stats.candidates = h->h_counters[C_FILL];
+	h->stats.stored_pairs = h->h_counters[C_RETAINED];
+	h->stats.bloom_insertions = h->h_counters[C_INSERTIONS];
+	h->stats.bloom_set_bits = h->h_counters[C_SETBITS];
+	h->stats.table_slots = T.cap;
+	h->phase = PH_RESOLVED;
+	return RG_OK;
+}
+
+int rg_count_kmers(rg_handle *h) {
+	if (!h) return RG_ERR_ARG;
+	if (h->cfg.size != 1) return fail(h, RG_ERR_STATE, "rg_count_kmers is the size==1 shortcut; use the decomposed calls with size > 1");
+	int rc = rg_count_local(h);
+	if (rc) return rc;
+	return rg_resolve_admission(h, ~(uint64_t)0);
+}
+
+int rg_histogram(rg_handle *h, uint32_t *coverage, uint64_t *count, uint64_t cap, uint64_t *n) {
+	if (!h || !n) return RG_ERR_ARG;
+	if (h->phase < PH_RESOLVED) return fail(h, RG_ERR_STATE, "rg_histogram needs the k-mer count first");
+	HIP_TRY(h, hipSetDevice(h->cfg.device));
+	unsigned long long *dense = nullptr;
+	uint32_t *ovf = nullptr;
+	HIP_TRY(h, hipMalloc((void **)&dense, HIST_DENSE * sizeof(unsigned long long)));
+	HIP_TRY(h, hipMalloc((void **)&ovf, HIST_OVF_CAP * sizeof(uint32_t)));
+	HIP_TRY(h, hipMemsetAsync(dense, 0, HIST_DENSE * sizeof(unsigned long long), h->stream));
+	HIP_TRY(h, hipMemsetAsync(h->d_counters + C_OVF, 0, sizeof(unsigned long long), h->stream));
+	hipLaunchKernelGGL(k_histogram, dim3(grid_for(h->tab.cap)), dim3(BLOCK), 0, h->stream, h->tab.slots, h->tab.cap, dense, ovf, h->d_counters);
+	HIP_TRY(h, hipGetLastError());
+	std::vector<unsigned long long> hd(HIST_DENSE);
+	HIP_TRY(h, hipMemcpyAsync(hd.data(), dense, HIST_DENSE * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+	int rc = sync_counters(h);
+	if (rc) {
+		(void)hipFree(dense);
+		(void)hipFree(ovf);
+		return rc;
+	}
+	uint64_t novf = h->h_counters[C_OVF];
+	std::vector<uint32_t> ho;
+	if (novf > HIST_OVF_CAP) {
+		(void)hipFree(dense);
+		(void)hipFree(ovf);
+		return fail(h, RG_ERR_CAPACITY, "more than %u vertices with coverage >= %u", HIST_OVF_CAP, HIST_DENSE);
+	}
+	if (novf) {
+		ho.resize(novf);
+		HIP_TRY(h, hipMemcpy(ho.data(), ovf, novf * sizeof(uint32_t), hipMemcpyDeviceToHost));
+		std::sort(ho.begin(), ho.end());
+	}
+	(void)hipFree(dense);
+	(void)hipFree(ovf);
+	uint64_t m = 0;
+	auto emit = [&](uint32_t c, uint64_t pairs) {
+		if (m < cap && coverage && count) {
+			coverage[m] = c;
+			count[m] = 2 * pairs;  // GridTableIterator visits the key and its reverse complement
+		}
+		m++;
+	};
+	for (uint32_t c = 0; c < HIST_DENSE; ++c)
+		if (hd[c]) emit(c, hd[c]);
+	for (size_t i = 0; i < ho.size();) {
+		size_t e = i;
+		while (e < ho.size() && ho[e] == ho[i]) e++;
+		emit(ho[i], e - i);
+		i = e;
+	}
+	*n = m;
+	return RG_OK;
+}
+
+int rg_add_edges(rg_handle *h) {
+	if (!h) return RG_ERR_ARG;
+	if (h->phase != PH_RESOLVED) return fail(h, RG_ERR_STATE, "rg_add_edges needs the k-mer count first (and runs once)");
+	HIP_TRY(h, hipSetDevice(h->cfg.device));
+	hipLaunchKernelGGL(k_publish_edges, dim3(grid_for(h->tab.cap)), dim3(BLOCK), 0, h->stream, h->tab.slots, h->tab.cap);
+	HIP_TRY(h, hipGetLastError());
+	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	h->phase = PH_EDGES;
+	return RG_OK;
+}
+
+int rg_purge_edges(rg_handle *h) {
+	if (!h) return RG_ERR_ARG;
+	if (h->phase != PH_EDGES) return fail(h, RG_ERR_STATE, "rg_purge_edges needs rg_add_edges first (and runs once)");
+	if (h->cfg.size != 1) return fail(h, RG_ERR_STATE, "rg_purge_edges supports size == 1 only in this version");
+	HIP_TRY(h, hipSetDevice(h->cfg.device));
+	if (h->W == 1) hipLaunchKernelGGL(k_purge<1>, dim3(grid_for(h->tab.cap)), dim3(BLOCK), 0, h->stream, h->tab.slots, h->tab.cap, h->cfg.k);
+	else hipLaunchKernelGGL(k_purge<2>, dim3(grid_for(h->tab.cap)), dim3(BLOCK), 0, h->stream, h->tab.slots, h->tab.cap, h->cfg.k);
+	HIP_TRY(h, hipGetLastError());
+	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	h->phase = PH_PURGED;
+	return RG_OK;
+}
+
+int rg_size(rg_handle *h, uint64_t *size) {
+	if (!h || !size) return RG_ERR_ARG;
+	if (h->phase < PH_RESOLVED) return fail(h, RG_ERR_STATE, "rg_size needs the k-mer count first");
+	*size = 2 * h->stats.stored_pairs;
+	return RG_OK;
+}
+
+int rg_export(rg_handle *h, void *host_buf, uint64_t cap_records, uint64_t *n_records) {
+	if (!h || !n_records) return RG_ERR_ARG;
+	if (h->phase < PH_RESOLVED) return fail(h, RG_ERR_STATE, "rg_export needs the k-mer count first");
+	const uint64_t n = h->stats.stored_pairs;
+	*n_records = n;
+	if (!host_buf || cap_records == 0 || n == 0) return RG_OK;
+	if (cap_records < n) return fail(h, RG_ERR_CAPACITY, "export buffer holds %llu records, need %llu", (unsigned long long)cap_records, (unsigned long long)n);
+	HIP_TRY(h, hipSetDevice(h->cfg.device));
+	const uint64_t rec = (uint64_t)h->W * 8 + 5;
+	const uint64_t cap = h->tab.cap;
+	uint64_t nchunks = std::min<uint64_t>(2048, (cap + BLOCK - 1) / BLOCK);
+	uint64_t chunk = (cap + nchunks - 1) / nchunks;
+	nchunks = (cap + chunk - 1) / chunk;
+	unsigned long long *d_chunk = nullptr;
+	uint8_t *d_out = nullptr;
+	HIP_TRY(h, hipMalloc((void **)&d_chunk, nchunks * sizeof(unsigned long long)));
+	HIP_TRY(h, hipMalloc((void **)&d_out, n * rec));
+	hipLaunchKernelGGL(k_export_count, dim3((int)nchunks), dim3(BLOCK), 0, h->stream, h->tab.slots, cap, chunk, d_chunk);
+	std::vector<unsigned long long> hc(nchunks);
+	HIP_TRY(h, hipMemcpyAsync(hc.data(), d_chunk, nchunks * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	unsigned long long run = 0;
+	for (auto &c : hc) {
+		unsigned long long t = c;
+		c = run;
+		run += t;
+	}
+	if (run != n) {
+		(void)hipFree(d_chunk);
+		(void)hipFree(d_out);
+		return fail(h, RG_ERR_STATE, "export found %llu stored pairs, expected %llu", run, (unsigned long long)n);
+	}
+	HIP_TRY(h, hipMemcpyAsync(d_chunk, hc.data(), nchunks * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
+	if (h->W == 1) hipLaunchKernelGGL(k_export_write<1>, dim3((int)nchunks), dim3(BLOCK), 0, h->stream, h->tab.slots, cap, chunk, d_chunk, d_out);
+	else hipLaunchKernelGGL(k_export_write<2>, dim3((int)nchunks), dim3(BLOCK), 0, h->stream, h->tab.slots, cap, chunk, d_chunk, d_out);
+	hipError_t e = hipGetLastError();
+	if (e == hipSuccess) e = hipMemcpyAsync(host_buf, d_out, n * rec, hipMemcpyDeviceToHost, h->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+	(void)hipFree(d_chunk);
+	(void)hipFree(d_out);
+	if (e != hipSuccess) return fail(h, RG_ERR_HIP, "export failed: %s", hipGetErrorString(e));
+	return RG_OK;
+}
+
+int rg_find(rg_handle *h, const uint64_t *kmers, uint64_t n, uint32_t *coverage, uint8_t *edges) {
+	if (!h) return RG_ERR_ARG;
+	if (h->phase < PH_RESOLVED) return fail(h, RG_ERR_STATE, "rg_find needs the k-mer count first");
+	if (n == 0) return RG_OK;
+	if (!kmers || !coverage || !edges) return fail(h, RG_ERR_ARG, "null argument");
+	HIP_TRY(h, hipSetDevice(h->cfg.device));
+	uint64_t *dq = nullptr;
+	uint32_t *dc = nullptr;
+	uint8_t *de = nullptr;
+	HIP_TRY(h, hipMalloc((void **)&dq, n * h->W * sizeof(uint64_t)));
+	HIP_TRY(h, hipMalloc((void **)&dc, n * sizeof(uint32_t)));
+	HIP_TRY(h, hipMalloc((void **)&de, n));
+	hipError_t e = hipMemcpyAsync(dq, kmers, n * h->W * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream);
+	if (e == hipSuccess) {
+		if (h->W == 1) hipLaunchKernelGGL(k_find<1>, dim3(grid_for(n)), dim3(BLOCK), 0, h->stream, h->tab.slots, h->tab.cap, h->cfg.k, dq, n, dc, de);
+		else hipLaunchKernelGGL(k_find<2>, dim3(grid_for(n)), dim3(BLOCK), 0, h->stream, h->tab.slots, h->tab.cap, h->cfg.k, dq, n, dc, de);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipMemcpyAsync(coverage, dc, n * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(edges, de, n, hipMemcpyDeviceToHost, h->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+	(void)hipFree(dq);
+	(void)hipFree(dc);
+	(void)hipFree(de);
+	if (e != hipSuccess) return fail(h, RG_ERR_HIP, "find failed: %s", hipGetErrorString(e));
+	return RG_OK;
+}
+
+int rg_degree_distribution(rg_handle *h, uint64_t out[25]) {
+	if (!h || !out) return RG_ERR_ARG;
+	if (h->phase < PH_RESOLVED) return fail(h, RG_ERR_STATE, "rg_degree_distribution needs the k-mer count first");
+	HIP_TRY(h, hipSetDevice(h->cfg.device));
+	unsigned long long *d = nullptr;
+	HIP_TRY(h, hipMalloc((void **)&d, 25 * sizeof(unsigned long long)));
+	HIP_TRY(h, hipMemsetAsync(d, 0, 25 * sizeof(unsigned long long), h->stream));
+	hipLaunchKernelGGL(k_degrees, dim3(grid_for(h->tab.cap)), dim3(BLOCK), 0, h->stream, h->tab.slots, h->tab.cap, d);
+	unsigned long long tmp[25];
+	hipError_t e = hipMemcpyAsync(tmp, d, sizeof tmp, hipMemcpyDeviceToHost, h->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+	(void)hipFree(d);
+	if (e != hipSuccess) return fail(h, RG_ERR_HIP, "degree distribution failed: %s", hipGetErrorString(e));
+	for (int i = 0; i < 25; ++i) out[i] = tmp[i];
+	return RG_OK;
+}
+
+int rg_set_profiling(rg_handle *h, int enable) {
+	if (!h) return RG_ERR_ARG;
+	h->profiling = enable != 0;
+	return RG_OK;
+}
+
+int rg_get_sweep_time(rg_handle *h, double *total_ms, uint64_t *launches) {
+	if (!h || !total_ms || !launches) return RG_ERR_ARG;
+	HIP_TRY(h, hipSetDevice(h->cfg.device));
+	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	double ms = 0;
+	for (auto &p : h->sweep_events) {
+		float t = 0;
+		HIP_TRY(h, hipEventElapsedTime(&t, p.first, p.second));
+		ms += t;
+	}
+	*total_ms = ms;
+	*launches = h->sweep_events.size();
+	return RG_OK;
+}
+
+int rg_get_stats(rg_handle *h, rg_stats *out) {
+	if (!h || !out) return RG_ERR_ARG;
+	*out = h->stats;
+	out->reads = h->n_reads;
+	return RG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,78 @@
+"""Owner exchange between ranks: the one data-path collective of each pass.
+
+Replaces RayPlatform's per-message RAY_MPI_TAG_VERTICES_DATA / OUT_EDGES_DATA / IN_EDGES_DATA
+point-to-point traffic (KmerAcademyBuilder.cpp:187-196, VerticesExtractor.cpp:175-251) with one
+all-to-all(v) of per-owner buckets: every rank aggregates its own reads per canonical k-mer,
+groups the 32-byte entries by owner = hash1(lower) % size (Kmer.cpp:165-170), and the owners merge
+what they receive.  torch.distributed is plumbing only (backend "nccl" = RCCL over xGMI on the GPU
+box, "gloo" in the CPU tests); the entries are produced and consumed by the HIP library.
+
+`engine` is anything with the GraphBuilder exchange surface: size, owner_counts(),
+export_owner_buckets(ptr, capacity), merge_entries(ptr, n).
+"""
+import torch
+import torch.distributed as dist
+
+from ._lib import RG_ENTRY_BYTES
+
+
+def partition_reads(total_reads, rank, size):
+    """SequencesLoader.cpp:287-297: contiguous ranges of floor(T/size) reads, the last rank takes the rest."""
+    per = total_reads // size
+    first = rank * per
+    last = total_reads if rank == size - 1 else first + per
+    return first, last
+
+
+def exchange_owner_buckets(engine, group=None, device="cuda"):
+    """all-to-all(v) of the per-owner buckets; returns (entries sent, entries received)."""
+    size = engine.size
+    if size == 1:
+        return 0, 0  # the local table already is the partition; nothing moves
+    counts = engine.owner_counts()
+    total = sum(counts)
+    send = torch.empty(max(1, total) * RG_ENTRY_BYTES, dtype=torch.uint8, device=device)
+    engine.export_owner_buckets(send.data_ptr(), max(1, total))
+    send_counts = torch.tensor(counts, dtype=torch.int64, device=device)
+    recv_counts = torch.empty(size, dtype=torch.int64, device=device)
+    dist.all_to_all_single(recv_counts, send_counts, group=group)
+    recv_list = [int(x) for x in recv_counts.cpu().tolist()]
+    n_recv = sum(recv_list)
+    recv = torch.empty(max(1, n_recv) * RG_ENTRY_BYTES, dtype=torch.uint8, device=device)
+    dist.all_to_all_single(recv[: n_recv * RG_ENTRY_BYTES], send[: total * RG_ENTRY_BYTES],
+                           output_split_sizes=[c * RG_ENTRY_BYTES for c in recv_list],
+                           input_split_sizes=[c * RG_ENTRY_BYTES for c in counts], group=group)
+    if device != "cpu":
+        torch.cuda.current_stream().synchronize()
+    engine.merge_entries(recv.data_ptr(), n_recv)
+    return total, n_recv
+
+
+HIST_DENSE = 65536
+
+
+def reduce_histogram(cov, cnt, group=None, device="cuda", size=1):
+    """merge the ranks' (coverage, count) pairs like rank 0 does on RAY_MPI_TAG_COVERAGE_DATA
+    (MessageProcessor.cpp:1048-1061): a dense all-reduce for coverage < 65536, the rare tail by object
+    gather.  Every rank gets the merged, ascending arrays."""
+    import numpy as np
+    if size == 1:
+        return cov, cnt
+    dense = torch.zeros(HIST_DENSE, dtype=torch.int64)
+    low = cov < HIST_DENSE
+    dense[torch.from_numpy(cov[low].astype(np.int64))] = torch.from_numpy(cnt[low].astype(np.int64))
+    dense = dense.to(device)
+    dist.all_reduce(dense, op=dist.ReduceOp.SUM, group=group)
+    dense = dense.cpu().numpy()
+    tail = list(zip(cov[~low].tolist(), cnt[~low].tolist()))
+    tails = [None] * size
+    dist.all_gather_object(tails, tail, group=group)
+    merged = {}
+    for t in tails:
+        for c, n in t:
+            merged[c] = merged.get(c, 0) + n
+    idx = np.nonzero(dense)[0]
+    out_cov = np.concatenate([idx.astype(np.uint32), np.asarray(sorted(merged), dtype=np.uint32)])
+    out_cnt = np.concatenate([dense[idx].astype(np.uint64),
+                              np.asarray([merged[c] for c in sorted(merged)], dtype=np.uint64)])
+    return out_cov, out_cnt

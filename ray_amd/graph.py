@@ -1,0 +1,206 @@
+"""Thin object wrapper over the C ABI (include/raygraph.h).  No compute happens in Python."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import RG_BLOOM_DEFAULT, RG_ENTRY_BYTES, UINT64_MAX, RgConfig, RgStats
+
+
+class RayGraphError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("raygraph error %d: %s" % (code, message))
+        self.code = code
+
+
+def record_dtype(kmer_words):
+    """Vertex::dump layout (VerticesExtractor/Vertex.cpp:438-454): key words, u32 coverage, u8 edges."""
+    W = kmer_words
+    return np.dtype({"names": ["key", "coverage", "edges"], "formats": [("<u8", (W,)), "<u4", "u1"],
+                     "offsets": [0, W * 8, W * 8 + 4], "itemsize": W * 8 + 5})
+
+
+def pack_read(sequence, trim=True):
+    """Read::constructor packing (SequencesLoader/Read.cpp:31-159) -> (bytes, length)."""
+    L = _lib.load()
+    raw = sequence.encode()
+    buf = (C.c_uint8 * (len(raw) // 4 + 2))()
+    n = L.rg_pack_read(raw, 1 if trim else 0, buf)
+    if n < 0:
+        raise RayGraphError(n, "rg_pack_read")
+    return bytes(buf[: (n + 3) // 4]), n
+
+
+def pack_reads(sequences, trim=True):
+    """ArrayOfReads as the three flat arrays rg_add_reads takes."""
+    chunks, offsets, lengths, pos = [], [], [], 0
+    for s in sequences:
+        b, n = pack_read(s, trim)
+        chunks.append(b)
+        offsets.append(pos)
+        lengths.append(n)
+        pos += len(b)
+    packed = np.frombuffer(b"".join(chunks), dtype=np.uint8).copy() if pos else np.zeros(0, np.uint8)
+    return packed, np.asarray(offsets, dtype=np.uint64), np.asarray(lengths, dtype=np.uint32)
+
+
+def coverage_distribution(coverage, count, path=None):
+    """CoverageDistribution (CoverageGatherer/CoverageDistribution.cpp:33-112) -> (min, peak, repeat)."""
+    L = _lib.load()
+    cov = np.ascontiguousarray(coverage, dtype=np.uint32)
+    cnt = np.ascontiguousarray(count, dtype=np.uint64)
+    mn, pk, rp = C.c_int32(), C.c_int32(), C.c_int32()
+    rc = L.rg_coverage_distribution(cov.ctypes.data_as(C.POINTER(C.c_uint32)), cnt.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                    len(cov), path.encode() if path else None, C.byref(mn), C.byref(pk), C.byref(rp))
+    if rc != 0:
+        raise RayGraphError(rc, "no k-mers found in reads" if len(cov) == 0 else "rg_coverage_distribution")
+    return mn.value, pk.value, rp.value
+
+
+class GraphBuilder:
+    """One rank's share of the distributed de Bruijn graph on one GPU."""
+
+    def __init__(self, k, rank=0, size=1, device=0, bloom_bits=RG_BLOOM_DEFAULT, kmer_words=0, table_slots=0,
+                 first_read_id=0, stream=None):
+        self._L = _lib.load()
+        cfg = RgConfig(k=k, kmer_words=kmer_words, rank=rank, size=size, device=device, reserved0=0,
+                       bloom_bits=bloom_bits, table_slots=table_slots, first_read_id=first_read_id,
+                       stream=C.c_void_p(stream) if stream else None)
+        self._h = C.c_void_p()
+        rc = self._L.rg_create(C.byref(cfg), C.byref(self._h))
+        if rc != 0:
+            msg = self._L.rg_last_error(None).decode()
+            self._h = None
+            raise RayGraphError(rc, msg)
+        self.k, self.rank, self.size = k, rank, size
+        self.kmer_words = kmer_words if kmer_words else (1 if k <= 31 else 2)
+        self._keep = []
+
+    # -- plumbing
+    def _check(self, rc):
+        if rc != 0:
+            raise RayGraphError(rc, self._L.rg_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.rg_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- input
+    def add_reads(self, packed, offsets, lengths):
+        packed = np.ascontiguousarray(packed, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        lengths = np.ascontiguousarray(lengths, dtype=np.uint32)
+        self._check(self._L.rg_add_reads(self._h, packed.ctypes.data, packed.size, offsets.ctypes.data,
+                                         lengths.ctypes.data, lengths.size))
+
+    def add_reads_device(self, packed_ptr, packed_bytes, offsets_ptr, lengths_ptr, n_reads, max_length, keep=None):
+        """device-resident arrays (e.g. torch tensors' data_ptr()); `keep` pins their owners."""
+        if keep is not None:
+            self._keep.append(keep)
+        self._check(self._L.rg_add_reads_device(self._h, packed_ptr, packed_bytes, offsets_ptr, lengths_ptr, n_reads,
+                                                max_length))
+
+    # -- pass 1
+    def count_kmers(self):
+        self._check(self._L.rg_count_kmers(self._h))
+
+    def count_local(self):
+        self._check(self._L.rg_count_local(self._h))
+
+    def owner_counts(self):
+        out = (C.c_uint64 * self.size)()
+        self._check(self._L.rg_owner_counts(self._h, out))
+        return [int(x) for x in out]
+
+    def export_owner_buckets(self, device_ptr, capacity_entries):
+        self._check(self._L.rg_export_owner_buckets(self._h, device_ptr, capacity_entries))
+
+    def merge_entries(self, device_ptr, n_entries):
+        self._check(self._L.rg_merge_entries(self._h, device_ptr, n_entries))
+
+    def resolve_admission(self, local_reads=UINT64_MAX):
+        self._check(self._L.rg_resolve_admission(self._h, local_reads))
+
+    # -- histogram / pass 2 / purge
+    def histogram(self):
+        n = C.c_uint64()
+        self._check(self._L.rg_histogram(self._h, None, None, 0, C.byref(n)))
+        cov = np.zeros(max(1, n.value), dtype=np.uint32)
+        cnt = np.zeros(max(1, n.value), dtype=np.uint64)
+        m = C.c_uint64()
+        self._check(self._L.rg_histogram(self._h, cov.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                         cnt.ctypes.data_as(C.POINTER(C.c_uint64)), n.value, C.byref(m)))
+        return cov[: m.value], cnt[: m.value]
+
+    def add_edges(self):
+        self._check(self._L.rg_add_edges(self._h))
+
+    def purge_edges(self):
+        self._check(self._L.rg_purge_edges(self._h))
+
+    # -- the store
+    def size_(self):
+        n = C.c_uint64()
+        self._check(self._L.rg_size(self._h, C.byref(n)))
+        return n.value
+
+    def export(self, sort=True):
+        """stored vertices as a structured array (key, coverage, edges); sorted by key if asked."""
+        n = C.c_uint64()
+        self._check(self._L.rg_export(self._h, None, 0, C.byref(n)))
+        dt = record_dtype(self.kmer_words)
+        buf = np.zeros(max(1, n.value), dtype=dt)
+        m = C.c_uint64()
+        self._check(self._L.rg_export(self._h, buf.ctypes.data, n.value, C.byref(m)))
+        rec = buf[: m.value]
+        if sort and len(rec):
+            keys = rec["key"]
+            order = np.lexsort(tuple(keys[:, j] for j in reversed(range(self.kmer_words))))
+            rec = rec[order]
+        return rec
+
+    def find(self, kmers):
+        """bulk GridTable::find: kmers (n, kmer_words) uint64, either strand -> (coverage, edges)."""
+        q = np.ascontiguousarray(kmers, dtype=np.uint64).reshape(-1, self.kmer_words)
+        n = q.shape[0]
+        cov = np.zeros(n, dtype=np.uint32)
+        e = np.zeros(n, dtype=np.uint8)
+        self._check(self._L.rg_find(self._h, q.ctypes.data_as(C.POINTER(C.c_uint64)), n,
+                                    cov.ctypes.data_as(C.POINTER(C.c_uint32)), e.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return cov, e
+
+    def degree_distribution(self):
+        out = np.zeros(25, dtype=np.uint64)
+        self._check(self._L.rg_degree_distribution(self._h, out.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return out.reshape(5, 5)
+
+    def set_profiling(self, enable=True):
+        self._check(self._L.rg_set_profiling(self._h, 1 if enable else 0))
+
+    def sweep_time(self):
+        """(total ms, launches) of the k-mer sweep kernel, from HIP events on the launch stream"""
+        ms, n = C.c_double(), C.c_uint64()
+        self._check(self._L.rg_get_sweep_time(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def stats(self):
+        s = RgStats()
+        self._check(self._L.rg_get_stats(self._h, C.byref(s)))
+        return {n: int(getattr(s, n)) for n, _ in RgStats._fields_}
+
+
+__all__ = ["GraphBuilder", "RayGraphError", "record_dtype", "pack_read", "pack_reads", "coverage_distribution",
+           "RG_BLOOM_DEFAULT", "RG_ENTRY_BYTES"]

@@ -1,0 +1,65 @@
+"""shared by the parity tests: run the oracle and the HIP path on the same reads and compare everything"""
+import os
+
+import numpy as np
+
+
+def oracle_run(ro, packed, offsets, lengths, k, nranks=1, bloom_bits=None, W=None, purge=False):
+    g = ro.Graph(k, nranks=nranks, bloom_bits=ro.BLOOM_DEFAULT if bloom_bits is None else bloom_bits, W=W)
+    g.set_reads(packed, offsets, lengths)
+    g.count_kmers()
+    out = {"pass1": g.export(), "hist": g.histogram(), "size": g.size(), "occ": g.occurrences(),
+           "bloom": [(g.bloom_bits(r), g.bloom_set_bits(r), g.bloom_insertions(r)) for r in range(nranks)]}
+    g.add_edges()
+    out["pass2"] = g.export()
+    if purge:
+        g.purge_edges()
+        out["purged"] = g.export()
+        out["degrees"] = g.degree_distribution()
+        out["kmers_txt"] = g.kmers_txt()
+    out["graph"] = g
+    return out
+
+
+def assert_records_equal(a, b, what=""):
+    assert len(a) == len(b), "%s: %d vs %d records" % (what, len(a), len(b))
+    assert np.array_equal(a["key"], b["key"]), what + ": retained k-mer sets differ"
+    assert np.array_equal(a["coverage"], b["coverage"]), what + ": coverages differ"
+    assert np.array_equal(a["edges"], b["edges"]), what + ": edge bitmaps differ"
+
+
+def gpu_vs_oracle(ro, packed, offsets, lengths, k, bloom_bits=None, W=None, purge=True, batches=1, tmpdir=None):
+    """single-rank parity through the C ABI; returns the oracle outputs for further checks"""
+    import ray_amd
+    from ray_amd.graph import RG_BLOOM_DEFAULT
+    want = oracle_run(ro, packed, offsets, lengths, k, 1, bloom_bits, W, purge)
+    b = ray_amd.GraphBuilder(k, bloom_bits=RG_BLOOM_DEFAULT if bloom_bits is None else bloom_bits,
+                             kmer_words=W if W else 0)
+    n = len(lengths)
+    cuts = [n * i // batches for i in range(batches + 1)]
+    for i in range(batches):
+        lo, hi = cuts[i], cuts[i + 1]
+        if hi > lo:
+            b.add_reads(packed, offsets[lo:hi], lengths[lo:hi])
+    b.count_kmers()
+    st = b.stats()
+    assert st["occurrences"] == want["occ"]
+    assert b.size_() == want["size"]
+    assert_records_equal(b.export(), want["pass1"], "after pass 1")
+    cov, cnt = b.histogram()
+    assert np.array_equal(cov, want["hist"][0]) and np.array_equal(cnt, want["hist"][1]), "coverage histogram differs"
+    assert (st["bloom_bits"], st["bloom_set_bits"], st["bloom_insertions"]) == want["bloom"][0]
+    b.add_edges()
+    assert_records_equal(b.export(), want["pass2"], "after pass 2")
+    if purge:
+        b.purge_edges()
+        assert_records_equal(b.export(), want["purged"], "after purge")
+        assert np.array_equal(b.degree_distribution(), want["degrees"])
+    if tmpdir is not None and len(cov):
+        p1, p2 = os.path.join(tmpdir, "gpu.txt"), os.path.join(tmpdir, "ora.txt")
+        v1 = ray_amd.coverage_distribution(cov, cnt, p1)
+        v2 = ro.coverage_distribution(want["hist"][0], want["hist"][1], p2)
+        assert v1 == v2
+        assert open(p1, "rb").read() == open(p2, "rb").read(), "CoverageDistribution.txt differs"
+    want["builder"] = b
+    return want

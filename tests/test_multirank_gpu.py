@@ -1,0 +1,61 @@
+"""The owner exchange on real hardware without needing N GPUs: R GraphBuilders (rank r of R) share
+device 0 in one process and swap their per-owner buckets through device buffers, exactly the bytes an
+all-to-all would move.  Result must equal the R-rank oracle (Bloom filter per rank sized from that
+rank's own read count, arrival order = source rank order)."""
+import numpy as np
+import pytest
+
+from helpers import assert_records_equal, oracle_run
+from ray_amd.exchange import partition_reads
+from ray_amd.synth import make_reads_numpy
+
+pytestmark = pytest.mark.gpu
+
+
+def run_ranks(packed, offsets, lengths, k, nranks, bloom, W=0):
+    import torch
+    import ray_amd
+    from ray_amd.graph import RG_BLOOM_DEFAULT, RG_ENTRY_BYTES
+    n = len(lengths)
+    builders, sends = [], []
+    for r in range(nranks):
+        first, last = partition_reads(n, r, nranks)
+        b = ray_amd.GraphBuilder(k, rank=r, size=nranks, bloom_bits=RG_BLOOM_DEFAULT if bloom is None else bloom,
+                                 kmer_words=W, first_read_id=first)
+        b.add_reads(packed, offsets[first:last], lengths[first:last])
+        b.count_local()
+        counts = b.owner_counts()
+        buf = torch.empty(max(1, sum(counts)) * RG_ENTRY_BYTES, dtype=torch.uint8, device="cuda")
+        b.export_owner_buckets(buf.data_ptr(), max(1, sum(counts)))
+        torch.cuda.synchronize()
+        builders.append(b)
+        sends.append((counts, buf))
+    for dst, b in enumerate(builders):
+        for counts, buf in sends:
+            start = sum(counts[:dst])
+            part = buf[start * RG_ENTRY_BYTES:(start + counts[dst]) * RG_ENTRY_BYTES]
+            b.merge_entries(part.data_ptr(), counts[dst])
+    for r, b in enumerate(builders):
+        first, last = partition_reads(n, r, nranks)
+        b.resolve_admission(last - first)
+        b.add_edges()
+    return builders
+
+
+@pytest.mark.parametrize("k,nranks,bloom", [(31, 2, None), (31, 4, 60000), (31, 8, 0), (63, 2, 90000), (21, 3, 20000)])
+def test_multirank_matches_oracle(oracle, k, nranks, bloom):
+    packed, offsets, lengths = make_reads_numpy(genome=15000, read_len=100 if k < 63 else 150, n_reads=5001,
+                                                seed=k + nranks, error=0.015)
+    want = oracle_run(oracle, packed, offsets, lengths, k, nranks, bloom)
+    builders = run_ranks(packed, offsets, lengths, k, nranks, bloom)
+    for r, b in enumerate(builders):
+        assert_records_equal(b.export(), want["graph"].export(r), "rank %d" % r)
+        st = b.stats()
+        assert (st["bloom_bits"], st["bloom_set_bits"], st["bloom_insertions"]) == want["bloom"][r]
+    # merged histogram, as rank 0 accumulates RAY_MPI_TAG_COVERAGE_DATA (MessageProcessor.cpp:1048-1061)
+    merged = {}
+    for b in builders:
+        for c, n in zip(*b.histogram()):
+            merged[int(c)] = merged.get(int(c), 0) + int(n)
+    assert sorted(merged) == want["hist"][0].tolist()
+    assert [merged[c] for c in sorted(merged)] == want["hist"][1].tolist()

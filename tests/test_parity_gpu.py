@@ -1,0 +1,146 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the oracle on the same seeded
+reads.  Bit-exact bar: retained k-mer set, per-vertex coverage, edge bitmaps (before and after the
+purge), coverage histogram, CoverageDistribution.txt bytes, Bloom statistics, degree table."""
+import numpy as np
+import pytest
+
+from helpers import assert_records_equal, gpu_vs_oracle, oracle_run
+from ray_amd.synth import make_reads_numpy
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("k,read_len,bloom,error", [
+    (31, 100, None, 0.01),    # the default filter: 16*k*reads bits
+    (31, 100, 0, 0.01),       # -bloom-filter-bits 0: order-free mode, singletons kept
+    (31, 100, 200000, 0.02),  # squeezed filter: false positives are common
+    (31, 100, 4096, 0.02),    # saturated filter: nearly every first sight is a false positive
+    (21, 60, None, 0.005),
+    (63, 150, None, 0.01),    # two-word k-mers (MAXKMERLENGTH=64)
+    (63, 150, 300000, 0.02),
+    (33, 100, 0, 0.0),
+    (47, 100, 100000, 0.01),
+    (5, 30, 64, 0.0),         # tiny k: dense graph, every edge bit exercised
+    (15, 40, None, 0.0),
+])
+def test_graph_matches_oracle(oracle, tmp_path, k, read_len, bloom, error):
+    packed, offsets, lengths = make_reads_numpy(genome=20000, read_len=read_len, n_reads=6000, seed=k + int(bloom or 0),
+                                                error=error)
+    gpu_vs_oracle(oracle, packed, offsets, lengths, k, bloom_bits=bloom, tmpdir=str(tmp_path))
+
+
+def test_two_word_layout_with_short_k(oracle):
+    """a MAXKMERLENGTH=64 build running -k 31 hashes with the two-word formula (Kmer.cpp:287-293)"""
+    packed, offsets, lengths = make_reads_numpy(genome=8000, read_len=80, n_reads=2500, seed=5, error=0.01)
+    gpu_vs_oracle(oracle, packed, offsets, lengths, 31, bloom_bits=60000, W=2)
+
+
+def test_ragged_short_and_empty_reads(oracle, tmp_path):
+    """reads shorter than k are skipped (KmerAcademyBuilder.cpp:130-134); lengths 1..90; odd byte offsets"""
+    packed, offsets, lengths = make_reads_numpy(genome=6000, read_len=90, n_reads=5000, seed=9, error=0.01, ragged=True)
+    assert (lengths < 31).any() and (lengths % 4 != 0).any()
+    gpu_vs_oracle(oracle, packed, offsets, lengths, 31, bloom_bits=50000, tmpdir=str(tmp_path))
+    gpu_vs_oracle(oracle, packed, offsets, lengths, 21, bloom_bits=None)
+
+
+def test_reads_added_in_several_batches_and_table_growth(oracle):
+    """rg_add_reads may be called repeatedly; read ids (hence arrival stamps) continue, the table grows"""
+    packed, offsets, lengths = make_reads_numpy(genome=30000, read_len=100, n_reads=8000, seed=21, error=0.02)
+    want = gpu_vs_oracle(oracle, packed, offsets, lengths, 31, bloom_bits=150000, batches=7)
+    assert want["builder"].stats()["table_slots"] >= 2 * want["builder"].stats()["candidates"] * 0.7
+
+
+def test_no_reads_and_no_kmers():
+    import ray_amd
+    b = ray_amd.GraphBuilder(31)
+    b.count_kmers()
+    assert b.size_() == 0 and len(b.export()) == 0
+    cov, cnt = b.histogram()
+    assert len(cov) == 0
+    b.add_edges()
+    b.purge_edges()
+    with pytest.raises(ray_amd.RayGraphError):  # "Assembler panic: no k-mers found in reads"
+        ray_amd.coverage_distribution(cov, cnt)
+    packed, offsets, lengths = ray_amd.pack_reads(["ACGTACGT", "NNNN", "", "ACG"])
+    b = ray_amd.GraphBuilder(31)
+    b.add_reads(packed, offsets, lengths)
+    b.count_kmers()
+    assert b.size_() == 0 and b.stats()["occurrences"] == 0
+
+
+def test_reference_edge_bitmap_example():
+    """Vertex.h:84-115 through the GPU: ATGAC <- GATGA, -> TGACT / TGACA stores 0x94; GTCAT reads 0x29"""
+    import ray_amd
+    packed, offsets, lengths = ray_amd.pack_reads(["GATGACT", "GATGACA"])
+    b = ray_amd.GraphBuilder(5, bloom_bits=0)
+    b.add_reads(packed, offsets, lengths)
+    b.count_kmers()
+    b.add_edges()
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    word = lambda s: sum(code[c] << (2 * i) for i, c in enumerate(s))
+    cov, edges = b.find(np.array([[word("ATGAC")], [word("GTCAT")], [word("AAAAA")]], dtype=np.uint64))
+    assert cov.tolist() == [2, 2, 0]
+    assert edges.tolist() == [0x94, 0x29, 0]
+
+
+def test_phase_order_is_enforced():
+    import ray_amd
+    b = ray_amd.GraphBuilder(21)
+    for call in (b.histogram, b.add_edges, b.purge_edges, b.size_, b.export):
+        with pytest.raises(ray_amd.RayGraphError) as e:
+            call()
+        assert e.value.code == -4
+    b.count_kmers()
+    with pytest.raises(ray_amd.RayGraphError):
+        b.count_kmers()
+    with pytest.raises(ray_amd.RayGraphError):
+        b.purge_edges()  # needs rg_add_edges first
+
+
+def test_find_both_strands_and_kmers_txt(oracle, tmp_path):
+    packed, offsets, lengths = make_reads_numpy(genome=3000, read_len=70, n_reads=1500, seed=33, error=0.01)
+    want = gpu_vs_oracle(oracle, packed, offsets, lengths, 21, bloom_bits=30000)
+    b, g = want["builder"], want["graph"]
+    rec = want["purged"]
+    rng = np.random.default_rng(1)
+    pick = rec["key"][rng.integers(0, len(rec), 300)]
+    queries = []
+    for key in pick:
+        words = (int(key[0]), 0)
+        queries.append(words if rng.random() < 0.5 else oracle.complement_vertex(words, 21))
+    queries += [(int(x), 0) for x in rng.integers(0, 1 << 42, 200)]  # mostly absent
+    cov, edges = b.find(np.array([[q[0]] for q in queries], dtype=np.uint64))
+    for q, c, e in zip(queries, cov, edges):
+        found, wc, we = g.find(q)
+        assert (int(c), int(e)) == ((wc, we) if found else (0, 0))
+    from ray_amd.kmers_txt import body_lines
+    got = sorted(body_lines(b.export(), 21))
+    assert got == sorted(want["kmers_txt"].strip().split("\n"))
+
+
+def test_plugin_mirror_runs_the_master_mode_sequence(oracle, tmp_path):
+    import ray_amd
+    packed, offsets, lengths = make_reads_numpy(genome=5000, read_len=80, n_reads=3000, seed=44, error=0.01)
+    subgraph, (cov, cnt), values = ray_amd.build_graph(packed, offsets, lengths, k=22, prefix=str(tmp_path), write_kmers=True)
+    want = oracle_run(oracle, packed, offsets, lengths, 21, purge=True)  # even k becomes k-1 (Parameters.cpp:892-907)
+    assert subgraph.size() == want["size"]
+    assert_records_equal(subgraph.export(), want["purged"], "plugin mirror")
+    ref = str(tmp_path / "ref.txt")
+    assert values == oracle.coverage_distribution(want["hist"][0], want["hist"][1], ref)
+    assert open(str(tmp_path / "CoverageDistribution.txt"), "rb").read() == open(ref, "rb").read()
+    lines = open(str(tmp_path / "kmers.txt")).read().strip().split("\n")
+    assert lines[0] == "# Generated by Ray 2.3.2-devel" and len([l for l in lines if l.startswith("#")]) == 13
+    assert sorted(l for l in lines if not l.startswith("#")) == sorted(want["kmers_txt"].strip().split("\n"))
+
+
+def test_two_runs_give_identical_exports(oracle):
+    import ray_amd
+    packed, offsets, lengths = make_reads_numpy(genome=20000, read_len=100, n_reads=6000, seed=2, error=0.01)
+    outs = []
+    for _ in range(2):
+        b = ray_amd.GraphBuilder(31)
+        b.add_reads(packed, offsets, lengths)
+        b.count_kmers()
+        b.add_edges()
+        outs.append(b.export(sort=True).tobytes())
+    assert outs[0] == outs[1]
