@@ -45,6 +45,13 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError("%s is missing: build it with `make -C ray_amd/csrc` (or __graft_entry__.build()); "
                           "ray_amd has no CPU fallback" % LIB_PATH)
+    # torch ships its own libamdhip64 (same SONAME as /opt/rocm's).  A process must hold ONE HIP runtime:
+    # importing torch first makes the dynamic loader resolve our NEEDED libamdhip64.so.7 to the copy torch
+    # already loaded; the other order loads two runtimes and the second one finds no GPU.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, u64, u32 = C.c_void_p, C.c_uint64, C.c_uint32
     u64p, u32p, u8p = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)
