@@ -1,0 +1,63 @@
+"""N>1 path on CPU: two processes over gloo run ray_amd.exchange (partitioning, count/bucket
+all-to-all(v), merge, histogram reduction) with the CPU stand-in engine of tests/model.py, and the
+result must equal the 2-rank oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _worker(rank, world, port, k, bloom, out_dir):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import torch.distributed as dist
+    from model import ModelEngine
+    from oracle import ray_oracle as ro
+    from ray_amd.exchange import exchange_owner_buckets, partition_reads, reduce_histogram
+    from ray_amd.synth import make_reads_numpy
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    packed, offsets, lengths = make_reads_numpy(genome=1200, read_len=60, n_reads=151, seed=77, error=0.02)
+    first, last = partition_reads(len(lengths), rank, world)
+    e = ModelEngine(ro, k, rank, world, bloom, first_read_id=first)
+    e.add_reads(packed, offsets[first:last], lengths[first:last])
+    e.count_local()
+    sent, received = exchange_owner_buckets(e, device="cpu")
+    assert sent == len(e.local)
+    e.resolve_admission(last - first)
+    cov, cnt = reduce_histogram(*e.histogram(), device="cpu", size=world)
+    np.save(os.path.join(out_dir, "rec%d.npy" % rank), e.records())
+    if rank == 0:
+        np.save(os.path.join(out_dir, "hist.npy"), np.stack([cov.astype(np.uint64), cnt]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("k,bloom", [(21, 4000), (21, None)])
+def test_two_rank_exchange_over_gloo(oracle, tmp_path, k, bloom):
+    sys.path.insert(0, HERE)
+    from helpers import assert_records_equal, oracle_run
+    from ray_amd.synth import make_reads_numpy
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, k, bloom, str(tmp_path)), nprocs=2, join=True)
+    packed, offsets, lengths = make_reads_numpy(genome=1200, read_len=60, n_reads=151, seed=77, error=0.02)
+    want = oracle_run(oracle, packed, offsets, lengths, k, 2, bloom)
+    for r in range(2):
+        got = np.load(str(tmp_path / ("rec%d.npy" % r)))
+        assert_records_equal(got, want["graph"].export(r), "rank %d" % r)
+    hist = np.load(str(tmp_path / "hist.npy"))
+    assert np.array_equal(hist[0], want["hist"][0].astype(np.uint64)) and np.array_equal(hist[1], want["hist"][1])
+
+
+def test_partition_reads_matches_sequences_loader():
+    """SequencesLoader.cpp:287-297"""
+    from ray_amd.exchange import partition_reads
+    assert [partition_reads(10, r, 3) for r in range(3)] == [(0, 3), (3, 6), (6, 10)]
+    assert [partition_reads(2, r, 4) for r in range(4)] == [(0, 0), (0, 0), (0, 0), (0, 2)]
+    assert partition_reads(7, 0, 1) == (0, 7)
