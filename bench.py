@@ -31,6 +31,7 @@ def parse():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink genome and read count (development only)")
     ap.add_argument("--cpu-sample-reads", type=int, default=60000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="print per-call wall times of the last step to stderr")
     return ap.parse_args()
 
 
@@ -92,25 +93,44 @@ def main():
     first_read_id = rank * n_reads
     stream = torch.cuda.current_stream().cuda_stream
 
+    marks = []
+
+    def mark(name):
+        if args.breakdown:
+            torch.cuda.synchronize()
+            marks.append((name, time.perf_counter()))
+
     def one_step(profile=False):
+        del marks[:]
+        mark("start")
         b = ray_amd.GraphBuilder(k, rank=rank, size=world, device=local_rank, first_read_id=first_read_id, stream=stream)
         if profile:
             b.set_profiling(True)
         b.add_reads_device(packed.data_ptr(), n_reads * ((cfg["read_len"] + 3) // 4), offsets.data_ptr(),
                            lengths.data_ptr(), n_reads, cfg["read_len"])
+        mark("create+add_reads")
         if world == 1:
-            b.count_kmers()                      # RAY_SLAVE_MODE_ADD_VERTICES
+            if args.breakdown:
+                b.count_local()
+                mark("count_local")
+                b.resolve_admission()
+            else:
+                b.count_kmers()                  # RAY_SLAVE_MODE_ADD_VERTICES
         else:
             b.count_local()
             exchange_owner_buckets(b, device=dev)
             b.resolve_admission(n_reads)
+        mark("count/resolve")
         cov, cnt = b.histogram()                 # RAY_SLAVE_MODE_SEND_DISTRIBUTION
         if world > 1:
             cov, cnt = reduce_histogram(cov, cnt, device=dev, size=world)
+        mark("histogram")
         b.add_edges()                            # RAY_SLAVE_MODE_ADD_EDGES
+        mark("add_edges")
         st = b.stats()
         sweep = b.sweep_time() if profile else (0.0, 0)
         b.close()
+        mark("destroy")
         return st, sweep, (cov, cnt)
 
     def barrier():
@@ -139,6 +159,9 @@ def main():
     else:
         stored, occ, cand = st["stored_pairs"], st["occurrences"], st["candidates"]
 
+    if rank == 0 and args.breakdown:
+        for (n0, t0_), (n1, t1_) in zip(marks, marks[1:]):
+            print("  %-18s %8.2f ms" % (n1, (t1_ - t0_) * 1e3), file=sys.stderr)
     if rank == 0:
         per_step = elapsed / args.steps
         # dominant kernel: the k-mer sweep (k_count).  Algorithmic bytes per k-mer occurrence (SURVEY.md 8d,

@@ -141,6 +141,13 @@ typedef struct rg_stats {
 } rg_stats;
 int rg_get_stats(rg_handle *h, rg_stats *out);
 
+/* ---- memory ------------------------------------------------------------------------------ */
+/* The library keeps freed device blocks (tables, Bloom stamps) in a per-device pool and reuses them
+ * for later handles instead of returning them to the driver (RayPlatform's MyAllocator /
+ * __Malloc bookkeeping plays the same role on the host, KmerAcademyBuilder/BloomFilter.cpp:96).
+ * This call gives every cached block back. */
+int rg_release_cached_memory(void);
+
 /* ---- profiling (the reference's MACRO_COLLECT_PROFILING_INFORMATION probes,
  * KmerAcademyBuilder.cpp:50,73,116,...) ------------------------------------------------------- */
 /* when enabled, every launch of the k-mer sweep kernel (the dominant kernel) is bracketed by HIP

@@ -524,6 +524,64 @@ __global__ __launch_bounds__(BLOCK) void k_export_write(const Slot *__restrict__
 
 // ================================================================================ host side
 
+// ---- device memory pool -------------------------------------------------------------------------
+// Freed blocks are kept per device and handed out again (best fit, at most 25 % larger than asked)
+// instead of going back to the driver: releasing tens of GiB of touched VRAM costs hundreds of
+// milliseconds per call on this stack, and a graph build allocates the same few sizes every time.
+// rg_release_cached_memory() returns everything to the driver.
+#include <map>
+#include <mutex>
+namespace {
+struct Pool {
+	std::mutex mu;
+	std::multimap<uint64_t, void *> free_blocks[64];  // per device: size -> block
+	std::map<void *, uint64_t> live[64];              // blocks handed out: ptr -> size
+} g_pool;
+
+hipError_t pool_alloc(int device, void **out, uint64_t bytes) {
+	if (bytes == 0) bytes = 256;
+	bytes = (bytes + 255) & ~255ull;
+	device &= 63;
+	{
+		std::lock_guard<std::mutex> lk(g_pool.mu);
+		auto &fb = g_pool.free_blocks[device];
+		auto it = fb.lower_bound(bytes);
+		if (it != fb.end() && it->first <= bytes + bytes / 4) {
+			*out = it->second;
+			g_pool.live[device][*out] = it->first;
+			fb.erase(it);
+			return hipSuccess;
+		}
+	}
+	hipError_t e = hipMalloc(out, bytes);
+	if (e != hipSuccess) {  // give cached blocks back and retry once
+		(void)hipGetLastError();
+		std::vector<void *> drop;
+		{
+			std::lock_guard<std::mutex> lk(g_pool.mu);
+			for (auto &kv : g_pool.free_blocks[device]) drop.push_back(kv.second);
+			g_pool.free_blocks[device].clear();
+		}
+		for (void *p : drop) (void)hipFree(p);
+		e = hipMalloc(out, bytes);
+		if (e != hipSuccess) return e;
+	}
+	std::lock_guard<std::mutex> lk(g_pool.mu);
+	g_pool.live[device][*out] = bytes;
+	return hipSuccess;
+}
+
+void pool_free(int device, void *p) {
+	if (!p) return;
+	device &= 63;
+	std::lock_guard<std::mutex> lk(g_pool.mu);
+	auto it = g_pool.live[device].find(p);
+	if (it == g_pool.live[device].end()) return;
+	g_pool.free_blocks[device].insert({it->second, p});
+	g_pool.live[device].erase(it);
+}
+}  // namespace
+
 struct Table {
 	Slot *slots = nullptr;
 	uint64_t cap = 0;
@@ -604,15 +662,15 @@ static int sync_counters(rg_handle *h) {
 }
 
 static int table_alloc(rg_handle *h, Table &t, uint64_t cap) {
-	HIP_TRY(h, hipMalloc((void **)&t.slots, cap * sizeof(Slot)));
+	HIP_TRY(h, pool_alloc(h->cfg.device, (void **)&t.slots, cap * sizeof(Slot)));
 	t.cap = cap;
 	hipLaunchKernelGGL(k_init_table, dim3(grid_for(cap)), dim3(BLOCK), 0, h->stream, t.slots, cap);
 	HIP_TRY(h, hipGetLastError());
 	return RG_OK;
 }
 
-static void table_free(Table &t) {
-	if (t.slots) (void)hipFree(t.slots);
+static void table_free(rg_handle *h, Table &t) {
+	if (t.slots) pool_free(h->cfg.device, t.slots);
 	t = Table();
 }
 
@@ -642,7 +700,7 @@ static int table_reserve(rg_handle *h, Table &t, uint64_t need, int fill_counter
 	else hipLaunchKernelGGL(k_rehash<2>, dim3(grid_for(t.cap)), dim3(BLOCK), 0, h->stream, t.slots, t.cap, bigger.slots, cap - 1, h->d_counters);
 	HIP_TRY(h, hipGetLastError());
 	HIP_TRY(h, hipStreamSynchronize(h->stream));
-	(void)hipFree(t.slots);
+	pool_free(h->cfg.device, t.slots);
 	t.slots = bigger.slots;
 	t.cap = cap;
 	return RG_OK;
@@ -681,9 +739,9 @@ int rg_create(const rg_config *cfg, rg_handle **out) {
 		}
 		h->own_stream = true;
 	}
-	if (hipMalloc((void **)&h->d_counters, sizeof(unsigned long long) * C_NUM) != hipSuccess ||
+	if (pool_alloc(h->cfg.device, (void **)&h->d_counters, sizeof(unsigned long long) * C_NUM) != hipSuccess ||
 	    hipHostMalloc((void **)&h->h_counters, sizeof(unsigned long long) * C_NUM) != hipSuccess ||
-	    hipMalloc((void **)&h->d_owner, sizeof(unsigned long long) * 2 * (size_t)cfg->size) != hipSuccess) {
+	    pool_alloc(h->cfg.device, (void **)&h->d_owner, sizeof(unsigned long long) * 2 * (size_t)cfg->size) != hipSuccess) {
 		rg_destroy(h);
 		return fail(nullptr, RG_ERR_NOMEM, "allocating counters failed");
 	}
@@ -703,15 +761,15 @@ int rg_destroy(rg_handle *h) {
 	}
 	for (auto &b : h->reads)
 		if (b.owned) {
-			(void)hipFree((void *)b.d_packed);
-			(void)hipFree((void *)b.d_off);
-			(void)hipFree((void *)b.d_len);
+			pool_free(h->cfg.device, (void *)b.d_packed);
+			pool_free(h->cfg.device, (void *)b.d_off);
+			pool_free(h->cfg.device, (void *)b.d_len);
 		}
-	table_free(h->tab);
-	table_free(h->local);
-	if (h->d_counters) (void)hipFree(h->d_counters);
+	table_free(h, h->tab);
+	table_free(h, h->local);
+	if (h->d_counters) pool_free(h->cfg.device, h->d_counters);
 	if (h->h_counters) (void)hipHostFree(h->h_counters);
-	if (h->d_owner) (void)hipFree(h->d_owner);
+	if (h->d_owner) pool_free(h->cfg.device, h->d_owner);
 	if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
 	delete h;
 	return RG_OK;
@@ -733,9 +791,9 @@ int rg_add_reads(rg_handle *h, const uint8_t *packed, uint64_t packed_bytes, con
 	ReadBatch b;
 	uint64_t padded = ((packed_bytes + 7) / 8) * 8 + 16;
 	void *dp = nullptr, *dof = nullptr, *dl = nullptr;
-	HIP_TRY(h, hipMalloc(&dp, padded));
-	HIP_TRY(h, hipMalloc(&dof, n_reads * sizeof(uint64_t)));
-	HIP_TRY(h, hipMalloc(&dl, n_reads * sizeof(uint32_t)));
+	HIP_TRY(h, pool_alloc(h->cfg.device, &dp, padded));
+	HIP_TRY(h, pool_alloc(h->cfg.device, &dof, n_reads * sizeof(uint64_t)));
+	HIP_TRY(h, pool_alloc(h->cfg.device, &dl, n_reads * sizeof(uint32_t)));
 	HIP_TRY(h, hipMemsetAsync((uint8_t *)dp + (padded - 24), 0, 24, h->stream));
 	HIP_TRY(h, hipMemcpyAsync(dp, packed, packed_bytes, hipMemcpyHostToDevice, h->stream));
 	HIP_TRY(h, hipMemcpyAsync(dof, byte_offsets, n_reads * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
@@ -876,7 +934,7 @@ int rg_merge_entries(rg_handle *h, const void *d_entries, uint64_t n_entries) {
 	if (h->cfg.size == 1) return fail(h, RG_ERR_STATE, "rg_merge_entries is for size > 1 (the local table is already the partition)");
 	HIP_TRY(h, hipSetDevice(h->cfg.device));
 	if (h->phase == PH_COUNTED_LOCAL) {
-		table_free(h->local);  // the buckets hold everything the local table knew
+		table_free(h, h->local);  // the buckets hold everything the local table knew
 		h->phase = PH_MERGING;
 	}
 	if (n_entries == 0) return RG_OK;
@@ -897,7 +955,7 @@ int rg_resolve_admission(rg_handle *h, uint64_t local_reads_for_bloom) {
 		if (h->phase != PH_COUNTED_LOCAL) return fail(h, RG_ERR_STATE, "rg_resolve_admission needs rg_count_local first");
 	} else {
 		if (h->phase != PH_MERGING && h->phase != PH_COUNTED_LOCAL) return fail(h, RG_ERR_STATE, "rg_resolve_admission needs rg_merge_entries first");
-		if (h->phase == PH_COUNTED_LOCAL) table_free(h->local);
+		if (h->phase == PH_COUNTED_LOCAL) table_free(h, h->local);
 	}
 	HIP_TRY(h, hipSetDevice(h->cfg.device));
 	Table &T = h->tab;
@@ -917,7 +975,7 @@ int rg_resolve_admission(rg_handle *h, uint64_t local_reads_for_bloom) {
 	const int grid = grid_for(T.cap);
 	if (m_bits > 0) {
 		unsigned long long *bitstamp = nullptr;
-		HIP_TRY(h, hipMalloc((void **)&bitstamp, m_bits * sizeof(unsigned long long)));
+		HIP_TRY(h, pool_alloc(h->cfg.device, (void **)&bitstamp, m_bits * sizeof(unsigned long long)));
 		hipError_t e = hipMemsetAsync(bitstamp, 0xFF, m_bits * sizeof(unsigned long long), h->stream);
 		if (e == hipSuccess) {
 			if (h->W == 1) {
@@ -930,7 +988,7 @@ int rg_resolve_admission(rg_handle *h, uint64_t local_reads_for_bloom) {
 			e = hipGetLastError();
 		}
 		hipError_t e2 = hipStreamSynchronize(h->stream);
-		(void)hipFree(bitstamp);  // the reference destroys its filter here too (MessageProcessor.cpp:1010)
+		pool_free(h->cfg.device, bitstamp);  // the reference destroys its filter here too (MessageProcessor.cpp:1010)
 		if (e != hipSuccess) return fail(h, RG_ERR_HIP, "Bloom resolution failed: %s", hipGetErrorString(e));
 		if (e2 != hipSuccess) return fail(h, RG_ERR_HIP, "Bloom resolution failed: %s", hipGetErrorString(e2));
 	} else {
@@ -965,8 +1023,8 @@ int rg_histogram(rg_handle *h, uint32_t *coverage, uint64_t *count, uint64_t cap
 	HIP_TRY(h, hipSetDevice(h->cfg.device));
 	unsigned long long *dense = nullptr;
 	uint32_t *ovf = nullptr;
-	HIP_TRY(h, hipMalloc((void **)&dense, HIST_DENSE * sizeof(unsigned long long)));
-	HIP_TRY(h, hipMalloc((void **)&ovf, HIST_OVF_CAP * sizeof(uint32_t)));
+	HIP_TRY(h, pool_alloc(h->cfg.device, (void **)&dense, HIST_DENSE * sizeof(unsigned long long)));
+	HIP_TRY(h, pool_alloc(h->cfg.device, (void **)&ovf, HIST_OVF_CAP * sizeof(uint32_t)));
 	HIP_TRY(h, hipMemsetAsync(dense, 0, HIST_DENSE * sizeof(unsigned long long), h->stream));
 	HIP_TRY(h, hipMemsetAsync(h->d_counters + C_OVF, 0, sizeof(unsigned long long), h->stream));
 	hipLaunchKernelGGL(k_histogram, dim3(grid_for(h->tab.cap)), dim3(BLOCK), 0, h->stream, h->tab.slots, h->tab.cap, dense, ovf, h->d_counters);
@@ -975,15 +1033,15 @@ int rg_histogram(rg_handle *h, uint32_t *coverage, uint64_t *count, uint64_t cap
 	HIP_TRY(h, hipMemcpyAsync(hd.data(), dense, HIST_DENSE * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
 	int rc = sync_counters(h);
 	if (rc) {
-		(void)hipFree(dense);
-		(void)hipFree(ovf);
+		pool_free(h->cfg.device, dense);
+		pool_free(h->cfg.device, ovf);
 		return rc;
 	}
 	uint64_t novf = h->h_counters[C_OVF];
 	std::vector<uint32_t> ho;
 	if (novf > HIST_OVF_CAP) {
-		(void)hipFree(dense);
-		(void)hipFree(ovf);
+		pool_free(h->cfg.device, dense);
+		pool_free(h->cfg.device, ovf);
 		return fail(h, RG_ERR_CAPACITY, "more than %u vertices with coverage >= %u", HIST_OVF_CAP, HIST_DENSE);
 	}
 	if (novf) {
@@ -991,8 +1049,8 @@ int rg_histogram(rg_handle *h, uint32_t *coverage, uint64_t *count, uint64_t cap
 		HIP_TRY(h, hipMemcpy(ho.data(), ovf, novf * sizeof(uint32_t), hipMemcpyDeviceToHost));
 		std::sort(ho.begin(), ho.end());
 	}
-	(void)hipFree(dense);
-	(void)hipFree(ovf);
+	pool_free(h->cfg.device, dense);
+	pool_free(h->cfg.device, ovf);
 	uint64_t m = 0;
 	auto emit = [&](uint32_t c, uint64_t pairs) {
 		if (m < cap && coverage && count) {
@@ -1059,8 +1117,8 @@ int rg_export(rg_handle *h, void *host_buf, uint64_t cap_records, uint64_t *n_re
 	nchunks = (cap + chunk - 1) / chunk;
 	unsigned long long *d_chunk = nullptr;
 	uint8_t *d_out = nullptr;
-	HIP_TRY(h, hipMalloc((void **)&d_chunk, nchunks * sizeof(unsigned long long)));
-	HIP_TRY(h, hipMalloc((void **)&d_out, n * rec));
+	HIP_TRY(h, pool_alloc(h->cfg.device, (void **)&d_chunk, nchunks * sizeof(unsigned long long)));
+	HIP_TRY(h, pool_alloc(h->cfg.device, (void **)&d_out, n * rec));
 	hipLaunchKernelGGL(k_export_count, dim3((int)nchunks), dim3(BLOCK), 0, h->stream, h->tab.slots, cap, chunk, d_chunk);
 	std::vector<unsigned long long> hc(nchunks);
 	HIP_TRY(h, hipMemcpyAsync(hc.data(), d_chunk, nchunks * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
@@ -1072,8 +1130,8 @@ int rg_export(rg_handle *h, void *host_buf, uint64_t cap_records, uint64_t *n_re
 		run += t;
 	}
 	if (run != n) {
-		(void)hipFree(d_chunk);
-		(void)hipFree(d_out);
+		pool_free(h->cfg.device, d_chunk);
+		pool_free(h->cfg.device, d_out);
 		return fail(h, RG_ERR_STATE, "export found %llu stored pairs, expected %llu", run, (unsigned long long)n);
 	}
 	HIP_TRY(h, hipMemcpyAsync(d_chunk, hc.data(), nchunks * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
@@ -1082,8 +1140,8 @@ int rg_export(rg_handle *h, void *host_buf, uint64_t cap_records, uint64_t *n_re
 	hipError_t e = hipGetLastError();
 	if (e == hipSuccess) e = hipMemcpyAsync(host_buf, d_out, n * rec, hipMemcpyDeviceToHost, h->stream);
 	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-	(void)hipFree(d_chunk);
-	(void)hipFree(d_out);
+	pool_free(h->cfg.device, d_chunk);
+	pool_free(h->cfg.device, d_out);
 	if (e != hipSuccess) return fail(h, RG_ERR_HIP, "export failed: %s", hipGetErrorString(e));
 	return RG_OK;
 }
@@ -1097,9 +1155,9 @@ int rg_find(rg_handle *h, const uint64_t *kmers, uint64_t n, uint32_t *coverage,
 	uint64_t *dq = nullptr;
 	uint32_t *dc = nullptr;
 	uint8_t *de = nullptr;
-	HIP_TRY(h, hipMalloc((void **)&dq, n * h->W * sizeof(uint64_t)));
-	HIP_TRY(h, hipMalloc((void **)&dc, n * sizeof(uint32_t)));
-	HIP_TRY(h, hipMalloc((void **)&de, n));
+	HIP_TRY(h, pool_alloc(h->cfg.device, (void **)&dq, n * h->W * sizeof(uint64_t)));
+	HIP_TRY(h, pool_alloc(h->cfg.device, (void **)&dc, n * sizeof(uint32_t)));
+	HIP_TRY(h, pool_alloc(h->cfg.device, (void **)&de, n));
 	hipError_t e = hipMemcpyAsync(dq, kmers, n * h->W * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream);
 	if (e == hipSuccess) {
 		if (h->W == 1) hipLaunchKernelGGL(k_find<1>, dim3(grid_for(n)), dim3(BLOCK), 0, h->stream, h->tab.slots, h->tab.cap, h->cfg.k, dq, n, dc, de);
@@ -1109,9 +1167,9 @@ int rg_find(rg_handle *h, const uint64_t *kmers, uint64_t n, uint32_t *coverage,
 	if (e == hipSuccess) e = hipMemcpyAsync(coverage, dc, n * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream);
 	if (e == hipSuccess) e = hipMemcpyAsync(edges, de, n, hipMemcpyDeviceToHost, h->stream);
 	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-	(void)hipFree(dq);
-	(void)hipFree(dc);
-	(void)hipFree(de);
+	pool_free(h->cfg.device, dq);
+	pool_free(h->cfg.device, dc);
+	pool_free(h->cfg.device, de);
 	if (e != hipSuccess) return fail(h, RG_ERR_HIP, "find failed: %s", hipGetErrorString(e));
 	return RG_OK;
 }
@@ -1121,15 +1179,28 @@ int rg_degree_distribution(rg_handle *h, uint64_t out[25]) {
 	if (h->phase < PH_RESOLVED) return fail(h, RG_ERR_STATE, "rg_degree_distribution needs the k-mer count first");
 	HIP_TRY(h, hipSetDevice(h->cfg.device));
 	unsigned long long *d = nullptr;
-	HIP_TRY(h, hipMalloc((void **)&d, 25 * sizeof(unsigned long long)));
+	HIP_TRY(h, pool_alloc(h->cfg.device, (void **)&d, 25 * sizeof(unsigned long long)));
 	HIP_TRY(h, hipMemsetAsync(d, 0, 25 * sizeof(unsigned long long), h->stream));
 	hipLaunchKernelGGL(k_degrees, dim3(grid_for(h->tab.cap)), dim3(BLOCK), 0, h->stream, h->tab.slots, h->tab.cap, d);
 	unsigned long long tmp[25];
 	hipError_t e = hipMemcpyAsync(tmp, d, sizeof tmp, hipMemcpyDeviceToHost, h->stream);
 	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-	(void)hipFree(d);
+	pool_free(h->cfg.device, d);
 	if (e != hipSuccess) return fail(h, RG_ERR_HIP, "degree distribution failed: %s", hipGetErrorString(e));
 	for (int i = 0; i < 25; ++i) out[i] = tmp[i];
+	return RG_OK;
+}
+
+int rg_release_cached_memory(void) {
+	std::vector<void *> drop;
+	{
+		std::lock_guard<std::mutex> lk(g_pool.mu);
+		for (int d = 0; d < 64; ++d) {
+			for (auto &kv : g_pool.free_blocks[d]) drop.push_back(kv.second);
+			g_pool.free_blocks[d].clear();
+		}
+	}
+	for (void *p : drop) (void)hipFree(p);
 	return RG_OK;
 }
 
