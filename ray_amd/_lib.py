@@ -24,7 +24,7 @@ class RgConfig(C.Structure):
 
 class RgStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("reads", "occurrences", "candidates", "stored_pairs", "bloom_bits",
-                                         "bloom_insertions", "bloom_set_bits", "table_slots")]
+                                         "bloom_insertions", "bloom_set_bits", "table_slots", "sweep_partitioned")]
 
 
 # every symbol include/raygraph.h declares

@@ -19,6 +19,7 @@
 
 #include "../../include/raygraph.h"
 #include "rg_device.h"
+#include "rg_partition.h"
 
 using namespace rg;
 
@@ -706,6 +707,163 @@ static int table_reserve(rg_handle *h, Table &t, uint64_t need, int fill_counter
 	return RG_OK;
 }
 
+// ---- the partitioned sweep (rg_partition.h) ------------------------------------------------------
+// Produces the log of aggregated entries for all reads of the handle.  *ok = false means a capacity
+// estimate was exceeded (nothing is lost: the caller then runs the direct sweep instead).
+template <int W>
+static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bool *ok) {
+	*ok = false;
+	*out_log = nullptr;
+	*out_n = 0;
+	const int dev = h->cfg.device;
+	const int k = h->cfg.k;
+	const int m = k < MMER_MAX ? k : MMER_MAX;
+	const int w = k - m + 1;
+	uint64_t occ_bound = 0, rec_bound = 0, total_reads = 0;
+	for (const ReadBatch &b : h->reads) {
+		if (b.maxlen < (uint32_t)k) continue;
+		const uint64_t per = (uint64_t)b.maxlen - k + 1;
+		occ_bound += b.n * per;
+		double frac = 3.0 / (w + 1);
+		if (frac > 1.0) frac = 1.0;
+		rec_bound += b.n * ((uint64_t)(per * frac) + (per + 63) / 64 + 2);
+		total_reads += b.n;
+		if (b.first_id + b.n >= (1ull << 33) - 1) return RG_OK;  // read ids must fit the record header
+	}
+	if (occ_bound == 0) {
+		*ok = true;
+		return RG_OK;
+	}
+	const int grid1 = (int)std::min<uint64_t>(2048, (total_reads + 3) / 4);
+	const uint64_t rec_cap = rec_bound + (uint64_t)grid1 * 4 * REC_CHUNK;
+	Rec<W> *R1 = nullptr, *RA = nullptr;
+	unsigned long long *d_small = nullptr;  // coarse_hist[256] | seg_begin[257] | cursorsA[256] | fine_hist[65536] | fine_begin[65537] | cursorsB[65536]
+	uint32_t *d_tile_first = nullptr;
+	const size_t OFF_CH = 0, OFF_SEG = 256, OFF_CA = 256 + 257, OFF_FH = OFF_CA + 256, OFF_FB = OFF_FH + NB_BUCKETS,
+	             OFF_CB = OFF_FB + NB_BUCKETS + 1, SMALL_N = OFF_CB + NB_BUCKETS;
+	auto cleanup = [&]() {
+		pool_free(dev, R1);
+		pool_free(dev, RA);
+		pool_free(dev, d_small);
+		pool_free(dev, d_tile_first);
+	};
+#define PTRY(call)                                                                                          \
+	do {                                                                                                    \
+		hipError_t e_ = (call);                                                                             \
+		if (e_ != hipSuccess) {                                                                             \
+			cleanup();                                                                                      \
+			return fail(h, e_ == hipErrorOutOfMemory ? RG_ERR_NOMEM : RG_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+		}                                                                                                   \
+	} while (0)
+	if (pool_alloc(dev, (void **)&R1, rec_cap * sizeof(Rec<W>)) != hipSuccess) {  // not enough memory: direct sweep
+		(void)hipGetLastError();
+		return RG_OK;
+	}
+	PTRY(pool_alloc(dev, (void **)&d_small, SMALL_N * sizeof(unsigned long long)));
+	PTRY(pool_alloc(dev, (void **)&d_tile_first, 257 * sizeof(uint32_t)));
+	PTRY(hipMemsetAsync(d_small, 0, SMALL_N * sizeof(unsigned long long), h->stream));
+	PTRY(hipMemsetAsync(h->d_counters + PC_REC_CURSOR, 0, 8 * sizeof(unsigned long long), h->stream));
+	// 1. reads -> records
+	for (const ReadBatch &b : h->reads) {
+		if (b.maxlen < (uint32_t)k) continue;
+		hipLaunchKernelGGL(k_superkmers<W>, dim3(grid1), dim3(256), 0, h->stream, b.d_packed, b.d_off, b.d_len, b.n, b.first_id, k, m, R1,
+		                   rec_cap, h->d_counters, d_small + OFF_CH);
+		PTRY(hipGetLastError());
+	}
+	std::vector<unsigned long long> hs(SMALL_N);
+	PTRY(hipMemcpyAsync(hs.data(), d_small, 256 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+	int rc = sync_counters(h);
+	if (rc) {
+		cleanup();
+		return rc;
+	}
+	if (h->h_counters[PC_REC_OVF]) {
+		cleanup();
+		return RG_OK;
+	}
+	const uint64_t n_in = std::min<uint64_t>(h->h_counters[PC_REC_CURSOR], rec_cap);
+	uint64_t valid = 0;
+	std::vector<uint32_t> tile_first(257);
+	uint32_t ntilesB = 0;
+	for (int c = 0; c < NB_COARSE; ++c) {
+		hs[OFF_SEG + c] = valid;
+		hs[OFF_CA + c] = valid;
+		tile_first[c] = ntilesB;
+		ntilesB += (uint32_t)((hs[OFF_CH + c] + SCATTER_TILE - 1) / SCATTER_TILE);
+		valid += hs[OFF_CH + c];
+	}
+	hs[OFF_SEG + 256] = valid;
+	tile_first[256] = ntilesB;
+	if (valid == 0) {
+		cleanup();
+		*ok = true;
+		return RG_OK;
+	}
+	PTRY(pool_alloc(dev, (void **)&RA, valid * sizeof(Rec<W>)));
+	PTRY(hipMemcpyAsync(d_small + OFF_SEG, hs.data() + OFF_SEG, (257 + 256) * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
+	PTRY(hipMemcpyAsync(d_tile_first, tile_first.data(), 257 * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+	// 2. coarse pass
+	hipLaunchKernelGGL((k_scatter<W, false>), dim3((unsigned)((n_in + SCATTER_TILE - 1) / SCATTER_TILE)), dim3(256), 0, h->stream, R1, n_in, m,
+	                   (const unsigned long long *)nullptr, (const uint32_t *)nullptr, d_small + OFF_CA, RA);
+	PTRY(hipGetLastError());
+	// 3. fine pass: histogram, scan on the host, scatter back into R1
+	hipLaunchKernelGGL(k_fine_hist<W>, dim3(ntilesB), dim3(256), 0, h->stream, RA, m, d_small + OFF_SEG, d_tile_first, d_small + OFF_FH);
+	PTRY(hipGetLastError());
+	PTRY(hipMemcpyAsync(hs.data() + OFF_FH, d_small + OFF_FH, NB_BUCKETS * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+	PTRY(hipStreamSynchronize(h->stream));
+	{
+		unsigned long long run = 0;
+		for (int i = 0; i < NB_BUCKETS; ++i) {
+			hs[OFF_FB + i] = run;
+			hs[OFF_CB + i] = run;
+			run += hs[OFF_FH + i];
+		}
+		hs[OFF_FB + NB_BUCKETS] = run;
+		if (run != valid) {
+			cleanup();
+			return fail(h, RG_ERR_STATE, "partition lost records: %llu of %llu", run, (unsigned long long)valid);
+		}
+	}
+	PTRY(hipMemcpyAsync(d_small + OFF_FB, hs.data() + OFF_FB, (2 * NB_BUCKETS + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
+	hipLaunchKernelGGL((k_scatter<W, true>), dim3(ntilesB), dim3(256), 0, h->stream, RA, valid, m, d_small + OFF_SEG, d_tile_first,
+	                   d_small + OFF_CB, R1);
+	PTRY(hipGetLastError());
+	// 4. aggregate per fine bucket into the log
+	size_t free_b = 0, total_b = 0;
+	PTRY(hipMemGetInfo(&free_b, &total_b));
+	uint64_t log_cap = std::min<uint64_t>(occ_bound, (uint64_t)(free_b * 0.4) / sizeof(Slot));
+	if (log_cap < 1024) log_cap = 1024;
+	Slot *log = nullptr;
+	// a pooled block of a previous run may already fit
+	if (pool_alloc(dev, (void **)&log, log_cap * sizeof(Slot)) != hipSuccess) {
+		(void)hipGetLastError();
+		cleanup();
+		return RG_OK;
+	}
+	hipLaunchKernelGGL(k_aggregate<W>, dim3(2048), dim3(256), 0, h->stream, R1, d_small + OFF_FB, (uint32_t)NB_BUCKETS, k, log, log_cap,
+	                   h->d_counters);
+	hipError_t e = hipGetLastError();
+	if (e == hipSuccess) rc = sync_counters(h);
+	cleanup();
+	if (e != hipSuccess || rc) {
+		pool_free(dev, log);
+		return e != hipSuccess ? fail(h, RG_ERR_HIP, "k_aggregate: %s", hipGetErrorString(e)) : rc;
+	}
+	if (h->h_counters[PC_LOG_OVF]) {
+		pool_free(dev, log);
+		return RG_OK;
+	}
+	*out_log = log;
+	*out_n = h->h_counters[PC_LOG_CURSOR];
+	*ok = true;
+#undef PTRY
+	return RG_OK;
+}
+
+static int sweep_partitioned(rg_handle *h, Slot **out_log, uint64_t *out_n, bool *ok) {
+	return h->W == 1 ? sweep_partitioned_t<1>(h, out_log, out_n, ok) : sweep_partitioned_t<2>(h, out_log, out_n, ok);
+}
+
 extern "C" {
 
 const char *rg_version(void) { return "raygraph-mi355x 0.1 (gfx950)"; }
@@ -841,6 +999,48 @@ int rg_count_local(rg_handle *h) {
 	Table &T = single ? h->tab : h->local;
 	const int fill_counter = single ? C_FILL : C_FILL_LOCAL;
 	const int k = h->cfg.k;
+	// choose the sweep: partitioned (super-k-mers + LDS aggregation) for real inputs, direct for small
+	// ones; cfg.reserved0 bit 0 forces the partitioned sweep, bit 1 the direct one (tests)
+	{
+		uint64_t occ_bound = 0;
+		for (const ReadBatch &b : h->reads)
+			if (b.maxlen >= (uint32_t)k) occ_bound += b.n * ((uint64_t)b.maxlen - k + 1);
+		const uint32_t flags = (uint32_t)h->cfg.reserved0;
+		if (!(flags & 2u) && ((flags & 1u) || occ_bound >= (1ull << 24))) {
+			Slot *log = nullptr;
+			uint64_t n_log = 0;
+			bool ok = false;
+			int rc = sweep_partitioned(h, &log, &n_log, &ok);
+			if (rc) return rc;
+			if (ok) {
+				h->stats.sweep_partitioned = 1;
+				if (single) {
+					rc = table_reserve(h, T, n_log ? n_log : 1, fill_counter);
+					if (rc == RG_OK && n_log) {
+						if (h->W == 1) hipLaunchKernelGGL(k_merge<1>, dim3(grid_for(n_log)), dim3(BLOCK), 0, h->stream, log, n_log, T.slots, T.cap - 1, h->d_counters);
+						else hipLaunchKernelGGL(k_merge<2>, dim3(grid_for(n_log)), dim3(BLOCK), 0, h->stream, log, n_log, T.slots, T.cap - 1, h->d_counters);
+						if (hipGetLastError() != hipSuccess) rc = fail(h, RG_ERR_HIP, "k_merge launch failed");
+					}
+					if (rc == RG_OK) rc = sync_counters(h);
+					pool_free(h->cfg.device, log);
+					if (rc) return rc;
+				} else {
+					h->local.slots = log;  // the log plays the local table's role: a flat array of entries
+					h->local.cap = n_log;
+					rc = sync_counters(h);
+					if (rc) return rc;
+				}
+				T.fill_known = single ? h->h_counters[fill_counter] : n_log;
+				T.fill_pending = 0;
+				h->stats.reads = h->n_reads;
+				h->stats.occurrences = h->h_counters[C_OCC];
+				h->phase = PH_COUNTED_LOCAL;
+				return RG_OK;
+			}
+			// an estimate was exceeded: forget what the attempt counted and sweep directly
+			HIP_TRY(h, hipMemsetAsync(h->d_counters + C_OCC, 0, sizeof(unsigned long long), h->stream));
+		}
+	}
 	const uint64_t LAUNCH_OCC = 1ull << 27;  // k-mer occurrences per launch (bounds table growth)
 	for (const ReadBatch &b : h->reads) {
 		if (b.maxlen < (uint32_t)k) continue;

@@ -1,0 +1,500 @@
+// rg_partition.h -- the partitioned sweep: super-k-mer records -> two-level bucket partition -> LDS
+// aggregation -> entry log.
+//
+// Why: a scattered device-scope atomic costs the same ~17.5 G/s chip-wide whatever it touches
+// (tools/microbench.hip), so a sweep that pays one global atomic per k-mer occurrence tops out
+// there.  LDS atomics run ~100x faster.  To let a workgroup aggregate in LDS, all occurrences of a
+// canonical k-mer must meet in one place first.  Moving k-mers themselves would cost 16 B per
+// occurrence per pass; instead consecutive k-mers of a read that share a bucket travel together as
+// one *super-k-mer record* (their bases + one header), ~2.5 B per occurrence:
+//
+//   k_superkmers   reads -> records.  bucket(k-mer) = hash of its canonical minimizer (the m-mer,
+//                  m = min(k,15), with the smallest mixed value among the k-mer's m-mers on both
+//                  strands), which is strand independent, so every occurrence of a canonical k-mer
+//                  gets the same bucket.
+//   k_scatter      two passes (coarse 8 bits, fine 8 bits): tile-local counting sort in LDS, one
+//                  cursor claim per (tile, bucket), coalesced runs out.
+//   k_aggregate    one workgroup per fine bucket: expand the records, merge (min stamp, count, edge
+//                  bits) per canonical k-mer in an LDS hash table, append the distinct entries to a log.
+//   k_merge        (raygraph.hip) builds the vertex table from the log: ~1 entry per distinct k-mer
+//                  instead of one atomic per occurrence.
+//
+// Correctness never depends on the bucketing: every stage only moves or merges (key, stamp, count,
+// edge bits) contributions and the final merge is the same commutative atomic upsert as the direct
+// sweep, so a k-mer split over two buckets, or an LDS table that fills up, costs time, not parity.
+#pragma once
+#include "rg_device.h"
+
+namespace rg {
+
+static constexpr int MMER_MAX = 15;          // minimizer length (<= 15 so that it fits 30 bits)
+static constexpr uint64_t REC_INVALID = ~0ull;
+static constexpr uint32_t REC_CHUNK = 1024;  // records a wavefront claims at a time from the output cursor
+static constexpr int NB_COARSE = 256, NB_FINE = 256, NB_BUCKETS = NB_COARSE * NB_FINE;
+
+// A record: 2*W words of bases (2 bits each, same order as the packed read) then a header word:
+//   bits  0..15 position of the first k-mer in its read     bits 24..30 offset of the minimizer in the record
+//   bits 16..21 number of k-mers - 1                         bits 31..63 global read id (33 bits)
+//   bit  22     a k-mer precedes the first one in the read (then base 0 of the record is its first base)
+//   bit  23     a k-mer follows the last one in the read (then the base after the last k-mer is present)
+template <int W>
+struct Rec {
+	uint64_t w[2 * W + 1];
+};
+
+__host__ __device__ inline uint32_t fmix32(uint32_t h) {  // murmur3 finalizer: a bijection on 32 bits
+	h ^= h >> 16;
+	h *= 0x85ebca6bu;
+	h ^= h >> 13;
+	h *= 0xc2b2ae35u;
+	h ^= h >> 16;
+	return h;
+}
+// bucket of a canonical minimizer; a different mix than the one that orders minimizers, whose small
+// values are exactly the ones that get picked
+__host__ __device__ inline uint32_t bucket16(uint32_t canon) { return fmix32(canon * 0x2545F491u + 0x68E31DA4u) >> 16; }
+
+__host__ __device__ inline int lmax_for(int W, int k) {
+	int l = 64 * W - k - 1;
+	return l > 64 ? 64 : l;
+}
+
+__device__ __forceinline__ uint32_t canon_mmer(uint64_t f, int m) {
+	uint64_t r = (~rev2(f)) >> (64 - 2 * m);
+	return (uint32_t)(f < r ? f : r);
+}
+
+// base t of a record
+template <int W>
+__device__ __forceinline__ uint32_t rec_base(const uint64_t (&b)[2 * W], uint32_t t) {
+	uint32_t j = t >> 5;
+	uint64_t word = b[0];
+	if (j == 1) word = b[1];
+	if (W == 2) {
+		if (j == 2) word = b[2];
+		if (j == 3) word = b[3];
+	}
+	return (uint32_t)(word >> ((t & 31u) * 2u)) & 3u;
+}
+
+// 64 bits of a record's base string starting at base t (t < 64*W)
+template <int W>
+__device__ __forceinline__ uint64_t rec_ext(const uint64_t (&b)[2 * W], uint32_t t) {
+	uint32_t j = t >> 5, s = (t & 31u) * 2u;
+	uint64_t lo = b[0], hi = b[1];
+	if (j == 1) {
+		lo = b[1];
+		hi = (W == 2) ? b[2 * W - 2] : 0;
+	}
+	if (W == 2) {
+		if (j == 2) {
+			lo = b[2];
+			hi = b[3];
+		}
+		if (j == 3) {
+			lo = b[3];
+			hi = 0;
+		}
+	}
+	return s ? ((lo >> s) | (hi << (64 - s))) : lo;
+}
+
+template <int W>
+__device__ __forceinline__ uint32_t rec_bucket(const Rec<W> &r, int m) {
+	uint64_t b[2 * W];
+#pragma unroll
+	for (int i = 0; i < 2 * W; ++i) b[i] = r.w[i];
+	uint32_t moff = (uint32_t)(r.w[2 * W] >> 24) & 127u;
+	uint64_t f = rec_ext<W>(b, moff) & ((1ull << (2 * m)) - 1);
+	return bucket16(canon_mmer(f, m));
+}
+
+enum PartCounter { PC_REC_CURSOR = 16, PC_REC_OVF, PC_LOG_CURSOR, PC_LOG_OVF, PC_LDS_SPILL };
+
+// ------------------------------------------------------------------------------------------------
+// reads -> super-k-mer records.  One wavefront per read at a time, 64 k-mer positions per step.
+template <int W>
+__global__ __launch_bounds__(256) void k_superkmers(const uint64_t *__restrict__ P, const uint64_t *__restrict__ offsets,
+                                                    const uint32_t *__restrict__ lengths, uint64_t nreads, uint64_t read_id_base,
+                                                    int k, int m, Rec<W> *__restrict__ recs, uint64_t rec_cap,
+                                                    unsigned long long *__restrict__ counters,
+                                                    unsigned long long *__restrict__ coarse_hist) {
+	constexpr int NB = 2 * W;
+	__shared__ uint32_t s_hk[4][128];
+	__shared__ uint32_t s_cn[4][128];
+	__shared__ uint32_t s_hist[NB_COARSE];
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	s_hist[threadIdx.x] = 0;
+	__syncthreads();
+	const int w = k - m + 1;
+	const int LMAX = lmax_for(W, k);
+	const uint64_t maskm = (1ull << (2 * m)) - 1;
+	const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+	uint64_t chunk_base = 0;
+	uint32_t chunk_used = REC_CHUNK;
+	bool have_chunk = false, dead = false;
+	unsigned long long occ = 0;
+
+	for (uint64_t r = (uint64_t)blockIdx.x * 4 + wave; r < nreads; r += nwaves) {
+		const uint32_t L = lengths[r];
+		if (L < (uint32_t)k) continue;
+		const uint32_t n = L - (uint32_t)k + 1;
+		const uint64_t bit0 = offsets[r] * 8;
+		if (lane == 0) occ += n;
+		for (uint32_t p0 = 0; p0 < n; p0 += 64) {
+			const uint32_t cnt = (n - p0 < 64u) ? (n - p0) : 64u;
+			const uint32_t nm = cnt + (uint32_t)w - 1;  // m-mers under the step's k-mers (<= 112)
+			for (uint32_t jl = lane; jl < nm; jl += 64) {
+				uint64_t f = ext64(P, bit0 + 2ull * (p0 + jl)) & maskm;
+				uint32_t c = canon_mmer(f, m);
+				s_hk[wave][jl] = (fmix32(c) & ~127u) | jl;
+				s_cn[wave][jl] = c;
+			}
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			const bool active = lane < cnt;
+			uint32_t v = 0xFFFFFFFFu;
+			if (active)
+				for (int t = 0; t < w; ++t) {
+					uint32_t x = s_hk[wave][lane + t];
+					v = x < v ? x : v;
+				}
+			const uint32_t jstar = v & 127u;
+			const uint32_t canon = active ? s_cn[wave][jstar] : 0;
+			const uint32_t bucket = bucket16(canon);
+			uint32_t prevb = __shfl_up(bucket, 1);
+			bool start = active && (lane == 0 || bucket != prevb);
+			unsigned long long ballot = __ballot(start);
+			// cut runs longer than a record can hold
+			{
+				unsigned long long below = ballot & ((lane == 63) ? ~0ull : ((2ull << lane) - 1));
+				uint32_t runstart = 63u - (uint32_t)__clzll(below | 1ull);
+				if (active && !start && ((lane - runstart) % (uint32_t)LMAX) == 0) start = true;
+				ballot = __ballot(start);
+			}
+			const uint32_t c = (uint32_t)__popcll(ballot);
+			if (chunk_used + c > REC_CHUNK) {  // wave-uniform
+				if (have_chunk && !dead)
+					for (uint32_t i = chunk_used + lane; i < REC_CHUNK; i += 64) recs[chunk_base + i].w[NB] = REC_INVALID;
+				unsigned long long nb = 0;
+				if (lane == 0) nb = atomicAdd(&counters[PC_REC_CURSOR], (unsigned long long)REC_CHUNK);
+				nb = __shfl(nb, 0);
+				if (nb + REC_CHUNK > rec_cap) {
+					dead = true;
+					if (lane == 0) atomicAdd(&counters[PC_REC_OVF], 1ull);
+				}
+				chunk_base = nb;
+				chunk_used = 0;
+				have_chunk = true;
+			}
+			if (start && !dead) {
+				const uint32_t idx = (uint32_t)__popcll(ballot & ((1ull << lane) - 1));
+				unsigned long long above = (lane == 63) ? 0ull : (ballot >> (lane + 1));
+				const uint32_t next = above ? (lane + 1 + (uint32_t)__ffsll((unsigned long long)above) - 1) : cnt;
+				const uint32_t len = next - lane;
+				const uint32_t p = p0 + lane;
+				const uint32_t hasL = p > 0, hasR = (p + len) < n;
+				const uint32_t first = p - hasL;  // read position of the record's base 0
+				const uint32_t nbases = hasL + len + (uint32_t)k - 1 + hasR;
+				Rec<W> rec;
+#pragma unroll
+				for (int i = 0; i < NB; ++i) rec.w[i] = (nbases > 32u * i) ? ext64(P, bit0 + 2ull * first + 64ull * i) : 0;
+				const uint32_t moff = (p0 + jstar) - first;
+				rec.w[NB] = (uint64_t)p | ((uint64_t)(len - 1) << 16) | ((uint64_t)hasL << 22) | ((uint64_t)hasR << 23) |
+				            ((uint64_t)moff << 24) | ((read_id_base + r) << 31);
+				recs[chunk_base + chunk_used + idx] = rec;
+				atomicAdd(&s_hist[bucket >> 8], 1u);
+			}
+			chunk_used += c;
+			__builtin_amdgcn_wave_barrier();
+		}
+	}
+	if (have_chunk && !dead)
+		for (uint32_t i = chunk_used + lane; i < REC_CHUNK; i += 64) recs[chunk_base + i].w[NB] = REC_INVALID;
+	if (lane == 0 && occ) atomicAdd(&counters[2 /*C_OCC*/], occ);
+	__syncthreads();
+	if (s_hist[threadIdx.x]) atomicAdd(&coarse_hist[threadIdx.x], (unsigned long long)s_hist[threadIdx.x]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// One partition pass.  FINE=false: input = k_superkmers output (with holes), digit = bucket >> 8,
+// cursors[256].  FINE=true: input = coarse-sorted records, a tile never crosses a coarse bucket
+// (tile_first[c] = first tile of coarse bucket c), digit = bucket & 255, cursors[c*256+digit].
+static constexpr int SCATTER_TILE = 2048;
+template <int W, bool FINE>
+__global__ __launch_bounds__(256) void k_scatter(const Rec<W> *__restrict__ in, uint64_t n_in, int m,
+                                                 const unsigned long long *__restrict__ seg_begin /* FINE: [257] */,
+                                                 const uint32_t *__restrict__ tile_first /* FINE: [257] */,
+                                                 unsigned long long *__restrict__ cursors, Rec<W> *__restrict__ out) {
+	constexpr int NB = 2 * W, PER = SCATTER_TILE / 256;
+	__shared__ Rec<W> s_rec[SCATTER_TILE];
+	__shared__ uint8_t s_dig[SCATTER_TILE];
+	__shared__ uint32_t s_cnt[256], s_off[256];
+	__shared__ unsigned long long s_gbase[256];
+	__shared__ uint32_t s_scan[256];
+	uint64_t begin, end;
+	uint32_t coarse = 0;
+	if (FINE) {
+		// coarse bucket of this tile: largest c with tile_first[c] <= blockIdx.x
+		int lo = 0, hi = NB_COARSE;
+		while (hi - lo > 1) {
+			int mid = (lo + hi) >> 1;
+			if (tile_first[mid] <= blockIdx.x) lo = mid;
+			else hi = mid;
+		}
+		coarse = (uint32_t)lo;
+		begin = seg_begin[coarse] + (uint64_t)(blockIdx.x - tile_first[coarse]) * SCATTER_TILE;
+		end = begin + SCATTER_TILE < seg_begin[coarse + 1] ? begin + SCATTER_TILE : seg_begin[coarse + 1];
+	} else {
+		begin = (uint64_t)blockIdx.x * SCATTER_TILE;
+		end = begin + SCATTER_TILE < n_in ? begin + SCATTER_TILE : n_in;
+	}
+	s_cnt[threadIdx.x] = 0;
+	__syncthreads();
+	Rec<W> mine[PER];
+	uint32_t dig[PER], rank[PER];
+#pragma unroll
+	for (int j = 0; j < PER; ++j) {
+		uint64_t i = begin + threadIdx.x + (uint64_t)j * 256;
+		dig[j] = 0xFFFFFFFFu;
+		rank[j] = 0;
+		if (i < end) {
+			mine[j] = in[i];
+			if (mine[j].w[NB] != REC_INVALID) {
+				uint32_t b = rec_bucket<W>(mine[j], m);
+				dig[j] = FINE ? (b & 255u) : (b >> 8);
+				rank[j] = atomicAdd(&s_cnt[dig[j]], 1u);
+			}
+		}
+	}
+	__syncthreads();
+	// exclusive scan of the 256 counts (Hillis-Steele), and one cursor claim per non-empty digit
+	{
+		uint32_t c = s_cnt[threadIdx.x];
+		s_scan[threadIdx.x] = c;
+		__syncthreads();
+		for (int d = 1; d < 256; d <<= 1) {
+			uint32_t t = (threadIdx.x >= (uint32_t)d) ? s_scan[threadIdx.x - d] : 0;
+			__syncthreads();
+			s_scan[threadIdx.x] += t;
+			__syncthreads();
+		}
+		s_off[threadIdx.x] = s_scan[threadIdx.x] - c;
+		unsigned long long g = 0;
+		if (c) {
+			g = atomicAdd(&cursors[(FINE ? coarse * 256u : 0u) + threadIdx.x], (unsigned long long)c);
+		}
+		s_gbase[threadIdx.x] = g;
+	}
+	__syncthreads();
+	const uint32_t total = s_scan[255];
+#pragma unroll
+	for (int j = 0; j < PER; ++j)
+		if (dig[j] != 0xFFFFFFFFu) {
+			uint32_t pos = s_off[dig[j]] + rank[j];
+			s_rec[pos] = mine[j];
+			s_dig[pos] = (uint8_t)dig[j];
+		}
+	__syncthreads();
+	for (uint32_t i = threadIdx.x; i < total; i += 256) {
+		uint32_t d = s_dig[i];
+		out[s_gbase[d] + (i - s_off[d])] = s_rec[i];
+	}
+}
+
+// fine-digit histogram of the coarse-sorted records: hist[c*256 + (bucket & 255)]
+template <int W>
+__global__ __launch_bounds__(256) void k_fine_hist(const Rec<W> *__restrict__ in, int m,
+                                                   const unsigned long long *__restrict__ seg_begin,
+                                                   const uint32_t *__restrict__ tile_first,
+                                                   unsigned long long *__restrict__ hist) {
+	__shared__ uint32_t s_cnt[256];
+	int lo = 0, hi = NB_COARSE;
+	while (hi - lo > 1) {
+		int mid = (lo + hi) >> 1;
+		if (tile_first[mid] <= blockIdx.x) lo = mid;
+		else hi = mid;
+	}
+	const uint32_t coarse = (uint32_t)lo;
+	const uint64_t begin = seg_begin[coarse] + (uint64_t)(blockIdx.x - tile_first[coarse]) * SCATTER_TILE;
+	const uint64_t end = begin + SCATTER_TILE < seg_begin[coarse + 1] ? begin + SCATTER_TILE : seg_begin[coarse + 1];
+	s_cnt[threadIdx.x] = 0;
+	__syncthreads();
+	for (uint64_t i = begin + threadIdx.x; i < end; i += 256) {
+		Rec<W> r = in[i];
+		atomicAdd(&s_cnt[rec_bucket<W>(r, m) & 255u], 1u);
+	}
+	__syncthreads();
+	if (s_cnt[threadIdx.x]) atomicAdd(&hist[coarse * 256u + threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// One workgroup per fine bucket: expand the records and aggregate per canonical k-mer in LDS.
+static constexpr uint32_t AGG_SLOTS = 2048;                // 64 KB of LDS
+static constexpr uint32_t AGG_FLUSH = AGG_SLOTS * 7 / 10;  // flush when this full
+
+template <int W>
+__device__ __forceinline__ bool lds_upsert(Slot *tab, uint32_t *fill, uint64_t i0, uint64_t i1, uint64_t stamp, uint32_t emask) {
+	uint32_t s = (uint32_t)slot_hash<W>(i0, i1) & (AGG_SLOTS - 1);
+	for (uint32_t probe = 0; probe < AGG_SLOTS; ++probe) {
+		Slot *p = tab + s;
+		uint64_t c0 = p->k0;
+		if (c0 == EMPTY) {
+			uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long *>(&p->k0), EMPTY, i0);
+			if (prev == EMPTY) {
+				atomicAdd(fill, 1u);
+				c0 = i0;
+			} else {
+				c0 = prev;
+			}
+		}
+		if (c0 == i0) {
+			bool match = true;
+			if (W == 2) {
+				uint64_t c1 = p->k1;
+				if (c1 == EMPTY) {
+					uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long *>(&p->k1), EMPTY, i1);
+					c1 = (prev == EMPTY) ? i1 : prev;
+				}
+				match = (c1 == i1);
+			}
+			if (match) {
+				if (stamp < p->stamp) atomicMin(reinterpret_cast<unsigned long long *>(&p->stamp), stamp);
+				uint64_t add = 1ull;
+				uint32_t pend = (uint32_t)(p->meta >> PEND_SHIFT) & 0xFFu;
+				if (emask & ~pend) atomicOr(reinterpret_cast<unsigned long long *>(&p->meta), (uint64_t)emask << PEND_SHIFT);
+				atomicAdd(reinterpret_cast<unsigned long long *>(&p->meta), add);
+				return true;
+			}
+		}
+		s = (s + 1) & (AGG_SLOTS - 1);
+	}
+	return false;
+}
+
+template <int W>
+__global__ __launch_bounds__(256) void k_aggregate(const Rec<W> *__restrict__ recs, const unsigned long long *__restrict__ fine_begin,
+                                                   uint32_t nbuckets, int k, Slot *__restrict__ log, uint64_t log_cap,
+                                                   unsigned long long *__restrict__ counters) {
+	constexpr int NB = 2 * W;
+	__shared__ Slot s_tab[AGG_SLOTS];
+	__shared__ uint32_t s_fill, s_nout;
+	__shared__ unsigned long long s_logbase;
+	const uint64_t mask0 = (2 * k >= 64) ? ~0ull : ((1ull << (2 * k)) - 1);
+	const uint64_t mask1 = (k > 32) ? ((1ull << (2 * k - 64)) - 1) : 0ull;
+
+	auto flush = [&]() {
+		// entries of this thread's slots -> log
+		uint32_t mine = 0;
+		for (uint32_t i = threadIdx.x; i < AGG_SLOTS; i += 256)
+			if (s_tab[i].k0 != EMPTY) mine++;
+		if (threadIdx.x == 0) s_nout = 0;
+		__syncthreads();
+		uint32_t base = mine ? atomicAdd(&s_nout, mine) : 0;
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			unsigned long long g = s_nout ? atomicAdd(&counters[PC_LOG_CURSOR], (unsigned long long)s_nout) : 0ull;
+			if (g + s_nout > log_cap) {
+				atomicAdd(&counters[PC_LOG_OVF], 1ull);
+				g = ~0ull;
+			}
+			s_logbase = g;
+			s_fill = 0;
+		}
+		__syncthreads();
+		const unsigned long long g = s_logbase;
+		for (uint32_t i = threadIdx.x; i < AGG_SLOTS; i += 256) {
+			if (s_tab[i].k0 != EMPTY) {
+				if (g != ~0ull) log[g + base] = s_tab[i];
+				base++;
+			}
+			s_tab[i].k0 = EMPTY;
+			s_tab[i].k1 = EMPTY;
+			s_tab[i].stamp = INF_STAMP;
+			s_tab[i].meta = 0;
+		}
+		__syncthreads();
+	};
+
+	for (uint32_t i = threadIdx.x; i < AGG_SLOTS; i += 256) {
+		s_tab[i].k0 = EMPTY;
+		s_tab[i].k1 = EMPTY;
+		s_tab[i].stamp = INF_STAMP;
+		s_tab[i].meta = 0;
+	}
+	if (threadIdx.x == 0) s_fill = 0;
+	__syncthreads();
+
+	for (uint32_t b = blockIdx.x; b < nbuckets; b += gridDim.x) {
+		const uint64_t begin = fine_begin[b], end = fine_begin[b + 1];
+		for (uint64_t base = begin; base < end; base += 256) {
+			const uint64_t ri = base + threadIdx.x;
+			if (ri < end) {
+				const Rec<W> rec = recs[ri];
+				uint64_t bw[NB];
+#pragma unroll
+				for (int i = 0; i < NB; ++i) bw[i] = rec.w[i];
+				const uint64_t hdr = rec.w[NB];
+				const uint32_t pos = (uint32_t)hdr & 0xFFFFu, len = ((uint32_t)(hdr >> 16) & 63u) + 1;
+				const uint32_t hasL = (uint32_t)(hdr >> 22) & 1u, hasR = (uint32_t)(hdr >> 23) & 1u;
+				const uint64_t stamp0 = ((hdr >> 31) << 16) | pos;
+				uint64_t f0 = rec_ext<W>(bw, hasL) & mask0, f1 = 0;
+				if (W == 2 && k > 32) f1 = rec_ext<W>(bw, hasL + 32) & mask1;
+				uint64_t r0, r1;
+				revcomp<W>(f0, f1, k, r0, r1);
+				uint32_t prev = hasL ? rec_base<W>(bw, 0) : 0;
+				bool prev_valid = hasL;
+				for (uint32_t i = 0; i < len; ++i) {
+					const bool has_next = (i + 1 < len) || hasR;
+					const uint32_t nb = has_next ? rec_base<W>(bw, hasL + i + (uint32_t)k) : 0;
+					const bool use_rc = kmer_less<W>(r0, r1, f0, f1);
+					uint32_t em = 0;
+					if (prev_valid) em |= use_rc ? (1u << (7 - prev)) : (1u << prev);
+					if (has_next) em |= use_rc ? (1u << (3 - nb)) : (1u << (4 + nb));
+					uint64_t i0, i1;
+					to_internal<W>(use_rc ? r0 : f0, use_rc ? r1 : f1, i0, i1);
+					if (W == 1) i1 = EMPTY;
+					if (!lds_upsert<W>(s_tab, &s_fill, i0, i1, stamp0 + i, em)) {
+						// LDS table full: this occurrence goes to the log on its own
+						unsigned long long g = atomicAdd(&counters[PC_LOG_CURSOR], 1ull);
+						if (g < log_cap) {
+							Slot e;
+							e.k0 = i0;
+							e.k1 = i1;
+							e.stamp = stamp0 + i;
+							e.meta = 1ull | ((uint64_t)em << PEND_SHIFT);
+							log[g] = e;
+						} else {
+							atomicAdd(&counters[PC_LOG_OVF], 1ull);
+						}
+						atomicAdd(&counters[PC_LDS_SPILL], 1ull);
+					}
+					// roll to the next k-mer
+					prev = (uint32_t)f0 & 3u;
+					prev_valid = true;
+					if (i + 1 < len) {
+						if (W == 1) {
+							f0 = (f0 >> 2) | ((uint64_t)nb << (2 * (k - 1)));
+							r0 = ((r0 << 2) | (uint64_t)(3u - nb)) & mask0;
+						} else {
+							f0 = (f0 >> 2) | (f1 << 62);
+							if (k > 32) {
+								f1 = (f1 >> 2) | ((uint64_t)nb << (2 * (k - 1) - 64));
+								r1 = ((r1 << 2) | (r0 >> 62)) & mask1;
+								r0 = (r0 << 2) | (uint64_t)(3u - nb);
+							} else {
+								f0 |= (uint64_t)nb << (2 * (k - 1));
+								r0 = ((r0 << 2) | (uint64_t)(3u - nb)) & mask0;
+							}
+						}
+					}
+				}
+			}
+			__syncthreads();
+			if (s_fill > AGG_FLUSH) flush();
+		}
+		flush();
+	}
+}
+
+}  // namespace rg

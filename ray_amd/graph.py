@@ -61,9 +61,9 @@ class GraphBuilder:
     """One rank's share of the distributed de Bruijn graph on one GPU."""
 
     def __init__(self, k, rank=0, size=1, device=0, bloom_bits=RG_BLOOM_DEFAULT, kmer_words=0, table_slots=0,
-                 first_read_id=0, stream=None):
+                 first_read_id=0, stream=None, sweep=0):
         self._L = _lib.load()
-        cfg = RgConfig(k=k, kmer_words=kmer_words, rank=rank, size=size, device=device, reserved0=0,
+        cfg = RgConfig(k=k, kmer_words=kmer_words, rank=rank, size=size, device=device, reserved0=sweep,
                        bloom_bits=bloom_bits, table_slots=table_slots, first_read_id=first_read_id,
                        stream=C.c_void_p(stream) if stream else None)
         self._h = C.c_void_p()

@@ -28,13 +28,21 @@ def assert_records_equal(a, b, what=""):
     assert np.array_equal(a["edges"], b["edges"]), what + ": edge bitmaps differ"
 
 
-def gpu_vs_oracle(ro, packed, offsets, lengths, k, bloom_bits=None, W=None, purge=True, batches=1, tmpdir=None):
-    """single-rank parity through the C ABI; returns the oracle outputs for further checks"""
+def gpu_vs_oracle(ro, packed, offsets, lengths, k, bloom_bits=None, W=None, purge=True, batches=1, tmpdir=None,
+                  sweeps=(1, 2)):
+    """single-rank parity through the C ABI, once per sweep implementation (1 = partitioned: super-k-mer
+    records + LDS aggregation, 2 = direct: one table upsert per occurrence); returns the oracle outputs"""
+    want = oracle_run(ro, packed, offsets, lengths, k, 1, bloom_bits, W, purge)
+    for sweep in sweeps:
+        want["builder"] = _gpu_check(ro, want, packed, offsets, lengths, k, bloom_bits, W, purge, batches, tmpdir, sweep)
+    return want
+
+
+def _gpu_check(ro, want, packed, offsets, lengths, k, bloom_bits, W, purge, batches, tmpdir, sweep):
     import ray_amd
     from ray_amd.graph import RG_BLOOM_DEFAULT
-    want = oracle_run(ro, packed, offsets, lengths, k, 1, bloom_bits, W, purge)
     b = ray_amd.GraphBuilder(k, bloom_bits=RG_BLOOM_DEFAULT if bloom_bits is None else bloom_bits,
-                             kmer_words=W if W else 0)
+                             kmer_words=W if W else 0, sweep=sweep)
     n = len(lengths)
     cuts = [n * i // batches for i in range(batches + 1)]
     for i in range(batches):
@@ -43,17 +51,19 @@ def gpu_vs_oracle(ro, packed, offsets, lengths, k, bloom_bits=None, W=None, purg
             b.add_reads(packed, offsets[lo:hi], lengths[lo:hi])
     b.count_kmers()
     st = b.stats()
-    assert st["occurrences"] == want["occ"]
-    assert b.size_() == want["size"]
-    assert_records_equal(b.export(), want["pass1"], "after pass 1")
+    tag = "sweep %d: " % sweep
+    assert st["sweep_partitioned"] == (1 if sweep == 1 else 0), tag + "wrong sweep ran"
+    assert st["occurrences"] == want["occ"], tag + "occurrences"
+    assert b.size_() == want["size"], tag + "size"
+    assert_records_equal(b.export(), want["pass1"], tag + "after pass 1")
     cov, cnt = b.histogram()
-    assert np.array_equal(cov, want["hist"][0]) and np.array_equal(cnt, want["hist"][1]), "coverage histogram differs"
-    assert (st["bloom_bits"], st["bloom_set_bits"], st["bloom_insertions"]) == want["bloom"][0]
+    assert np.array_equal(cov, want["hist"][0]) and np.array_equal(cnt, want["hist"][1]), tag + "coverage histogram differs"
+    assert (st["bloom_bits"], st["bloom_set_bits"], st["bloom_insertions"]) == want["bloom"][0], tag + "Bloom statistics"
     b.add_edges()
-    assert_records_equal(b.export(), want["pass2"], "after pass 2")
+    assert_records_equal(b.export(), want["pass2"], tag + "after pass 2")
     if purge:
         b.purge_edges()
-        assert_records_equal(b.export(), want["purged"], "after purge")
+        assert_records_equal(b.export(), want["purged"], tag + "after purge")
         assert np.array_equal(b.degree_distribution(), want["degrees"])
     if tmpdir is not None and len(cov):
         p1, p2 = os.path.join(tmpdir, "gpu.txt"), os.path.join(tmpdir, "ora.txt")
@@ -61,5 +71,4 @@ def gpu_vs_oracle(ro, packed, offsets, lengths, k, bloom_bits=None, W=None, purg
         v2 = ro.coverage_distribution(want["hist"][0], want["hist"][1], p2)
         assert v1 == v2
         assert open(p1, "rb").read() == open(p2, "rb").read(), "CoverageDistribution.txt differs"
-    want["builder"] = b
-    return want
+    return b

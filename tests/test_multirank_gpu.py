@@ -12,7 +12,7 @@ from ray_amd.synth import make_reads_numpy
 pytestmark = pytest.mark.gpu
 
 
-def run_ranks(packed, offsets, lengths, k, nranks, bloom, W=0):
+def run_ranks(packed, offsets, lengths, k, nranks, bloom, W=0, sweep=0):
     import torch
     import ray_amd
     from ray_amd.graph import RG_BLOOM_DEFAULT, RG_ENTRY_BYTES
@@ -21,7 +21,7 @@ def run_ranks(packed, offsets, lengths, k, nranks, bloom, W=0):
     for r in range(nranks):
         first, last = partition_reads(n, r, nranks)
         b = ray_amd.GraphBuilder(k, rank=r, size=nranks, bloom_bits=RG_BLOOM_DEFAULT if bloom is None else bloom,
-                                 kmer_words=W, first_read_id=first)
+                                 kmer_words=W, first_read_id=first, sweep=sweep)
         b.add_reads(packed, offsets[first:last], lengths[first:last])
         b.count_local()
         counts = b.owner_counts()
@@ -47,7 +47,12 @@ def test_multirank_matches_oracle(oracle, k, nranks, bloom):
     packed, offsets, lengths = make_reads_numpy(genome=15000, read_len=100 if k < 63 else 150, n_reads=5001,
                                                 seed=k + nranks, error=0.015)
     want = oracle_run(oracle, packed, offsets, lengths, k, nranks, bloom)
-    builders = run_ranks(packed, offsets, lengths, k, nranks, bloom)
+    for sweep in (1, 2):
+        builders = run_ranks(packed, offsets, lengths, k, nranks, bloom, sweep=sweep)
+        check_ranks(builders, want)
+
+
+def check_ranks(builders, want):
     for r, b in enumerate(builders):
         assert_records_equal(b.export(), want["graph"].export(r), "rank %d" % r)
         st = b.stats()
