@@ -734,44 +734,63 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 		*ok = true;
 		return RG_OK;
 	}
+	// number of buckets: about 4096 k-mer occurrences each, so that whenever duplicates are worth merging
+	// (coverage >= 3) a bucket's distinct k-mers fit the LDS table of k_aggregate
+	int bits = (h->cfg.reserved0 >> 8) & 0xFF;
+	if (bits == 0) {
+		bits = 8;
+		while (bits < MAX_BUCKET_BITS && (occ_bound >> bits) > 4096) bits++;
+	}
+	if (bits < 8) bits = 8;
+	if (bits > MAX_BUCKET_BITS) bits = MAX_BUCKET_BITS;
+	const int dbits[3] = {8, std::min(8, bits - 8), std::max(0, bits - 16)};
+	const uint64_t NBUCK = 1ull << bits;
 	const int grid1 = (int)std::min<uint64_t>(2048, (total_reads + 3) / 4);
 	const uint64_t rec_cap = rec_bound + (uint64_t)grid1 * 4 * REC_CHUNK;
-	Rec<W> *R1 = nullptr, *RA = nullptr;
-	unsigned long long *d_small = nullptr;  // coarse_hist[256] | seg_begin[257] | cursorsA[256] | fine_hist[65536] | fine_begin[65537] | cursorsB[65536]
-	uint32_t *d_tile_first = nullptr;
-	const size_t OFF_CH = 0, OFF_SEG = 256, OFF_CA = 256 + 257, OFF_FH = OFF_CA + 256, OFF_FB = OFF_FH + NB_BUCKETS,
-	             OFF_CB = OFF_FB + NB_BUCKETS + 1, SMALL_N = OFF_CB + NB_BUCKETS;
+
+	Rec<W> *buf[2] = {nullptr, nullptr};
+	unsigned long long *d_seg = nullptr, *d_hist = nullptr, *d_begin = nullptr, *d_sums = nullptr;
+	uint32_t *d_tile = nullptr;
+	Slot *log = nullptr;
 	auto cleanup = [&]() {
-		pool_free(dev, R1);
-		pool_free(dev, RA);
-		pool_free(dev, d_small);
-		pool_free(dev, d_tile_first);
+		pool_free(dev, buf[0]);
+		pool_free(dev, buf[1]);
+		pool_free(dev, d_seg);
+		pool_free(dev, d_hist);
+		pool_free(dev, d_begin);
+		pool_free(dev, d_sums);
+		pool_free(dev, d_tile);
 	};
 #define PTRY(call)                                                                                          \
 	do {                                                                                                    \
 		hipError_t e_ = (call);                                                                             \
 		if (e_ != hipSuccess) {                                                                             \
 			cleanup();                                                                                      \
+			pool_free(dev, log);                                                                            \
 			return fail(h, e_ == hipErrorOutOfMemory ? RG_ERR_NOMEM : RG_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
 		}                                                                                                   \
 	} while (0)
-	if (pool_alloc(dev, (void **)&R1, rec_cap * sizeof(Rec<W>)) != hipSuccess) {  // not enough memory: direct sweep
+	if (pool_alloc(dev, (void **)&buf[0], rec_cap * sizeof(Rec<W>)) != hipSuccess) {  // not enough memory: direct sweep
 		(void)hipGetLastError();
 		return RG_OK;
 	}
-	PTRY(pool_alloc(dev, (void **)&d_small, SMALL_N * sizeof(unsigned long long)));
-	PTRY(pool_alloc(dev, (void **)&d_tile_first, 257 * sizeof(uint32_t)));
-	PTRY(hipMemsetAsync(d_small, 0, SMALL_N * sizeof(unsigned long long), h->stream));
+	const uint64_t SEGMAX = 65536;
+	PTRY(pool_alloc(dev, (void **)&d_seg, (SEGMAX + 1) * sizeof(unsigned long long)));
+	PTRY(pool_alloc(dev, (void **)&d_tile, (SEGMAX + 1) * sizeof(uint32_t)));
+	PTRY(pool_alloc(dev, (void **)&d_hist, NBUCK * sizeof(unsigned long long)));
+	PTRY(pool_alloc(dev, (void **)&d_begin, (NBUCK + 1) * sizeof(unsigned long long)));
+	PTRY(pool_alloc(dev, (void **)&d_sums, (NBUCK / SCAN_PER_BLOCK + 2) * sizeof(unsigned long long)));
+	PTRY(hipMemsetAsync(d_hist, 0, 256 * sizeof(unsigned long long), h->stream));
 	PTRY(hipMemsetAsync(h->d_counters + PC_REC_CURSOR, 0, 8 * sizeof(unsigned long long), h->stream));
-	// 1. reads -> records
+	// 1. reads -> records (+ first-level histogram)
 	for (const ReadBatch &b : h->reads) {
 		if (b.maxlen < (uint32_t)k) continue;
-		hipLaunchKernelGGL(k_superkmers<W>, dim3(grid1), dim3(256), 0, h->stream, b.d_packed, b.d_off, b.d_len, b.n, b.first_id, k, m, R1,
-		                   rec_cap, h->d_counters, d_small + OFF_CH);
+		hipLaunchKernelGGL(k_superkmers<W>, dim3(grid1), dim3(256), 0, h->stream, b.d_packed, b.d_off, b.d_len, b.n, b.first_id, k, m, bits,
+		                   buf[0], rec_cap, h->d_counters, d_hist);
 		PTRY(hipGetLastError());
 	}
-	std::vector<unsigned long long> hs(SMALL_N);
-	PTRY(hipMemcpyAsync(hs.data(), d_small, 256 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+	std::vector<unsigned long long> hist(256), begin;
+	PTRY(hipMemcpyAsync(hist.data(), d_hist, 256 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
 	int rc = sync_counters(h);
 	if (rc) {
 		cleanup();
@@ -783,65 +802,70 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	}
 	const uint64_t n_in = std::min<uint64_t>(h->h_counters[PC_REC_CURSOR], rec_cap);
 	uint64_t valid = 0;
-	std::vector<uint32_t> tile_first(257);
-	uint32_t ntilesB = 0;
-	for (int c = 0; c < NB_COARSE; ++c) {
-		hs[OFF_SEG + c] = valid;
-		hs[OFF_CA + c] = valid;
-		tile_first[c] = ntilesB;
-		ntilesB += (uint32_t)((hs[OFF_CH + c] + SCATTER_TILE - 1) / SCATTER_TILE);
-		valid += hs[OFF_CH + c];
-	}
-	hs[OFF_SEG + 256] = valid;
-	tile_first[256] = ntilesB;
+	for (auto c : hist) valid += c;
 	if (valid == 0) {
 		cleanup();
 		*ok = true;
 		return RG_OK;
 	}
-	PTRY(pool_alloc(dev, (void **)&RA, valid * sizeof(Rec<W>)));
-	PTRY(hipMemcpyAsync(d_small + OFF_SEG, hs.data() + OFF_SEG, (257 + 256) * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
-	PTRY(hipMemcpyAsync(d_tile_first, tile_first.data(), 257 * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
-	// 2. coarse pass
-	hipLaunchKernelGGL((k_scatter<W, false>), dim3((unsigned)((n_in + SCATTER_TILE - 1) / SCATTER_TILE)), dim3(256), 0, h->stream, R1, n_in, m,
-	                   (const unsigned long long *)nullptr, (const uint32_t *)nullptr, d_small + OFF_CA, RA);
-	PTRY(hipGetLastError());
-	// 3. fine pass: histogram, scan on the host, scatter back into R1
-	hipLaunchKernelGGL(k_fine_hist<W>, dim3(ntilesB), dim3(256), 0, h->stream, RA, m, d_small + OFF_SEG, d_tile_first, d_small + OFF_FH);
-	PTRY(hipGetLastError());
-	PTRY(hipMemcpyAsync(hs.data() + OFF_FH, d_small + OFF_FH, NB_BUCKETS * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-	PTRY(hipStreamSynchronize(h->stream));
-	{
-		unsigned long long run = 0;
-		for (int i = 0; i < NB_BUCKETS; ++i) {
-			hs[OFF_FB + i] = run;
-			hs[OFF_CB + i] = run;
-			run += hs[OFF_FH + i];
+	PTRY(pool_alloc(dev, (void **)&buf[1], valid * sizeof(Rec<W>)));
+
+	// 2. partition levels
+	int cur = 0;                                      // buf[cur] holds the level's input
+	std::vector<unsigned long long> seg_begin = {0, n_in};  // host copy of the current segmentation
+	std::vector<uint32_t> tile_first;
+	int used_bits = 0;
+	for (int level = 0; level < 3 && dbits[level] > 0; ++level) {
+		const uint32_t S = (uint32_t)seg_begin.size() - 1;
+		const int db = dbits[level];
+		const int shift = 24 - used_bits - db;
+		tile_first.assign(S + 1, 0);
+		uint64_t ntiles = 0;
+		for (uint32_t sgi = 0; sgi < S; ++sgi) {
+			tile_first[sgi] = (uint32_t)ntiles;
+			ntiles += (seg_begin[sgi + 1] - seg_begin[sgi] + SCATTER_TILE - 1) / SCATTER_TILE;
 		}
-		hs[OFF_FB + NB_BUCKETS] = run;
-		if (run != valid) {
-			cleanup();
-			return fail(h, RG_ERR_STATE, "partition lost records: %llu of %llu", run, (unsigned long long)valid);
+		tile_first[S] = (uint32_t)ntiles;
+		PTRY(hipMemcpyAsync(d_seg, seg_begin.data(), (S + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
+		PTRY(hipMemcpyAsync(d_tile, tile_first.data(), (S + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+		const uint64_t nout = (uint64_t)S << db;  // buckets after this level
+		if (level > 0) {  // level 0's histogram came out of k_superkmers
+			PTRY(hipMemsetAsync(d_hist, 0, nout * sizeof(unsigned long long), h->stream));
+			hipLaunchKernelGGL(k_level_hist<W>, dim3((unsigned)ntiles), dim3(256), 0, h->stream, buf[cur], m, S, d_seg, d_tile, shift, db, d_hist);
+			PTRY(hipGetLastError());
+		}
+		// exclusive scan -> d_begin[nout+1]; the scatter's cursors are a copy of it (reusing d_hist)
+		const uint32_t nblk = (uint32_t)((nout + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK);
+		hipLaunchKernelGGL(k_scan_local, dim3(nblk), dim3(256), 0, h->stream, d_hist, d_begin, nout, d_sums);
+		hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(64), 0, h->stream, d_sums, nblk, d_sums + nblk);
+		hipLaunchKernelGGL(k_scan_add, dim3(nblk), dim3(256), 0, h->stream, d_begin, nout, d_sums, d_sums + nblk, d_hist);
+		PTRY(hipGetLastError());
+		hipLaunchKernelGGL(k_scatter<W>, dim3((unsigned)ntiles), dim3(256), 0, h->stream, buf[cur], m, S, d_seg, d_tile, shift, db, d_hist,
+		                   buf[cur ^ 1]);
+		PTRY(hipGetLastError());
+		used_bits += db;
+		cur ^= 1;
+		if (level < 2 && dbits[level + 1] > 0) {  // the next level needs this segmentation on the host
+			seg_begin.resize(nout + 1);
+			PTRY(hipMemcpyAsync(seg_begin.data(), d_begin, (nout + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+			PTRY(hipStreamSynchronize(h->stream));
+			if (seg_begin[nout] != valid) {
+				cleanup();
+				return fail(h, RG_ERR_STATE, "partition level %d lost records: %llu of %llu", level, seg_begin[nout], (unsigned long long)valid);
+			}
 		}
 	}
-	PTRY(hipMemcpyAsync(d_small + OFF_FB, hs.data() + OFF_FB, (2 * NB_BUCKETS + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
-	hipLaunchKernelGGL((k_scatter<W, true>), dim3(ntilesB), dim3(256), 0, h->stream, RA, valid, m, d_small + OFF_SEG, d_tile_first,
-	                   d_small + OFF_CB, R1);
-	PTRY(hipGetLastError());
-	// 4. aggregate per fine bucket into the log
-	size_t free_b = 0, total_b = 0;
-	PTRY(hipMemGetInfo(&free_b, &total_b));
-	uint64_t log_cap = std::min<uint64_t>(occ_bound, (uint64_t)(free_b * 0.4) / sizeof(Slot));
-	if (log_cap < 1024) log_cap = 1024;
-	Slot *log = nullptr;
-	// a pooled block of a previous run may already fit
+	// 3. aggregate per bucket into the log.  The log holds one entry per distinct k-mer of a bucket
+	// flush; a quarter of the occurrences is a deterministic size (the pool reuses the block) that only
+	// low-coverage inputs exceed -- they fall back to the direct sweep
+	uint64_t log_cap = std::min<uint64_t>(occ_bound, std::max<uint64_t>(occ_bound / 4, 1ull << 20));
 	if (pool_alloc(dev, (void **)&log, log_cap * sizeof(Slot)) != hipSuccess) {
 		(void)hipGetLastError();
 		cleanup();
 		return RG_OK;
 	}
-	hipLaunchKernelGGL(k_aggregate<W>, dim3(2048), dim3(256), 0, h->stream, R1, d_small + OFF_FB, (uint32_t)NB_BUCKETS, k, log, log_cap,
-	                   h->d_counters);
+	hipLaunchKernelGGL(k_aggregate<W>, dim3((unsigned)std::min<uint64_t>(NBUCK, 2048)), dim3(256), 0, h->stream, buf[cur], d_begin,
+	                   (uint32_t)NBUCK, k, log, log_cap, h->d_counters);
 	hipError_t e = hipGetLastError();
 	if (e == hipSuccess) rc = sync_counters(h);
 	cleanup();
@@ -856,6 +880,10 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	*out_log = log;
 	*out_n = h->h_counters[PC_LOG_CURSOR];
 	*ok = true;
+	if (getenv("RG_DEBUG"))
+		fprintf(stderr, "[raygraph] partitioned sweep: %llu reads, %llu occurrences, 2^%d buckets, %llu record slots (%llu valid, cap %llu), log %llu entries (cap %llu), %llu LDS spills\n",
+		        (unsigned long long)total_reads, (unsigned long long)h->h_counters[C_OCC], bits, (unsigned long long)n_in, (unsigned long long)valid,
+		        (unsigned long long)rec_cap, (unsigned long long)*out_n, (unsigned long long)log_cap, (unsigned long long)h->h_counters[PC_LDS_SPILL]);
 #undef PTRY
 	return RG_OK;
 }
@@ -1005,7 +1033,7 @@ int rg_count_local(rg_handle *h) {
 		uint64_t occ_bound = 0;
 		for (const ReadBatch &b : h->reads)
 			if (b.maxlen >= (uint32_t)k) occ_bound += b.n * ((uint64_t)b.maxlen - k + 1);
-		const uint32_t flags = (uint32_t)h->cfg.reserved0;
+		const uint32_t flags = (uint32_t)h->cfg.reserved0 & 0xFFu;
 		if (!(flags & 2u) && ((flags & 1u) || occ_bound >= (1ull << 24))) {
 			Slot *log = nullptr;
 			uint64_t n_log = 0;

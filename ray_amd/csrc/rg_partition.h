@@ -30,7 +30,8 @@ namespace rg {
 static constexpr int MMER_MAX = 15;          // minimizer length (<= 15 so that it fits 30 bits)
 static constexpr uint64_t REC_INVALID = ~0ull;
 static constexpr uint32_t REC_CHUNK = 1024;  // records a wavefront claims at a time from the output cursor
-static constexpr int NB_COARSE = 256, NB_FINE = 256, NB_BUCKETS = NB_COARSE * NB_FINE;
+static constexpr int NB_COARSE = 256;  // first-level digit; further levels split by up to 8 more bits each
+static constexpr int MAX_BUCKET_BITS = 24;
 
 // A record: 2*W words of bases (2 bits each, same order as the packed read) then a header word:
 //   bits  0..15 position of the first k-mer in its read     bits 24..30 offset of the minimizer in the record
@@ -52,7 +53,7 @@ __host__ __device__ inline uint32_t fmix32(uint32_t h) {  // murmur3 finalizer: 
 }
 // bucket of a canonical minimizer; a different mix than the one that orders minimizers, whose small
 // values are exactly the ones that get picked
-__host__ __device__ inline uint32_t bucket16(uint32_t canon) { return fmix32(canon * 0x2545F491u + 0x68E31DA4u) >> 16; }
+__host__ __device__ inline uint32_t bucket24(uint32_t canon) { return fmix32(canon * 0x2545F491u + 0x68E31DA4u) >> 8; }
 
 __host__ __device__ inline int lmax_for(int W, int k) {
 	int l = 64 * W - k - 1;
@@ -106,7 +107,7 @@ __device__ __forceinline__ uint32_t rec_bucket(const Rec<W> &r, int m) {
 	for (int i = 0; i < 2 * W; ++i) b[i] = r.w[i];
 	uint32_t moff = (uint32_t)(r.w[2 * W] >> 24) & 127u;
 	uint64_t f = rec_ext<W>(b, moff) & ((1ull << (2 * m)) - 1);
-	return bucket16(canon_mmer(f, m));
+	return bucket24(canon_mmer(f, m));
 }
 
 enum PartCounter { PC_REC_CURSOR = 16, PC_REC_OVF, PC_LOG_CURSOR, PC_LOG_OVF, PC_LDS_SPILL };
@@ -116,7 +117,7 @@ enum PartCounter { PC_REC_CURSOR = 16, PC_REC_OVF, PC_LOG_CURSOR, PC_LOG_OVF, PC
 template <int W>
 __global__ __launch_bounds__(256) void k_superkmers(const uint64_t *__restrict__ P, const uint64_t *__restrict__ offsets,
                                                     const uint32_t *__restrict__ lengths, uint64_t nreads, uint64_t read_id_base,
-                                                    int k, int m, Rec<W> *__restrict__ recs, uint64_t rec_cap,
+                                                    int k, int m, int bits, Rec<W> *__restrict__ recs, uint64_t rec_cap,
                                                     unsigned long long *__restrict__ counters,
                                                     unsigned long long *__restrict__ coarse_hist) {
 	constexpr int NB = 2 * W;
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(256) void k_superkmers(const uint64_t *__restrict__
 				}
 			const uint32_t jstar = v & 127u;
 			const uint32_t canon = active ? s_cn[wave][jstar] : 0;
-			const uint32_t bucket = bucket16(canon);
+			const uint32_t bucket = bucket24(canon) >> (24 - bits);  // runs share the full bucket id
 			uint32_t prevb = __shfl_up(bucket, 1);
 			bool start = active && (lane == 0 || bucket != prevb);
 			unsigned long long ballot = __ballot(start);
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(256) void k_superkmers(const uint64_t *__restrict__
 				rec.w[NB] = (uint64_t)p | ((uint64_t)(len - 1) << 16) | ((uint64_t)hasL << 22) | ((uint64_t)hasR << 23) |
 				            ((uint64_t)moff << 24) | ((read_id_base + r) << 31);
 				recs[chunk_base + chunk_used + idx] = rec;
-				atomicAdd(&s_hist[bucket >> 8], 1u);
+				atomicAdd(&s_hist[bucket >> (bits - 8)], 1u);
 			}
 			chunk_used += c;
 			__builtin_amdgcn_wave_barrier();
@@ -217,14 +218,26 @@ __global__ __launch_bounds__(256) void k_superkmers(const uint64_t *__restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
-// One partition pass.  FINE=false: input = k_superkmers output (with holes), digit = bucket >> 8,
-// cursors[256].  FINE=true: input = coarse-sorted records, a tile never crosses a coarse bucket
-// (tile_first[c] = first tile of coarse bucket c), digit = bucket & 255, cursors[c*256+digit].
+// One partition level.  The input is cut into S segments (seg_begin[S+1]; level 1: the single segment
+// [0, n_in) of k_superkmers output, holes included).  A tile of SCATTER_TILE records never crosses a
+// segment (tile_first[s] = first tile of segment s).  digit = (bucket24 >> shift) & (2^dbits - 1);
+// the records of segment s with digit d go to the range that starts at cursors[(s << dbits) + d].
 static constexpr int SCATTER_TILE = 2048;
-template <int W, bool FINE>
-__global__ __launch_bounds__(256) void k_scatter(const Rec<W> *__restrict__ in, uint64_t n_in, int m,
-                                                 const unsigned long long *__restrict__ seg_begin /* FINE: [257] */,
-                                                 const uint32_t *__restrict__ tile_first /* FINE: [257] */,
+
+__device__ __forceinline__ uint32_t find_segment(const uint32_t *__restrict__ tile_first, uint32_t S, uint32_t tile) {
+	uint32_t lo = 0, hi = S;  // largest s with tile_first[s] <= tile
+	while (hi - lo > 1) {
+		uint32_t mid = (lo + hi) >> 1;
+		if (tile_first[mid] <= tile) lo = mid;
+		else hi = mid;
+	}
+	return lo;
+}
+
+template <int W>
+__global__ __launch_bounds__(256) void k_scatter(const Rec<W> *__restrict__ in, int m, uint32_t S,
+                                                 const unsigned long long *__restrict__ seg_begin,
+                                                 const uint32_t *__restrict__ tile_first, int shift, int dbits,
                                                  unsigned long long *__restrict__ cursors, Rec<W> *__restrict__ out) {
 	constexpr int NB = 2 * W, PER = SCATTER_TILE / 256;
 	__shared__ Rec<W> s_rec[SCATTER_TILE];
@@ -232,23 +245,10 @@ __global__ __launch_bounds__(256) void k_scatter(const Rec<W> *__restrict__ in, 
 	__shared__ uint32_t s_cnt[256], s_off[256];
 	__shared__ unsigned long long s_gbase[256];
 	__shared__ uint32_t s_scan[256];
-	uint64_t begin, end;
-	uint32_t coarse = 0;
-	if (FINE) {
-		// coarse bucket of this tile: largest c with tile_first[c] <= blockIdx.x
-		int lo = 0, hi = NB_COARSE;
-		while (hi - lo > 1) {
-			int mid = (lo + hi) >> 1;
-			if (tile_first[mid] <= blockIdx.x) lo = mid;
-			else hi = mid;
-		}
-		coarse = (uint32_t)lo;
-		begin = seg_begin[coarse] + (uint64_t)(blockIdx.x - tile_first[coarse]) * SCATTER_TILE;
-		end = begin + SCATTER_TILE < seg_begin[coarse + 1] ? begin + SCATTER_TILE : seg_begin[coarse + 1];
-	} else {
-		begin = (uint64_t)blockIdx.x * SCATTER_TILE;
-		end = begin + SCATTER_TILE < n_in ? begin + SCATTER_TILE : n_in;
-	}
+	const uint32_t seg = find_segment(tile_first, S, blockIdx.x);
+	const uint64_t begin = seg_begin[seg] + (uint64_t)(blockIdx.x - tile_first[seg]) * SCATTER_TILE;
+	const uint64_t end = begin + SCATTER_TILE < seg_begin[seg + 1] ? begin + SCATTER_TILE : seg_begin[seg + 1];
+	const uint32_t dmask = (1u << dbits) - 1;
 	s_cnt[threadIdx.x] = 0;
 	__syncthreads();
 	Rec<W> mine[PER];
@@ -261,14 +261,13 @@ __global__ __launch_bounds__(256) void k_scatter(const Rec<W> *__restrict__ in, 
 		if (i < end) {
 			mine[j] = in[i];
 			if (mine[j].w[NB] != REC_INVALID) {
-				uint32_t b = rec_bucket<W>(mine[j], m);
-				dig[j] = FINE ? (b & 255u) : (b >> 8);
+				dig[j] = (rec_bucket<W>(mine[j], m) >> shift) & dmask;
 				rank[j] = atomicAdd(&s_cnt[dig[j]], 1u);
 			}
 		}
 	}
 	__syncthreads();
-	// exclusive scan of the 256 counts (Hillis-Steele), and one cursor claim per non-empty digit
+	// exclusive scan of the digit counts (Hillis-Steele) and one cursor claim per non-empty digit
 	{
 		uint32_t c = s_cnt[threadIdx.x];
 		s_scan[threadIdx.x] = c;
@@ -281,9 +280,7 @@ __global__ __launch_bounds__(256) void k_scatter(const Rec<W> *__restrict__ in, 
 		}
 		s_off[threadIdx.x] = s_scan[threadIdx.x] - c;
 		unsigned long long g = 0;
-		if (c) {
-			g = atomicAdd(&cursors[(FINE ? coarse * 256u : 0u) + threadIdx.x], (unsigned long long)c);
-		}
+		if (c) g = atomicAdd(&cursors[((uint64_t)seg << dbits) + threadIdx.x], (unsigned long long)c);
 		s_gbase[threadIdx.x] = g;
 	}
 	__syncthreads();
@@ -302,30 +299,79 @@ __global__ __launch_bounds__(256) void k_scatter(const Rec<W> *__restrict__ in, 
 	}
 }
 
-// fine-digit histogram of the coarse-sorted records: hist[c*256 + (bucket & 255)]
+// digit histogram of one level: hist[(seg << dbits) + digit]
 template <int W>
-__global__ __launch_bounds__(256) void k_fine_hist(const Rec<W> *__restrict__ in, int m,
-                                                   const unsigned long long *__restrict__ seg_begin,
-                                                   const uint32_t *__restrict__ tile_first,
-                                                   unsigned long long *__restrict__ hist) {
+__global__ __launch_bounds__(256) void k_level_hist(const Rec<W> *__restrict__ in, int m, uint32_t S,
+                                                    const unsigned long long *__restrict__ seg_begin,
+                                                    const uint32_t *__restrict__ tile_first, int shift, int dbits,
+                                                    unsigned long long *__restrict__ hist) {
 	__shared__ uint32_t s_cnt[256];
-	int lo = 0, hi = NB_COARSE;
-	while (hi - lo > 1) {
-		int mid = (lo + hi) >> 1;
-		if (tile_first[mid] <= blockIdx.x) lo = mid;
-		else hi = mid;
-	}
-	const uint32_t coarse = (uint32_t)lo;
-	const uint64_t begin = seg_begin[coarse] + (uint64_t)(blockIdx.x - tile_first[coarse]) * SCATTER_TILE;
-	const uint64_t end = begin + SCATTER_TILE < seg_begin[coarse + 1] ? begin + SCATTER_TILE : seg_begin[coarse + 1];
+	const uint32_t seg = find_segment(tile_first, S, blockIdx.x);
+	const uint64_t begin = seg_begin[seg] + (uint64_t)(blockIdx.x - tile_first[seg]) * SCATTER_TILE;
+	const uint64_t end = begin + SCATTER_TILE < seg_begin[seg + 1] ? begin + SCATTER_TILE : seg_begin[seg + 1];
+	const uint32_t dmask = (1u << dbits) - 1;
 	s_cnt[threadIdx.x] = 0;
 	__syncthreads();
 	for (uint64_t i = begin + threadIdx.x; i < end; i += 256) {
 		Rec<W> r = in[i];
-		atomicAdd(&s_cnt[rec_bucket<W>(r, m) & 255u], 1u);
+		if (r.w[2 * W] != REC_INVALID) atomicAdd(&s_cnt[(rec_bucket<W>(r, m) >> shift) & dmask], 1u);
 	}
 	__syncthreads();
-	if (s_cnt[threadIdx.x]) atomicAdd(&hist[coarse * 256u + threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
+	if (threadIdx.x <= dmask && s_cnt[threadIdx.x])
+		atomicAdd(&hist[((uint64_t)seg << dbits) + threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
+}
+
+// exclusive scan of n counters, three small kernels (block sums, scan of the sums, add back)
+static constexpr int SCAN_PER_BLOCK = 2048;
+__global__ __launch_bounds__(256) void k_scan_local(const unsigned long long *__restrict__ in, unsigned long long *__restrict__ out,
+                                                    uint64_t n, unsigned long long *__restrict__ block_sums) {
+	__shared__ unsigned long long s_t[256];
+	const uint64_t base = (uint64_t)blockIdx.x * SCAN_PER_BLOCK + (uint64_t)threadIdx.x * 8;
+	unsigned long long v[8], sum = 0;
+#pragma unroll
+	for (int j = 0; j < 8; ++j) {
+		v[j] = (base + j < n) ? in[base + j] : 0;
+		sum += v[j];
+	}
+	s_t[threadIdx.x] = sum;
+	__syncthreads();
+	for (int d = 1; d < 256; d <<= 1) {
+		unsigned long long t = (threadIdx.x >= (uint32_t)d) ? s_t[threadIdx.x - d] : 0;
+		__syncthreads();
+		s_t[threadIdx.x] += t;
+		__syncthreads();
+	}
+	unsigned long long run = s_t[threadIdx.x] - sum;
+#pragma unroll
+	for (int j = 0; j < 8; ++j) {
+		if (base + j < n) out[base + j] = run;
+		run += v[j];
+	}
+	if (threadIdx.x == 255) block_sums[blockIdx.x] = s_t[255];
+}
+__global__ void k_scan_sums(unsigned long long *__restrict__ block_sums, uint32_t nblocks, unsigned long long *__restrict__ total) {
+	if (threadIdx.x == 0 && blockIdx.x == 0) {
+		unsigned long long run = 0;
+		for (uint32_t i = 0; i < nblocks; ++i) {
+			unsigned long long t = block_sums[i];
+			block_sums[i] = run;
+			run += t;
+		}
+		*total = run;
+	}
+}
+__global__ __launch_bounds__(256) void k_scan_add(unsigned long long *__restrict__ out, uint64_t n,
+                                                  const unsigned long long *__restrict__ block_sums,
+                                                  const unsigned long long *__restrict__ total,
+                                                  unsigned long long *__restrict__ copy) {
+	const uint64_t base = (uint64_t)blockIdx.x * SCAN_PER_BLOCK;
+	const unsigned long long add = block_sums[blockIdx.x];
+	for (uint64_t i = base + threadIdx.x; i < base + SCAN_PER_BLOCK && i < n; i += 256) {
+		unsigned long long v = out[i] + add;
+		out[i] = v;
+		if (copy) copy[i] = v;
+	}
+	if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = *total;
 }
 
 // ------------------------------------------------------------------------------------------------

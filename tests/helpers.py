@@ -29,9 +29,10 @@ def assert_records_equal(a, b, what=""):
 
 
 def gpu_vs_oracle(ro, packed, offsets, lengths, k, bloom_bits=None, W=None, purge=True, batches=1, tmpdir=None,
-                  sweeps=(1, 2)):
-    """single-rank parity through the C ABI, once per sweep implementation (1 = partitioned: super-k-mer
-    records + LDS aggregation, 2 = direct: one table upsert per occurrence); returns the oracle outputs"""
+                  sweeps=(1 | (8 << 8), 1 | (12 << 8), 1 | (19 << 8), 2)):
+    """single-rank parity through the C ABI, once per sweep implementation: the partitioned sweep
+    (super-k-mer records + LDS aggregation) with 2^8, 2^12 and 2^19 buckets = one, two and three partition
+    levels, and the direct sweep (one table upsert per occurrence); returns the oracle outputs"""
     want = oracle_run(ro, packed, offsets, lengths, k, 1, bloom_bits, W, purge)
     for sweep in sweeps:
         want["builder"] = _gpu_check(ro, want, packed, offsets, lengths, k, bloom_bits, W, purge, batches, tmpdir, sweep)
@@ -51,8 +52,8 @@ def _gpu_check(ro, want, packed, offsets, lengths, k, bloom_bits, W, purge, batc
             b.add_reads(packed, offsets[lo:hi], lengths[lo:hi])
     b.count_kmers()
     st = b.stats()
-    tag = "sweep %d: " % sweep
-    assert st["sweep_partitioned"] == (1 if sweep == 1 else 0), tag + "wrong sweep ran"
+    tag = "sweep 0x%x: " % sweep
+    assert st["sweep_partitioned"] == (1 if (sweep & 0xFF) == 1 else 0), tag + "wrong sweep ran"
     assert st["occurrences"] == want["occ"], tag + "occurrences"
     assert b.size_() == want["size"], tag + "size"
     assert_records_equal(b.export(), want["pass1"], tag + "after pass 1")
