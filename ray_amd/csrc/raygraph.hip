@@ -189,6 +189,7 @@ __global__ __launch_bounds__(BLOCK) void k_merge(const Slot *__restrict__ in, ui
 	bool failed = false;
 	for (; i < n; i += stride) {
 		Slot v = in[i];
+		if (v.k0 == EMPTY) continue;  // unused entry of a log chunk
 		uint64_t add = v.meta & COUNT_MASK;
 		uint32_t em = (uint32_t)(v.meta >> PEND_SHIFT) & 0xFFu;
 		if (!upsert<W>(tab, mask, v.k0, W == 2 ? v.k1 : 0, v.stamp, add, em, claimed)) failed = true;
@@ -290,10 +291,9 @@ __global__ __launch_bounds__(BLOCK) void k_admit(Slot *__restrict__ tab, uint64_
 			from_internal<W>(v.k0, v.k1, K0, K1);
 			const uint64_t origin = hash2<W>(K0, K1);
 			bool fp = true;  // all 8 bits were set before this key first arrived
-#pragma unroll
-			for (int j = 0; j < 8; ++j) {
+			for (int j = 0; j < 8 && fp; ++j) {
 				uint64_t b = (origin ^ BLOOM_MAGIC[j]) % m_bits;
-				if (bitstamp[b] == v.stamp) fp = false;  // this key's first arrival set the bit
+				if (bitstamp[b] == v.stamp) fp = false;  // this key's first arrival set the bit: one proof is enough
 			}
 			if (fp) cov = N + 1;
 			else {
@@ -858,13 +858,14 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	// 3. aggregate per bucket into the log.  The log holds one entry per distinct k-mer of a bucket
 	// flush; a quarter of the occurrences is a deterministic size (the pool reuses the block) that only
 	// low-coverage inputs exceed -- they fall back to the direct sweep
-	uint64_t log_cap = std::min<uint64_t>(occ_bound, std::max<uint64_t>(occ_bound / 4, 1ull << 20));
+	const unsigned agg_grid = (unsigned)std::min<uint64_t>(NBUCK, 3072);
+	uint64_t log_cap = std::min<uint64_t>(occ_bound, std::max<uint64_t>(occ_bound / 4, 1ull << 20)) + (uint64_t)agg_grid * LOG_CHUNK;
 	if (pool_alloc(dev, (void **)&log, log_cap * sizeof(Slot)) != hipSuccess) {
 		(void)hipGetLastError();
 		cleanup();
 		return RG_OK;
 	}
-	hipLaunchKernelGGL(k_aggregate<W>, dim3((unsigned)std::min<uint64_t>(NBUCK, 2048)), dim3(256), 0, h->stream, buf[cur], d_begin,
+	hipLaunchKernelGGL(k_aggregate<W>, dim3(agg_grid), dim3(256), 0, h->stream, buf[cur], d_begin,
 	                   (uint32_t)NBUCK, k, log, log_cap, h->d_counters);
 	hipError_t e = hipGetLastError();
 	if (e == hipSuccess) rc = sync_counters(h);

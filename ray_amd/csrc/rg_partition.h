@@ -375,20 +375,34 @@ __global__ __launch_bounds__(256) void k_scan_add(unsigned long long *__restrict
 }
 
 // ------------------------------------------------------------------------------------------------
-// One workgroup per fine bucket: expand the records and aggregate per canonical k-mer in LDS.
-static constexpr uint32_t AGG_SLOTS = 2048;                // 64 KB of LDS
-static constexpr uint32_t AGG_FLUSH = AGG_SLOTS * 7 / 10;  // flush when this full
+// One workgroup per bucket at a time: expand the records and aggregate per canonical k-mer in an LDS
+// hash table (structure of arrays, 24 B per slot for one-word keys), then append the distinct entries
+// to the log.  Slots claimed since the last flush are remembered in a list, so a flush costs O(distinct
+// keys), not O(table).  Log space is reserved LOG_CHUNK entries at a time per workgroup (one global
+// atomic per chunk instead of one per bucket); unused entries of a chunk are marked EMPTY.
+static constexpr uint32_t AGG_SLOTS = 1024;
+static constexpr uint32_t AGG_FLUSH = AGG_SLOTS * 7 / 10;
+static constexpr uint32_t LOG_CHUNK = 2048;
 
 template <int W>
-__device__ __forceinline__ bool lds_upsert(Slot *tab, uint32_t *fill, uint64_t i0, uint64_t i1, uint64_t stamp, uint32_t emask) {
+struct AggTable {
+	uint64_t k0[AGG_SLOTS];
+	uint64_t k1[W == 2 ? AGG_SLOTS : 1];
+	uint64_t stamp[AGG_SLOTS];
+	uint64_t meta[AGG_SLOTS];
+	uint16_t list[AGG_SLOTS];
+};
+
+template <int W>
+__device__ __forceinline__ bool lds_upsert(AggTable<W> &t, uint32_t *fill, uint64_t i0, uint64_t i1, uint64_t stamp, uint32_t emask) {
 	uint32_t s = (uint32_t)slot_hash<W>(i0, i1) & (AGG_SLOTS - 1);
 	for (uint32_t probe = 0; probe < AGG_SLOTS; ++probe) {
-		Slot *p = tab + s;
-		uint64_t c0 = p->k0;
+		uint64_t c0 = t.k0[s];
 		if (c0 == EMPTY) {
-			uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long *>(&p->k0), EMPTY, i0);
+			uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long *>(&t.k0[s]), EMPTY, i0);
 			if (prev == EMPTY) {
-				atomicAdd(fill, 1u);
+				uint32_t idx = atomicAdd(fill, 1u);
+				t.list[idx] = (uint16_t)s;
 				c0 = i0;
 			} else {
 				c0 = prev;
@@ -397,19 +411,19 @@ __device__ __forceinline__ bool lds_upsert(Slot *tab, uint32_t *fill, uint64_t i
 		if (c0 == i0) {
 			bool match = true;
 			if (W == 2) {
-				uint64_t c1 = p->k1;
+				uint64_t c1 = t.k1[s];
 				if (c1 == EMPTY) {
-					uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long *>(&p->k1), EMPTY, i1);
+					uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long *>(&t.k1[s]), EMPTY, i1);
 					c1 = (prev == EMPTY) ? i1 : prev;
 				}
 				match = (c1 == i1);
 			}
 			if (match) {
-				if (stamp < p->stamp) atomicMin(reinterpret_cast<unsigned long long *>(&p->stamp), stamp);
+				if (stamp < t.stamp[s]) atomicMin(reinterpret_cast<unsigned long long *>(&t.stamp[s]), stamp);
 				uint64_t add = 1ull;
-				uint32_t pend = (uint32_t)(p->meta >> PEND_SHIFT) & 0xFFu;
-				if (emask & ~pend) atomicOr(reinterpret_cast<unsigned long long *>(&p->meta), (uint64_t)emask << PEND_SHIFT);
-				atomicAdd(reinterpret_cast<unsigned long long *>(&p->meta), add);
+				uint32_t pend = (uint32_t)(t.meta[s] >> PEND_SHIFT) & 0xFFu;
+				if (emask & ~pend) atomicOr(reinterpret_cast<unsigned long long *>(&t.meta[s]), (uint64_t)emask << PEND_SHIFT);
+				atomicAdd(reinterpret_cast<unsigned long long *>(&t.meta[s]), add);
 				return true;
 			}
 		}
@@ -419,60 +433,78 @@ __device__ __forceinline__ bool lds_upsert(Slot *tab, uint32_t *fill, uint64_t i
 }
 
 template <int W>
-__global__ __launch_bounds__(256) void k_aggregate(const Rec<W> *__restrict__ recs, const unsigned long long *__restrict__ fine_begin,
+__global__ __launch_bounds__(256) void k_aggregate(const Rec<W> *__restrict__ recs, const unsigned long long *__restrict__ bucket_begin,
                                                    uint32_t nbuckets, int k, Slot *__restrict__ log, uint64_t log_cap,
                                                    unsigned long long *__restrict__ counters) {
 	constexpr int NB = 2 * W;
-	__shared__ Slot s_tab[AGG_SLOTS];
-	__shared__ uint32_t s_fill, s_nout;
-	__shared__ unsigned long long s_logbase;
+	__shared__ AggTable<W> s_t;
+	__shared__ uint32_t s_fill, s_chunk_used;
+	__shared__ unsigned long long s_chunk_base, s_new_base;
 	const uint64_t mask0 = (2 * k >= 64) ? ~0ull : ((1ull << (2 * k)) - 1);
 	const uint64_t mask1 = (k > 32) ? ((1ull << (2 * k - 64)) - 1) : 0ull;
+	const unsigned long long NO_CHUNK = ~0ull;
 
+	// all threads call this at the same point (the condition is uniform: s_fill is read after a barrier).
+	// The flushed entries continue the workgroup's current log chunk and spill over into a new one.
 	auto flush = [&]() {
-		// entries of this thread's slots -> log
-		uint32_t mine = 0;
-		for (uint32_t i = threadIdx.x; i < AGG_SLOTS; i += 256)
-			if (s_tab[i].k0 != EMPTY) mine++;
-		if (threadIdx.x == 0) s_nout = 0;
-		__syncthreads();
-		uint32_t base = mine ? atomicAdd(&s_nout, mine) : 0;
-		__syncthreads();
-		if (threadIdx.x == 0) {
-			unsigned long long g = s_nout ? atomicAdd(&counters[PC_LOG_CURSOR], (unsigned long long)s_nout) : 0ull;
-			if (g + s_nout > log_cap) {
-				atomicAdd(&counters[PC_LOG_OVF], 1ull);
-				g = ~0ull;
+		const uint32_t n = s_fill;
+		if (n == 0) return;
+		const uint32_t room = (s_chunk_base == NO_CHUNK) ? 0u : LOG_CHUNK - s_chunk_used;
+		const unsigned long long old_dst = s_chunk_base + s_chunk_used;
+		if (n > room) {
+			__syncthreads();
+			if (threadIdx.x == 0) {
+				unsigned long long g = atomicAdd(&counters[PC_LOG_CURSOR], (unsigned long long)LOG_CHUNK);
+				if (g + LOG_CHUNK > log_cap) atomicAdd(&counters[PC_LOG_OVF], 1ull);
+				s_new_base = g;
 			}
-			s_logbase = g;
-			s_fill = 0;
+			__syncthreads();
+		}
+		const unsigned long long new_dst = s_new_base;
+		for (uint32_t i = threadIdx.x; i < n; i += 256) {
+			const uint32_t sl = s_t.list[i];
+			const unsigned long long dst = (i < room) ? old_dst + i : new_dst + (i - room);
+			if (dst < log_cap) {
+				Slot e;
+				e.k0 = s_t.k0[sl];
+				e.k1 = (W == 2) ? s_t.k1[sl] : EMPTY;
+				e.stamp = s_t.stamp[sl];
+				e.meta = s_t.meta[sl];
+				log[dst] = e;
+			}
+			s_t.k0[sl] = EMPTY;
+			if (W == 2) s_t.k1[sl] = EMPTY;
+			s_t.stamp[sl] = INF_STAMP;
+			s_t.meta[sl] = 0;
 		}
 		__syncthreads();
-		const unsigned long long g = s_logbase;
-		for (uint32_t i = threadIdx.x; i < AGG_SLOTS; i += 256) {
-			if (s_tab[i].k0 != EMPTY) {
-				if (g != ~0ull) log[g + base] = s_tab[i];
-				base++;
+		if (threadIdx.x == 0) {
+			if (n > room) {
+				s_chunk_base = new_dst;
+				s_chunk_used = n - room;
+			} else {
+				s_chunk_used += n;
 			}
-			s_tab[i].k0 = EMPTY;
-			s_tab[i].k1 = EMPTY;
-			s_tab[i].stamp = INF_STAMP;
-			s_tab[i].meta = 0;
+			s_fill = 0;
 		}
 		__syncthreads();
 	};
 
 	for (uint32_t i = threadIdx.x; i < AGG_SLOTS; i += 256) {
-		s_tab[i].k0 = EMPTY;
-		s_tab[i].k1 = EMPTY;
-		s_tab[i].stamp = INF_STAMP;
-		s_tab[i].meta = 0;
+		s_t.k0[i] = EMPTY;
+		if (W == 2) s_t.k1[i] = EMPTY;
+		s_t.stamp[i] = INF_STAMP;
+		s_t.meta[i] = 0;
 	}
-	if (threadIdx.x == 0) s_fill = 0;
+	if (threadIdx.x == 0) {
+		s_fill = 0;
+		s_chunk_used = 0;
+		s_chunk_base = NO_CHUNK;
+	}
 	__syncthreads();
 
 	for (uint32_t b = blockIdx.x; b < nbuckets; b += gridDim.x) {
-		const uint64_t begin = fine_begin[b], end = fine_begin[b + 1];
+		const uint64_t begin = bucket_begin[b], end = bucket_begin[b + 1];
 		for (uint64_t base = begin; base < end; base += 256) {
 			const uint64_t ri = base + threadIdx.x;
 			if (ri < end) {
@@ -499,14 +531,13 @@ __global__ __launch_bounds__(256) void k_aggregate(const Rec<W> *__restrict__ re
 					if (has_next) em |= use_rc ? (1u << (3 - nb)) : (1u << (4 + nb));
 					uint64_t i0, i1;
 					to_internal<W>(use_rc ? r0 : f0, use_rc ? r1 : f1, i0, i1);
-					if (W == 1) i1 = EMPTY;
-					if (!lds_upsert<W>(s_tab, &s_fill, i0, i1, stamp0 + i, em)) {
+					if (!lds_upsert<W>(s_t, &s_fill, i0, i1, stamp0 + i, em)) {
 						// LDS table full: this occurrence goes to the log on its own
 						unsigned long long g = atomicAdd(&counters[PC_LOG_CURSOR], 1ull);
 						if (g < log_cap) {
 							Slot e;
 							e.k0 = i0;
-							e.k1 = i1;
+							e.k1 = (W == 2) ? i1 : EMPTY;
 							e.stamp = stamp0 + i;
 							e.meta = 1ull | ((uint64_t)em << PEND_SHIFT);
 							log[g] = e;
@@ -540,6 +571,14 @@ __global__ __launch_bounds__(256) void k_aggregate(const Rec<W> *__restrict__ re
 			if (s_fill > AGG_FLUSH) flush();
 		}
 		flush();
+	}
+	// close the last chunk
+	__syncthreads();
+	{
+		const unsigned long long ob = s_chunk_base;
+		if (ob != NO_CHUNK)
+			for (uint32_t i = s_chunk_used + threadIdx.x; i < LOG_CHUNK; i += 256)
+				if (ob + i < log_cap) log[ob + i].k0 = EMPTY;
 	}
 }
 
