@@ -74,10 +74,16 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    backend = os.environ.get("RAYGRAPH_BENCH_BACKEND", "nccl")  # "gloo": rehearse N ranks on one GPU (host-staged)
+    if backend == "gloo":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(dev))
+        else:
+            dist.init_process_group(backend)
 
     cfg = dict(synth.CONFIGS[args.workload])
     k = cfg["k"]
@@ -128,7 +134,7 @@ def main():
         b.add_edges()                            # RAY_SLAVE_MODE_ADD_EDGES
         mark("add_edges")
         st = b.stats()
-        sweep = b.sweep_time() if profile else (0.0, 0)
+        sweep = b.kernel_profile() if profile else {}
         b.close()
         mark("destroy")
         return st, sweep, (cov, cnt)
@@ -142,18 +148,21 @@ def main():
         one_step()
     barrier()
     t0 = time.perf_counter()
-    sweep_ms, sweep_launches = 0.0, 0
+    kprof = {}
     for _ in range(args.steps):
-        st, sweep, hist = one_step(profile=True)
-        sweep_ms += sweep[0]
-        sweep_launches += sweep[1]
+        st, prof, hist = one_step(profile=True)
+        for name, (ms, n) in prof.items():
+            a = kprof.setdefault(name, [0.0, 0])
+            a[0] += ms
+            a[1] += n
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        rdev = dev if backend == "nccl" else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        tot = torch.tensor([st["stored_pairs"], st["occurrences"], st["candidates"]], dtype=torch.int64, device=dev)
+        tot = torch.tensor([st["stored_pairs"], st["occurrences"], st["candidates"]], dtype=torch.int64, device=rdev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         stored, occ, cand = [int(x) for x in tot.tolist()]
     else:
@@ -164,15 +173,37 @@ def main():
             print("  %-18s %8.2f ms" % (n1, (t1_ - t0_) * 1e3), file=sys.stderr)
     if rank == 0:
         per_step = elapsed / args.steps
-        # dominant kernel: the k-mer sweep (k_count).  Algorithmic bytes per k-mer occurrence (SURVEY.md 8d,
-        # W=1): L/(4n) B of packed read + 16 B table (8 B key compare + 8 B count read-modify-write).
+        # Dominant kernel = the one with the largest HIP-event time per step (events bracket every launch on the
+        # launch stream).  Its algorithmic bytes over its time, against the HBM peak.
         L = cfg["read_len"]
         n_per_read = L - k + 1
-        Kb = 8 * (1 if k <= 31 else 2)
-        bytes_per_occ = L / (4.0 * n_per_read) + Kb + 8
-        occ_rank0 = st["occurrences"]
-        kernel_s = (sweep_ms / 1e3) / args.steps if sweep_ms else float("nan")
-        achieved = bytes_per_occ * occ_rank0 / kernel_s / 1e9 if sweep_ms else None
+        W = 1 if k <= 31 else 2
+        Kb = 8 * W
+        occ0, cand0, recs0 = st["occurrences"], st["candidates"], st["superkmer_records"]
+        rec_bytes = 8 * (2 * W + 1)
+        alg_bytes = {
+            "k_count": occ0 * (L / (4.0 * n_per_read) + Kb + 8),            # read bits + key compare + count RMW
+            "k_superkmers": occ0 * L / (4.0 * n_per_read) + recs0 * rec_bytes,  # read bits in, records out
+            "k_scatter": st["partition_levels"] * 2 * recs0 * rec_bytes,     # records in + out, per level
+            "k_level_hist": max(0, st["partition_levels"] - 1) * recs0 * rec_bytes,
+            "k_aggregate": recs0 * rec_bytes + st["log_entries"] * 32,       # records in, entries out
+            "k_merge": st["log_entries"] * 32 + cand0 * 32,                  # entries in, slots written
+            "k_bloom_touch": cand0 * (32 + 8 * 8),                           # slot + 8 stamp words
+            "k_admit": cand0 * (32 + 8 + 8),                                 # slot + >= 1 stamp word + coverage write
+            "bloom_stamp_fill": st["bloom_bits"] * 8,
+            "k_histogram": st["table_slots"] * 32,
+            "k_publish_edges": st["table_slots"] * 32,
+        }
+        per_kernel = {name: {"ms_per_step": ms / args.steps, "launches_per_step": n / args.steps,
+                             "algorithmic_GBps": (alg_bytes[name] / (ms / args.steps / 1e3) / 1e9) if name in alg_bytes and ms else None}
+                      for name, (ms, n) in kprof.items()}
+        dom = max(kprof, key=lambda nm: kprof[nm][0]) if kprof else None
+        kernel_s = (kprof[dom][0] / 1e3) / args.steps if dom else float("nan")
+        achieved = per_kernel[dom]["algorithmic_GBps"] if dom else None
+        sweep_ms = kprof[dom][0] if dom else 0.0
+        sweep_launches = kprof[dom][1] if dom else 0
+        bytes_per_occ = (alg_bytes[dom] / occ0) if dom and occ0 else None
+        pass1_bytes_per_occ = L / (4.0 * n_per_read) + 8 + Kb + 8         # stream + Bloom + table
         out = {
             "metric": "distinct k-mers inserted/sec (whole node)",
             "value": stored / per_step,
@@ -188,9 +219,13 @@ def main():
             "kmer_occurrences": occ, "distinct_candidates": cand, "vertices_stored": stored,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
-                         "kernel": "k_count", "bytes_per_occurrence": bytes_per_occ,
+                         "kernel": dom, "bytes_per_occurrence": bytes_per_occ,
                          "kernel_ms_per_step": kernel_s * 1e3 if sweep_ms else None,
                          "launches_per_step": sweep_launches / args.steps},
+            "kernels": per_kernel,
+            "pass1_algorithmic": {"bytes_per_occurrence": pass1_bytes_per_occ,
+                                  "GBps_over_whole_step": pass1_bytes_per_occ * occ0 / per_step / 1e9,
+                                  "frac_of_hbm_peak": pass1_bytes_per_occ * occ0 / per_step / 1e9 / HBM_PEAK_GBS},
             "setup_s": gen_s,
         }
         if not args.no_cpu_baseline and world == 1:

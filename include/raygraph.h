@@ -42,7 +42,7 @@ typedef struct rg_config {
 	int32_t rank;           /* MPI rank == GPU owner index */
 	int32_t size;           /* number of ranks */
 	int32_t device;         /* HIP device ordinal */
-	int32_t reserved0;      /* sweep selection, bits 0-7: 0 = automatic, 1 = force the partitioned sweep, 2 = force the direct sweep; bits 8-15: log2 of the bucket count of the partitioned sweep (0 = automatic) */
+	int32_t reserved0;      /* sweep selection, bits 0-7: 0 = automatic, 1 = force the partitioned sweep, 2 = force the direct sweep; bits 8-15: log2 of the bucket count of the partitioned sweep (0 = automatic); bit 4 / bit 5: force the partitioned / the dense Bloom resolution */
 	uint64_t bloom_bits;    /* RG_BLOOM_DEFAULT, 0 = Bloom filter off, else -bloom-filter-bits */
 	uint64_t table_slots;   /* initial open-addressing capacity hint (like -hash-table-buckets); 0 = auto */
 	uint64_t first_read_id; /* global id of this rank's first read (SequencesLoader.cpp:287-297) */
@@ -139,6 +139,10 @@ typedef struct rg_stats {
 	uint64_t bloom_set_bits;   /* BloomFilter::getNumberOfSetBits */
 	uint64_t table_slots;      /* current open-addressing capacity */
 	uint64_t sweep_partitioned; /* 1 if pass 1 ran as the partitioned sweep, 0 if as the direct sweep */
+	uint64_t superkmer_records; /* partitioned sweep: super-k-mer records written */
+	uint64_t partition_levels;  /* partitioned sweep: scatter levels run (1..3) */
+	uint64_t log_entries;       /* partitioned sweep: aggregated entries handed to the table merge */
+	uint64_t bloom_partitioned; /* 1 if admission was resolved by Bloom-region partitioning, 0 if by dense stamps */
 } rg_stats;
 int rg_get_stats(rg_handle *h, rg_stats *out);
 
@@ -151,11 +155,10 @@ int rg_release_cached_memory(void);
 
 /* ---- profiling (the reference's MACRO_COLLECT_PROFILING_INFORMATION probes,
  * KmerAcademyBuilder.cpp:50,73,116,...) ------------------------------------------------------- */
-/* when enabled, every launch of the k-mer sweep kernel (the dominant kernel) is bracketed by HIP
- * events on the launch stream */
+/* when enabled, the launches of every hot kernel are bracketed by HIP events on the launch stream */
 int rg_set_profiling(rg_handle *h, int enable);
-/* sum of the bracketed sweep launches in milliseconds and their number (synchronises the stream) */
-int rg_get_sweep_time(rg_handle *h, double *total_ms, uint64_t *launches);
+/* one text line per kernel: "<name> <total milliseconds> <launches>\n" (synchronises the stream) */
+int rg_get_kernel_profile(rg_handle *h, char *buf, uint64_t cap);
 
 /* ---- host-side master-mode helpers (no GPU needed) ------------------------------------------- */
 /* CoverageDistribution::CoverageDistribution (CoverageGatherer/CoverageDistribution.cpp:33-112):

@@ -24,14 +24,14 @@ class RgConfig(C.Structure):
 
 class RgStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("reads", "occurrences", "candidates", "stored_pairs", "bloom_bits",
-                                         "bloom_insertions", "bloom_set_bits", "table_slots", "sweep_partitioned")]
+                                         "bloom_insertions", "bloom_set_bits", "table_slots", "sweep_partitioned", "superkmer_records", "partition_levels", "log_entries", "bloom_partitioned")]
 
 
 # every symbol include/raygraph.h declares
 SYMBOLS = ["rg_create", "rg_destroy", "rg_last_error", "rg_add_reads", "rg_add_reads_device", "rg_count_kmers",
            "rg_count_local", "rg_owner_counts", "rg_export_owner_buckets", "rg_merge_entries",
            "rg_resolve_admission", "rg_histogram", "rg_add_edges", "rg_purge_edges", "rg_size", "rg_export",
-           "rg_find", "rg_degree_distribution", "rg_get_stats", "rg_set_profiling", "rg_get_sweep_time", "rg_release_cached_memory", "rg_coverage_distribution", "rg_pack_read",
+           "rg_find", "rg_degree_distribution", "rg_get_stats", "rg_set_profiling", "rg_get_kernel_profile", "rg_release_cached_memory", "rg_coverage_distribution", "rg_pack_read",
            "rg_version"]
 
 _lib = None
@@ -78,7 +78,7 @@ def load():
         "rg_get_stats": ([vp, C.POINTER(RgStats)], C.c_int),
         "rg_release_cached_memory": ([], C.c_int),
         "rg_set_profiling": ([vp, C.c_int], C.c_int),
-        "rg_get_sweep_time": ([vp, C.POINTER(C.c_double), u64p], C.c_int),
+        "rg_get_kernel_profile": ([vp, C.c_char_p, u64], C.c_int),
         "rg_coverage_distribution": ([u32p, u64p, u64, C.c_char_p, i32p, i32p, i32p], C.c_int),
         "rg_pack_read": ([C.c_char_p, C.c_int, u8p], C.c_int),
         "rg_version": ([], C.c_char_p),

@@ -14,12 +14,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
 #include "../../include/raygraph.h"
 #include "rg_device.h"
 #include "rg_partition.h"
+#include "rg_bloom.h"
 
 using namespace rg;
 
@@ -302,6 +304,39 @@ __global__ __launch_bounds__(BLOCK) void k_admit(Slot *__restrict__ tab, uint64_
 			}
 		} else {
 			cov = N;
+		}
+		if (cov > 0xFFFFFFFFull) cov = 0xFFFFFFFFull;
+		if (cov) retained++;
+		tab[i].meta = (v.meta & ~COUNT_MASK) | cov;
+	}
+	for (int d = 32; d > 0; d >>= 1) {
+		retained += __shfl_down(retained, d);
+		inserted += __shfl_down(inserted, d);
+	}
+	if ((threadIdx.x & 63) == 0) {
+		if (retained) atomicAdd(&counters[C_RETAINED], (unsigned long long)retained);
+		if (inserted) atomicAdd(&counters[C_INSERTIONS], (unsigned long long)inserted);
+	}
+}
+
+// A7 with the "lost" marks of rg_bloom.h: a key whose 8 bit checks all found the bit set earlier is a
+// false positive
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_admit_lost(Slot *__restrict__ tab, uint64_t cap, const uint32_t *__restrict__ lost,
+                                                      unsigned long long *__restrict__ counters) {
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	uint32_t retained = 0, inserted = 0;
+	for (; i < cap; i += stride) {
+		Slot v = tab[i];
+		if (v.k0 == EMPTY) continue;
+		const uint64_t N = v.meta & COUNT_MASK;
+		const uint32_t nlost = (lost[i >> 2] >> ((i & 3u) * 8u)) & 0xFFu;
+		uint64_t cov;
+		if (nlost == 8) cov = N + 1;
+		else {
+			inserted++;
+			cov = (N >= 2) ? N : 0;
 		}
 		if (cov > 0xFFFFFFFFull) cov = 0xFFFFFFFFull;
 		if (cov) retained++;
@@ -620,7 +655,27 @@ struct rg_handle {
 	std::string err;
 	// optional per-kernel timing with HIP events on the launch stream (rg_set_profiling)
 	bool profiling = false;
-	std::vector<std::pair<hipEvent_t, hipEvent_t>> sweep_events;
+	std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof;
+};
+
+// brackets the launches issued during its lifetime with two HIP events on the handle's stream
+struct ProfScope {
+	rg_handle *h;
+	const char *name;
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	ProfScope(rg_handle *h_, const char *name_) : h(h_), name(name_) {
+		if (!h->profiling) return;
+		if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+			e0 = nullptr;
+			return;
+		}
+		(void)hipEventRecord(e0, h->stream);
+	}
+	~ProfScope() {
+		if (!e0) return;
+		(void)hipEventRecord(e1, h->stream);
+		h->prof[name].emplace_back(e0, e1);
+	}
 };
 
 static thread_local std::string g_create_error;
@@ -719,6 +774,7 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	const int k = h->cfg.k;
 	const int m = k < MMER_MAX ? k : MMER_MAX;
 	const int w = k - m + 1;
+	if (w > lmax_for(W, k)) return RG_OK;  // a record could not hold a whole minimizer run (never for valid k)
 	uint64_t occ_bound = 0, rec_bound = 0, total_reads = 0;
 	for (const ReadBatch &b : h->reads) {
 		if (b.maxlen < (uint32_t)k) continue;
@@ -745,8 +801,18 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	if (bits > MAX_BUCKET_BITS) bits = MAX_BUCKET_BITS;
 	const int dbits[3] = {8, std::min(8, bits - 8), std::max(0, bits - 16)};
 	const uint64_t NBUCK = 1ull << bits;
-	const int grid1 = (int)std::min<uint64_t>(2048, (total_reads + 3) / 4);
-	const uint64_t rec_cap = rec_bound + (uint64_t)grid1 * 4 * REC_CHUNK;
+	// persistent grids sized to what is resident at once, so that no second, nearly empty round of
+	// workgroups runs behind the first
+	int n_cu = 256, occ1 = 4, occ3 = 4;
+	(void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ1, k_superkmers<W>, 256, 0) != hipSuccess || occ1 < 1) occ1 = 4;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ3, k_aggregate<W>, 256, 0) != hipSuccess || occ3 < 1) occ3 = 4;
+	(void)hipGetLastError();
+	const int grid1 = (int)std::min<uint64_t>((uint64_t)n_cu * occ1, (total_reads + 3) / 4);
+	uint64_t launches1 = 0;  // every launch of k_superkmers leaves up to one open chunk per wavefront
+	for (const ReadBatch &b : h->reads)
+		if (b.maxlen >= (uint32_t)k) launches1++;
+	const uint64_t rec_cap = rec_bound + launches1 * (uint64_t)grid1 * 4 * REC_CHUNK;
 
 	Rec<W> *buf[2] = {nullptr, nullptr};
 	unsigned long long *d_seg = nullptr, *d_hist = nullptr, *d_begin = nullptr, *d_sums = nullptr;
@@ -785,8 +851,11 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	// 1. reads -> records (+ first-level histogram)
 	for (const ReadBatch &b : h->reads) {
 		if (b.maxlen < (uint32_t)k) continue;
-		hipLaunchKernelGGL(k_superkmers<W>, dim3(grid1), dim3(256), 0, h->stream, b.d_packed, b.d_off, b.d_len, b.n, b.first_id, k, m, bits,
-		                   buf[0], rec_cap, h->d_counters, d_hist);
+		{
+			ProfScope ps(h, "k_superkmers");
+			hipLaunchKernelGGL(k_superkmers<W>, dim3(grid1), dim3(256), 0, h->stream, b.d_packed, b.d_off, b.d_len, b.n, b.first_id, k, m, buf[0],
+			                   rec_cap, h->d_counters, d_hist);
+		}
 		PTRY(hipGetLastError());
 	}
 	std::vector<unsigned long long> hist(256), begin;
@@ -831,6 +900,7 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 		const uint64_t nout = (uint64_t)S << db;  // buckets after this level
 		if (level > 0) {  // level 0's histogram came out of k_superkmers
 			PTRY(hipMemsetAsync(d_hist, 0, nout * sizeof(unsigned long long), h->stream));
+			ProfScope ps(h, "k_level_hist");
 			hipLaunchKernelGGL(k_level_hist<W>, dim3((unsigned)ntiles), dim3(256), 0, h->stream, buf[cur], m, S, d_seg, d_tile, shift, db, d_hist);
 			PTRY(hipGetLastError());
 		}
@@ -840,8 +910,11 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 		hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(64), 0, h->stream, d_sums, nblk, d_sums + nblk);
 		hipLaunchKernelGGL(k_scan_add, dim3(nblk), dim3(256), 0, h->stream, d_begin, nout, d_sums, d_sums + nblk, d_hist);
 		PTRY(hipGetLastError());
-		hipLaunchKernelGGL(k_scatter<W>, dim3((unsigned)ntiles), dim3(256), 0, h->stream, buf[cur], m, S, d_seg, d_tile, shift, db, d_hist,
-		                   buf[cur ^ 1]);
+		{
+			ProfScope ps(h, "k_scatter");
+			hipLaunchKernelGGL(k_scatter<W>, dim3((unsigned)ntiles), dim3(256), 0, h->stream, buf[cur], m, S, d_seg, d_tile, shift, db, d_hist,
+			                   buf[cur ^ 1]);
+		}
 		PTRY(hipGetLastError());
 		used_bits += db;
 		cur ^= 1;
@@ -858,15 +931,18 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	// 3. aggregate per bucket into the log.  The log holds one entry per distinct k-mer of a bucket
 	// flush; a quarter of the occurrences is a deterministic size (the pool reuses the block) that only
 	// low-coverage inputs exceed -- they fall back to the direct sweep
-	const unsigned agg_grid = (unsigned)std::min<uint64_t>(NBUCK, 3072);
+	const unsigned agg_grid = (unsigned)std::min<uint64_t>(NBUCK, (uint64_t)n_cu * occ3);
 	uint64_t log_cap = std::min<uint64_t>(occ_bound, std::max<uint64_t>(occ_bound / 4, 1ull << 20)) + (uint64_t)agg_grid * LOG_CHUNK;
 	if (pool_alloc(dev, (void **)&log, log_cap * sizeof(Slot)) != hipSuccess) {
 		(void)hipGetLastError();
 		cleanup();
 		return RG_OK;
 	}
-	hipLaunchKernelGGL(k_aggregate<W>, dim3(agg_grid), dim3(256), 0, h->stream, buf[cur], d_begin,
-	                   (uint32_t)NBUCK, k, log, log_cap, h->d_counters);
+	{
+		ProfScope ps(h, "k_aggregate");
+		hipLaunchKernelGGL(k_aggregate<W>, dim3(agg_grid), dim3(256), 0, h->stream, buf[cur], d_begin, (uint32_t)NBUCK, k, log, log_cap,
+		                   h->d_counters);
+	}
 	hipError_t e = hipGetLastError();
 	if (e == hipSuccess) rc = sync_counters(h);
 	cleanup();
@@ -881,6 +957,9 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	*out_log = log;
 	*out_n = h->h_counters[PC_LOG_CURSOR];
 	*ok = true;
+	h->stats.superkmer_records = valid;
+	h->stats.partition_levels = (uint64_t)((dbits[0] > 0) + (dbits[1] > 0) + (dbits[2] > 0));
+	h->stats.log_entries = *out_n;
 	if (getenv("RG_DEBUG"))
 		fprintf(stderr, "[raygraph] partitioned sweep: %llu reads, %llu occurrences, 2^%d buckets, %llu record slots (%llu valid, cap %llu), log %llu entries (cap %llu), %llu LDS spills\n",
 		        (unsigned long long)total_reads, (unsigned long long)h->h_counters[C_OCC], bits, (unsigned long long)n_in, (unsigned long long)valid,
@@ -891,6 +970,147 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 
 static int sweep_partitioned(rg_handle *h, Slot **out_log, uint64_t *out_n, bool *ok) {
 	return h->W == 1 ? sweep_partitioned_t<1>(h, out_log, out_n, ok) : sweep_partitioned_t<2>(h, out_log, out_n, ok);
+}
+
+// ---- Bloom admission through region partitioning (rg_bloom.h) -----------------------------------
+// *ok = false: not applicable or a region overflowed; the caller then uses the dense stamp method.
+static int bloom_partitioned(rg_handle *h, uint64_t m_bits, uint64_t keys, bool *ok) {
+	*ok = false;
+	const int dev = h->cfg.device;
+	Table &T = h->tab;
+	const uint64_t R = (m_bits + REGION_BITS - 1) / REGION_BITS;
+	if (R > 65536 || T.cap >= (1ull << 31) || keys == 0) return RG_OK;
+	const int nlevels = R > 256 ? 2 : 1;
+	const int shift1 = nlevels == 2 ? 56 : 48;
+	const uint64_t NBUCK = nlevels == 2 ? 65536 : 256;
+	int n_cu = 256;
+	(void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+	const int grid_items = (int)std::min<uint64_t>((uint64_t)n_cu * 8, (T.cap + 255) / 256);
+	const uint64_t item_cap = 8 * (keys + (uint64_t)grid_items * 4 * ITEM_CHUNK_KEYS);
+	unsigned long long *A = nullptr, *B = nullptr, *d_seg = nullptr, *d_hist = nullptr, *d_begin = nullptr, *d_sums = nullptr;
+	uint32_t *d_tile = nullptr, *d_lost = nullptr;
+	auto cleanup = [&]() {
+		pool_free(dev, A);
+		pool_free(dev, B);
+		pool_free(dev, d_seg);
+		pool_free(dev, d_hist);
+		pool_free(dev, d_begin);
+		pool_free(dev, d_sums);
+		pool_free(dev, d_tile);
+		pool_free(dev, d_lost);
+	};
+#define BTRY(call)                                                                                          \
+	do {                                                                                                    \
+		hipError_t e_ = (call);                                                                             \
+		if (e_ != hipSuccess) {                                                                             \
+			cleanup();                                                                                      \
+			return fail(h, e_ == hipErrorOutOfMemory ? RG_ERR_NOMEM : RG_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+		}                                                                                                   \
+	} while (0)
+	if (pool_alloc(dev, (void **)&A, item_cap * 8) != hipSuccess || pool_alloc(dev, (void **)&B, 8 * keys * 8) != hipSuccess) {
+		(void)hipGetLastError();
+		cleanup();
+		return RG_OK;
+	}
+	BTRY(pool_alloc(dev, (void **)&d_seg, 257 * sizeof(unsigned long long)));
+	BTRY(pool_alloc(dev, (void **)&d_tile, 257 * sizeof(uint32_t)));
+	BTRY(pool_alloc(dev, (void **)&d_hist, NBUCK * sizeof(unsigned long long)));
+	BTRY(pool_alloc(dev, (void **)&d_begin, (NBUCK + 1) * sizeof(unsigned long long)));
+	BTRY(pool_alloc(dev, (void **)&d_sums, (NBUCK / SCAN_PER_BLOCK + 2) * sizeof(unsigned long long)));
+	const uint64_t lost_words = T.cap / 4 + 1;
+	BTRY(pool_alloc(dev, (void **)&d_lost, lost_words * sizeof(uint32_t)));
+	BTRY(hipMemsetAsync(d_lost, 0, lost_words * sizeof(uint32_t), h->stream));
+	BTRY(hipMemsetAsync(d_hist, 0, 256 * sizeof(unsigned long long), h->stream));
+	BTRY(hipMemsetAsync(h->d_counters + BC_ITEM_CURSOR, 0, 4 * sizeof(unsigned long long), h->stream));
+	{
+		ProfScope ps(h, "k_bloom_items");
+		if (h->W == 1) hipLaunchKernelGGL(k_bloom_items<1>, dim3(grid_items), dim3(256), 0, h->stream, T.slots, T.cap, m_bits, A, item_cap, shift1, h->d_counters, d_hist);
+		else hipLaunchKernelGGL(k_bloom_items<2>, dim3(grid_items), dim3(256), 0, h->stream, T.slots, T.cap, m_bits, A, item_cap, shift1, h->d_counters, d_hist);
+		BTRY(hipGetLastError());
+	}
+	int rc = sync_counters(h);
+	if (rc) {
+		cleanup();
+		return rc;
+	}
+	if (h->h_counters[BC_ITEM_OVF]) {
+		if (getenv("RG_DEBUG")) fprintf(stderr, "[raygraph] Bloom partition: item buffer overflow, using dense stamps\n");
+		cleanup();
+		return RG_OK;
+	}
+	const uint64_t n_in = std::min<uint64_t>(h->h_counters[BC_ITEM_CURSOR], item_cap);
+	std::vector<unsigned long long> seg_begin = {0, n_in};
+	std::vector<uint32_t> tile_first;
+	unsigned long long *bufs[2] = {A, B};
+	int cur = 0;
+	for (int level = 0; level < nlevels; ++level) {
+		const uint32_t S = (uint32_t)seg_begin.size() - 1;
+		const int shift = level == 0 ? shift1 : 48;
+		tile_first.assign(S + 1, 0);
+		uint64_t ntiles = 0;
+		for (uint32_t sgi = 0; sgi < S; ++sgi) {
+			tile_first[sgi] = (uint32_t)ntiles;
+			ntiles += (seg_begin[sgi + 1] - seg_begin[sgi] + SCATTER64_TILE - 1) / SCATTER64_TILE;
+		}
+		tile_first[S] = (uint32_t)ntiles;
+		BTRY(hipMemcpyAsync(d_seg, seg_begin.data(), (S + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
+		BTRY(hipMemcpyAsync(d_tile, tile_first.data(), (S + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+		const uint64_t nout = (uint64_t)S << 8;
+		ProfScope ps(h, "k_scatter64");
+		if (level > 0) {
+			BTRY(hipMemsetAsync(d_hist, 0, nout * sizeof(unsigned long long), h->stream));
+			hipLaunchKernelGGL(k_hist64, dim3((unsigned)ntiles), dim3(256), 0, h->stream, bufs[cur], S, d_seg, d_tile, shift, d_hist);
+		}
+		const uint32_t nblk = (uint32_t)((nout + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK);
+		hipLaunchKernelGGL(k_scan_local, dim3(nblk), dim3(256), 0, h->stream, d_hist, d_begin, nout, d_sums);
+		hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(64), 0, h->stream, d_sums, nblk, d_sums + nblk);
+		hipLaunchKernelGGL(k_scan_add, dim3(nblk), dim3(256), 0, h->stream, d_begin, nout, d_sums, d_sums + nblk, d_hist);
+		hipLaunchKernelGGL(k_scatter64, dim3((unsigned)ntiles), dim3(256), 0, h->stream, bufs[cur], S, d_seg, d_tile, shift, d_hist, bufs[cur ^ 1]);
+		BTRY(hipGetLastError());
+		cur ^= 1;
+		if (level + 1 < nlevels) {
+			seg_begin.resize(nout + 1);
+			BTRY(hipMemcpyAsync(seg_begin.data(), d_begin, (nout + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+			BTRY(hipStreamSynchronize(h->stream));
+			if (seg_begin[nout] != 8 * keys) {
+				cleanup();
+				return fail(h, RG_ERR_STATE, "Bloom partition lost items: %llu of %llu", seg_begin[nout], (unsigned long long)(8 * keys));
+			}
+		}
+	}
+	BTRY(hipMemsetAsync(h->d_counters + C_SETBITS, 0, sizeof(unsigned long long), h->stream));
+	{
+		ProfScope ps(h, "k_bloom_region");
+		const unsigned grid = (unsigned)std::min<uint64_t>(NBUCK, (uint64_t)n_cu);
+		if (h->W == 1) hipLaunchKernelGGL(k_bloom_region<1>, dim3(grid), dim3(512), 0, h->stream, bufs[cur], d_begin, (uint32_t)NBUCK, T.slots, d_lost, h->d_counters, (int)C_SETBITS);
+		else hipLaunchKernelGGL(k_bloom_region<2>, dim3(grid), dim3(512), 0, h->stream, bufs[cur], d_begin, (uint32_t)NBUCK, T.slots, d_lost, h->d_counters, (int)C_SETBITS);
+		BTRY(hipGetLastError());
+	}
+	rc = sync_counters(h);
+	if (rc) {
+		cleanup();
+		return rc;
+	}
+	if (getenv("RG_DEBUG"))
+		fprintf(stderr, "[raygraph] Bloom partition: %llu keys, %llu bits, %llu regions in %d level(s), %llu regions too contested\n",
+		        (unsigned long long)keys, (unsigned long long)m_bits, (unsigned long long)R, nlevels, (unsigned long long)h->h_counters[BC_REGION_OVF]);
+	if (h->h_counters[BC_REGION_OVF]) {  // a region had more contested bits than LDS can rank: dense method
+		(void)hipMemsetAsync(h->d_counters + C_SETBITS, 0, sizeof(unsigned long long), h->stream);
+		cleanup();
+		return RG_OK;
+	}
+	{
+		ProfScope ps(h, "k_admit");
+		const int grid = grid_for(T.cap);
+		if (h->W == 1) hipLaunchKernelGGL(k_admit_lost<1>, dim3(grid), dim3(BLOCK), 0, h->stream, T.slots, T.cap, d_lost, h->d_counters);
+		else hipLaunchKernelGGL(k_admit_lost<2>, dim3(grid), dim3(BLOCK), 0, h->stream, T.slots, T.cap, d_lost, h->d_counters);
+		BTRY(hipGetLastError());
+	}
+	BTRY(hipStreamSynchronize(h->stream));
+	cleanup();
+	*ok = true;
+#undef BTRY
+	return RG_OK;
 }
 
 extern "C" {
@@ -942,10 +1162,11 @@ int rg_destroy(rg_handle *h) {
 	if (!h) return RG_OK;
 	(void)hipSetDevice(h->cfg.device);
 	if (h->stream) (void)hipStreamSynchronize(h->stream);
-	for (auto &p : h->sweep_events) {
-		(void)hipEventDestroy(p.first);
-		(void)hipEventDestroy(p.second);
-	}
+	for (auto &kv : h->prof)
+		for (auto &p : kv.second) {
+			(void)hipEventDestroy(p.first);
+			(void)hipEventDestroy(p.second);
+		}
 	for (auto &b : h->reads)
 		if (b.owned) {
 			pool_free(h->cfg.device, (void *)b.d_packed);
@@ -1046,6 +1267,7 @@ int rg_count_local(rg_handle *h) {
 				if (single) {
 					rc = table_reserve(h, T, n_log ? n_log : 1, fill_counter);
 					if (rc == RG_OK && n_log) {
+						ProfScope ps(h, "k_merge");
 						if (h->W == 1) hipLaunchKernelGGL(k_merge<1>, dim3(grid_for(n_log)), dim3(BLOCK), 0, h->stream, log, n_log, T.slots, T.cap - 1, h->d_counters);
 						else hipLaunchKernelGGL(k_merge<2>, dim3(grid_for(n_log)), dim3(BLOCK), 0, h->stream, log, n_log, T.slots, T.cap - 1, h->d_counters);
 						if (hipGetLastError() != hipSuccess) rc = fail(h, RG_ERR_HIP, "k_merge launch failed");
@@ -1083,12 +1305,7 @@ int rg_count_local(rg_handle *h) {
 			if (rc) return rc;
 			uint64_t ntiles = (r1 - r0 + TILE_READS - 1) / TILE_READS;
 			int grid = (int)std::min<uint64_t>(ntiles, 256 * 8);
-			hipEvent_t ev0 = nullptr, ev1 = nullptr;
-			if (h->profiling) {
-				HIP_TRY(h, hipEventCreate(&ev0));
-				HIP_TRY(h, hipEventCreate(&ev1));
-				HIP_TRY(h, hipEventRecord(ev0, h->stream));
-			}
+			ProfScope ps(h, "k_count");
 			if (h->W == 1)
 				hipLaunchKernelGGL(k_count<1>, dim3(grid), dim3(BLOCK), 0, h->stream, b.d_packed, b.d_off, b.d_len, r0, r1,
 				                   b.first_id + r0, k, T.slots, T.cap - 1, h->d_counters, fill_counter);
@@ -1096,10 +1313,6 @@ int rg_count_local(rg_handle *h) {
 				hipLaunchKernelGGL(k_count<2>, dim3(grid), dim3(BLOCK), 0, h->stream, b.d_packed, b.d_off, b.d_len, r0, r1,
 				                   b.first_id + r0, k, T.slots, T.cap - 1, h->d_counters, fill_counter);
 			HIP_TRY(h, hipGetLastError());
-			if (h->profiling) {
-				HIP_TRY(h, hipEventRecord(ev1, h->stream));
-				h->sweep_events.emplace_back(ev0, ev1);
-			}
 			T.fill_pending += bound;
 		}
 	}
@@ -1170,6 +1383,7 @@ int rg_merge_entries(rg_handle *h, const void *d_entries, uint64_t n_entries) {
 	if (!d_entries) return fail(h, RG_ERR_ARG, "null entries");
 	int rc = table_reserve(h, h->tab, n_entries, C_FILL);
 	if (rc) return rc;
+	ProfScope ps(h, "k_merge");
 	if (h->W == 1) hipLaunchKernelGGL(k_merge<1>, dim3(grid_for(n_entries)), dim3(BLOCK), 0, h->stream, (const Slot *)d_entries, n_entries, h->tab.slots, h->tab.cap - 1, h->d_counters);
 	else hipLaunchKernelGGL(k_merge<2>, dim3(grid_for(n_entries)), dim3(BLOCK), 0, h->stream, (const Slot *)d_entries, n_entries, h->tab.slots, h->tab.cap - 1, h->d_counters);
 	HIP_TRY(h, hipGetLastError());
@@ -1202,17 +1416,40 @@ int rg_resolve_admission(rg_handle *h, uint64_t local_reads_for_bloom) {
 	}
 	h->stats.bloom_bits = m_bits;
 	const int grid = grid_for(T.cap);
+	bool resolved = false;
 	if (m_bits > 0) {
+		// keys in the table decide the method: region partitioning when the filter stays sparse
+		// (8 touches per key), dense first-touch stamps otherwise.  cfg.reserved0 bit 4 forces the
+		// first, bit 5 the second (tests).
+		int rc0 = sync_counters(h);
+		if (rc0) return rc0;
+		const uint64_t keys = h->h_counters[C_FILL];
+		const uint32_t flags = (uint32_t)h->cfg.reserved0 & 0xFFu;
+		const double lambda = 8.0 * (double)keys / (double)m_bits;
+		if (!(flags & 32u) && ((flags & 16u) || (lambda <= 0.25 && keys >= (1ull << 20)))) {
+			rc0 = bloom_partitioned(h, m_bits, keys, &resolved);
+			if (rc0) return rc0;
+			h->stats.bloom_partitioned = resolved ? 1 : 0;
+		}
+	}
+	if (m_bits > 0 && !resolved) {
 		unsigned long long *bitstamp = nullptr;
 		HIP_TRY(h, pool_alloc(h->cfg.device, (void **)&bitstamp, m_bits * sizeof(unsigned long long)));
-		hipError_t e = hipMemsetAsync(bitstamp, 0xFF, m_bits * sizeof(unsigned long long), h->stream);
+		hipError_t e;
+		{
+			ProfScope ps(h, "bloom_stamp_fill");
+			e = hipMemsetAsync(bitstamp, 0xFF, m_bits * sizeof(unsigned long long), h->stream);
+		}
 		if (e == hipSuccess) {
-			if (h->W == 1) {
-				hipLaunchKernelGGL(k_bloom_touch<1>, dim3(grid), dim3(BLOCK), 0, h->stream, T.slots, T.cap, m_bits, bitstamp, h->d_counters);
-				hipLaunchKernelGGL((k_admit<1, true>), dim3(grid), dim3(BLOCK), 0, h->stream, T.slots, T.cap, m_bits, bitstamp, h->d_counters);
-			} else {
-				hipLaunchKernelGGL(k_bloom_touch<2>, dim3(grid), dim3(BLOCK), 0, h->stream, T.slots, T.cap, m_bits, bitstamp, h->d_counters);
-				hipLaunchKernelGGL((k_admit<2, true>), dim3(grid), dim3(BLOCK), 0, h->stream, T.slots, T.cap, m_bits, bitstamp, h->d_counters);
+			{
+				ProfScope ps(h, "k_bloom_touch");
+				if (h->W == 1) hipLaunchKernelGGL(k_bloom_touch<1>, dim3(grid), dim3(BLOCK), 0, h->stream, T.slots, T.cap, m_bits, bitstamp, h->d_counters);
+				else hipLaunchKernelGGL(k_bloom_touch<2>, dim3(grid), dim3(BLOCK), 0, h->stream, T.slots, T.cap, m_bits, bitstamp, h->d_counters);
+			}
+			{
+				ProfScope ps(h, "k_admit");
+				if (h->W == 1) hipLaunchKernelGGL((k_admit<1, true>), dim3(grid), dim3(BLOCK), 0, h->stream, T.slots, T.cap, m_bits, bitstamp, h->d_counters);
+				else hipLaunchKernelGGL((k_admit<2, true>), dim3(grid), dim3(BLOCK), 0, h->stream, T.slots, T.cap, m_bits, bitstamp, h->d_counters);
 			}
 			e = hipGetLastError();
 		}
@@ -1220,7 +1457,7 @@ int rg_resolve_admission(rg_handle *h, uint64_t local_reads_for_bloom) {
 		pool_free(h->cfg.device, bitstamp);  // the reference destroys its filter here too (MessageProcessor.cpp:1010)
 		if (e != hipSuccess) return fail(h, RG_ERR_HIP, "Bloom resolution failed: %s", hipGetErrorString(e));
 		if (e2 != hipSuccess) return fail(h, RG_ERR_HIP, "Bloom resolution failed: %s", hipGetErrorString(e2));
-	} else {
+	} else if (m_bits == 0) {
 		if (h->W == 1) hipLaunchKernelGGL((k_admit<1, false>), dim3(grid), dim3(BLOCK), 0, h->stream, T.slots, T.cap, 0ull, (const unsigned long long *)nullptr, h->d_counters);
 		else hipLaunchKernelGGL((k_admit<2, false>), dim3(grid), dim3(BLOCK), 0, h->stream, T.slots, T.cap, 0ull, (const unsigned long long *)nullptr, h->d_counters);
 		HIP_TRY(h, hipGetLastError());
@@ -1256,6 +1493,7 @@ int rg_histogram(rg_handle *h, uint32_t *coverage, uint64_t *count, uint64_t cap
 	HIP_TRY(h, pool_alloc(h->cfg.device, (void **)&ovf, HIST_OVF_CAP * sizeof(uint32_t)));
 	HIP_TRY(h, hipMemsetAsync(dense, 0, HIST_DENSE * sizeof(unsigned long long), h->stream));
 	HIP_TRY(h, hipMemsetAsync(h->d_counters + C_OVF, 0, sizeof(unsigned long long), h->stream));
+	ProfScope ps(h, "k_histogram");
 	hipLaunchKernelGGL(k_histogram, dim3(grid_for(h->tab.cap)), dim3(BLOCK), 0, h->stream, h->tab.slots, h->tab.cap, dense, ovf, h->d_counters);
 	HIP_TRY(h, hipGetLastError());
 	std::vector<unsigned long long> hd(HIST_DENSE);
@@ -1304,6 +1542,7 @@ int rg_add_edges(rg_handle *h) {
 	if (!h) return RG_ERR_ARG;
 	if (h->phase != PH_RESOLVED) return fail(h, RG_ERR_STATE, "rg_add_edges needs the k-mer count first (and runs once)");
 	HIP_TRY(h, hipSetDevice(h->cfg.device));
+	ProfScope ps(h, "k_publish_edges");
 	hipLaunchKernelGGL(k_publish_edges, dim3(grid_for(h->tab.cap)), dim3(BLOCK), 0, h->stream, h->tab.slots, h->tab.cap);
 	HIP_TRY(h, hipGetLastError());
 	HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1439,18 +1678,24 @@ int rg_set_profiling(rg_handle *h, int enable) {
 	return RG_OK;
 }
 
-int rg_get_sweep_time(rg_handle *h, double *total_ms, uint64_t *launches) {
-	if (!h || !total_ms || !launches) return RG_ERR_ARG;
+int rg_get_kernel_profile(rg_handle *h, char *buf, uint64_t cap) {
+	if (!h || !buf || cap == 0) return RG_ERR_ARG;
 	HIP_TRY(h, hipSetDevice(h->cfg.device));
 	HIP_TRY(h, hipStreamSynchronize(h->stream));
-	double ms = 0;
-	for (auto &p : h->sweep_events) {
-		float t = 0;
-		HIP_TRY(h, hipEventElapsedTime(&t, p.first, p.second));
-		ms += t;
+	std::string out;
+	for (auto &kv : h->prof) {
+		double ms = 0;
+		for (auto &p : kv.second) {
+			float t = 0;
+			HIP_TRY(h, hipEventElapsedTime(&t, p.first, p.second));
+			ms += t;
+		}
+		char line[160];
+		snprintf(line, sizeof line, "%s %.6f %zu\n", kv.first.c_str(), ms, kv.second.size());
+		out += line;
 	}
-	*total_ms = ms;
-	*launches = h->sweep_events.size();
+	if (out.size() + 1 > cap) return fail(h, RG_ERR_CAPACITY, "profile needs %zu bytes", out.size() + 1);
+	memcpy(buf, out.c_str(), out.size() + 1);
 	return RG_OK;
 }
 

@@ -1,0 +1,283 @@
+// rg_bloom.h -- Bloom admission resolved without scattered global atomics.
+//
+// The dense method (raygraph.hip: k_bloom_touch / k_admit) keeps one 8-byte first-touch stamp per
+// Bloom bit and pays 8 scattered device-scope atomics per distinct key (~17.5 G/s chip-wide).  At the
+// fill the reference's sizing aims for (a few percent) almost every bit is touched by one key only, and
+// then nothing has to be ordered at all.  So instead:
+//
+//   k_bloom_items   8 items (bit index, table slot) per key, streamed out
+//   k_scatter64     1-2 partition levels by Bloom region (2^17 bits per region)
+//   k_bloom_region  one workgroup per region, all in LDS: two bitmaps (touched / touched again);
+//                   only for bits touched more than once are the stamps fetched and the earliest
+//                   found; every later toucher of such a bit gets one "lost" mark on its key
+//   k_admit_lost    a key is a false positive iff all 8 of its bit checks lost (MessageProcessor.cpp:741-750)
+//
+// Same result as the dense method bit for bit; used when the expected fill is low, falls back to
+// the dense method otherwise or when a region holds more contested bits than LDS can rank.
+#pragma once
+#include "rg_device.h"
+
+namespace rg {
+
+static constexpr int REGION_BITS_LOG2 = 17;
+static constexpr uint32_t REGION_BITS = 1u << REGION_BITS_LOG2;
+static constexpr uint32_t REGION_WORDS = REGION_BITS / 32;  // 4096 words per bitmap
+static constexpr uint32_t REGION_MULTI_CAP = 6144;          // contested bits a region can rank (48 KB of stamps)
+static constexpr uint64_t ITEM_INVALID = ~0ull;
+static constexpr uint32_t ITEM_CHUNK_KEYS = 512;  // keys (x8 items) a wavefront claims at a time
+static constexpr int SCATTER64_TILE = 4096;
+
+enum BloomCounter { BC_ITEM_CURSOR = 24, BC_ITEM_OVF, BC_REGION_OVF };
+
+// item = bit index (33 bits) << 31 | table slot (31 bits)
+template <int W>
+__global__ __launch_bounds__(256) void k_bloom_items(const Slot *__restrict__ tab, uint64_t cap, uint64_t m_bits,
+                                                     unsigned long long *__restrict__ items, uint64_t item_cap, int shift1,
+                                                     unsigned long long *__restrict__ counters, unsigned long long *__restrict__ hist1) {
+	__shared__ uint32_t s_hist[256];
+	const uint32_t lane = threadIdx.x & 63u;
+	s_hist[threadIdx.x] = 0;
+	__syncthreads();
+	uint64_t chunk_base = 0;
+	uint32_t chunk_used = ITEM_CHUNK_KEYS;
+	bool have_chunk = false, dead = false;
+	const uint64_t nwaves = (uint64_t)gridDim.x * 4, wave_id = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+	for (uint64_t base = wave_id * 64; base < cap; base += nwaves * 64) {
+		const uint64_t i = base + lane;
+		Slot v;
+		bool used = false;
+		if (i < cap) {
+			v = tab[i];
+			used = v.k0 != EMPTY;
+		}
+		const unsigned long long ballot = __ballot(used);
+		const uint32_t c = (uint32_t)__popcll(ballot);
+		if (c == 0) continue;
+		// keys that do not fit the current chunk continue in a freshly claimed one (no holes in between)
+		const uint32_t room = have_chunk ? ITEM_CHUNK_KEYS - chunk_used : 0u;
+		uint64_t new_base = 0;
+		if (c > room) {
+			unsigned long long nb = 0;
+			if (lane == 0) nb = atomicAdd(&counters[BC_ITEM_CURSOR], (unsigned long long)ITEM_CHUNK_KEYS * 8);
+			nb = __shfl(nb, 0);
+			if (nb + ITEM_CHUNK_KEYS * 8 > item_cap) {
+				dead = true;
+				if (lane == 0) atomicAdd(&counters[BC_ITEM_OVF], 1ull);
+			}
+			new_base = nb;
+		}
+		if (used && !dead) {
+			const uint32_t idx = (uint32_t)__popcll(ballot & ((1ull << lane) - 1));
+			uint64_t K0, K1;
+			from_internal<W>(v.k0, v.k1, K0, K1);
+			const uint64_t origin = hash2<W>(K0, K1);
+			unsigned long long *dst = (idx < room) ? items + chunk_base + (uint64_t)(chunk_used + idx) * 8
+			                                       : items + new_base + (uint64_t)(idx - room) * 8;
+#pragma unroll
+			for (int j = 0; j < 8; ++j) {
+				const uint64_t b = (origin ^ BLOOM_MAGIC[j]) % m_bits;
+				const unsigned long long item = (b << 31) | i;
+				dst[j] = item;
+				atomicAdd(&s_hist[(item >> shift1) & 255u], 1u);
+			}
+		}
+		if (c > room) {
+			chunk_base = new_base;
+			chunk_used = c - room;
+			have_chunk = true;
+		} else {
+			chunk_used += c;
+		}
+	}
+	if (have_chunk && !dead)
+		for (uint32_t j = chunk_used * 8 + lane; j < ITEM_CHUNK_KEYS * 8; j += 64) items[chunk_base + j] = ITEM_INVALID;
+	__syncthreads();
+	if (s_hist[threadIdx.x]) atomicAdd(&hist1[threadIdx.x], (unsigned long long)s_hist[threadIdx.x]);
+}
+
+__device__ __forceinline__ uint32_t find_seg64(const uint32_t *__restrict__ tile_first, uint32_t S, uint32_t tile) {
+	uint32_t lo = 0, hi = S;
+	while (hi - lo > 1) {
+		uint32_t mid = (lo + hi) >> 1;
+		if (tile_first[mid] <= tile) lo = mid;
+		else hi = mid;
+	}
+	return lo;
+}
+
+__global__ __launch_bounds__(256) void k_hist64(const unsigned long long *__restrict__ in, uint32_t S,
+                                                const unsigned long long *__restrict__ seg_begin,
+                                                const uint32_t *__restrict__ tile_first, int shift,
+                                                unsigned long long *__restrict__ hist) {
+	__shared__ uint32_t s_cnt[256];
+	const uint32_t seg = find_seg64(tile_first, S, blockIdx.x);
+	const uint64_t begin = seg_begin[seg] + (uint64_t)(blockIdx.x - tile_first[seg]) * SCATTER64_TILE;
+	const uint64_t end = begin + SCATTER64_TILE < seg_begin[seg + 1] ? begin + SCATTER64_TILE : seg_begin[seg + 1];
+	s_cnt[threadIdx.x] = 0;
+	__syncthreads();
+	for (uint64_t i = begin + threadIdx.x; i < end; i += 256) {
+		unsigned long long it = in[i];
+		if (it != ITEM_INVALID) atomicAdd(&s_cnt[(it >> shift) & 255u], 1u);
+	}
+	__syncthreads();
+	if (s_cnt[threadIdx.x]) atomicAdd(&hist[((uint64_t)seg << 8) + threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
+}
+
+// one partition level of 8-byte items: same scheme as k_scatter (tile-local counting sort in LDS)
+__global__ __launch_bounds__(256) void k_scatter64(const unsigned long long *__restrict__ in, uint32_t S,
+                                                   const unsigned long long *__restrict__ seg_begin,
+                                                   const uint32_t *__restrict__ tile_first, int shift,
+                                                   unsigned long long *__restrict__ cursors, unsigned long long *__restrict__ out) {
+	constexpr int PER = SCATTER64_TILE / 256;
+	__shared__ unsigned long long s_item[SCATTER64_TILE];
+	__shared__ uint8_t s_dig[SCATTER64_TILE];
+	__shared__ uint32_t s_cnt[256], s_off[256], s_scan[256];
+	__shared__ unsigned long long s_gbase[256];
+	const uint32_t seg = find_seg64(tile_first, S, blockIdx.x);
+	const uint64_t begin = seg_begin[seg] + (uint64_t)(blockIdx.x - tile_first[seg]) * SCATTER64_TILE;
+	const uint64_t end = begin + SCATTER64_TILE < seg_begin[seg + 1] ? begin + SCATTER64_TILE : seg_begin[seg + 1];
+	s_cnt[threadIdx.x] = 0;
+	__syncthreads();
+	unsigned long long mine[PER];
+	uint32_t dig[PER], rank[PER];
+#pragma unroll
+	for (int j = 0; j < PER; ++j) {
+		const uint64_t i = begin + threadIdx.x + (uint64_t)j * 256;
+		dig[j] = 0xFFFFFFFFu;
+		rank[j] = 0;
+		mine[j] = ITEM_INVALID;
+		if (i < end) {
+			mine[j] = in[i];
+			if (mine[j] != ITEM_INVALID) {
+				dig[j] = (uint32_t)(mine[j] >> shift) & 255u;
+				rank[j] = atomicAdd(&s_cnt[dig[j]], 1u);
+			}
+		}
+	}
+	__syncthreads();
+	{
+		const uint32_t c = s_cnt[threadIdx.x];
+		s_scan[threadIdx.x] = c;
+		__syncthreads();
+		for (int d = 1; d < 256; d <<= 1) {
+			uint32_t t = (threadIdx.x >= (uint32_t)d) ? s_scan[threadIdx.x - d] : 0;
+			__syncthreads();
+			s_scan[threadIdx.x] += t;
+			__syncthreads();
+		}
+		s_off[threadIdx.x] = s_scan[threadIdx.x] - c;
+		unsigned long long g = 0;
+		if (c) g = atomicAdd(&cursors[((uint64_t)seg << 8) + threadIdx.x], (unsigned long long)c);
+		s_gbase[threadIdx.x] = g;
+	}
+	__syncthreads();
+	const uint32_t total = s_scan[255];
+#pragma unroll
+	for (int j = 0; j < PER; ++j)
+		if (dig[j] != 0xFFFFFFFFu) {
+			const uint32_t pos = s_off[dig[j]] + rank[j];
+			s_item[pos] = mine[j];
+			s_dig[pos] = (uint8_t)dig[j];
+		}
+	__syncthreads();
+	for (uint32_t i = threadIdx.x; i < total; i += 256) {
+		const uint32_t d = s_dig[i];
+		out[s_gbase[d] + (i - s_off[d])] = s_item[i];
+	}
+}
+
+// One workgroup per Bloom region at a time.  lost[slot >> 2] holds four 8-bit counters.
+template <int W>
+__global__ __launch_bounds__(512) void k_bloom_region(const unsigned long long *__restrict__ items,
+                                                      const unsigned long long *__restrict__ region_begin, uint32_t nregions,
+                                                      const Slot *__restrict__ tab, uint32_t *__restrict__ lost,
+                                                      unsigned long long *__restrict__ counters, int c_setbits) {
+	__shared__ uint32_t s_b1[REGION_WORDS];       // bit touched
+	__shared__ uint32_t s_b2[REGION_WORDS];       // bit touched more than once
+	__shared__ uint32_t s_pre[REGION_WORDS];      // exclusive prefix of popc(s_b2): rank of a contested bit
+	__shared__ unsigned long long s_min[REGION_MULTI_CAP];
+	__shared__ uint32_t s_scan[512];
+	__shared__ uint32_t s_setbits;
+	uint32_t setbits_total = 0;
+	for (uint32_t r = blockIdx.x; r < nregions; r += gridDim.x) {
+		const uint64_t begin = region_begin[r], end = region_begin[r + 1];
+		if (begin == end) continue;  // uniform
+		for (uint32_t i = threadIdx.x; i < REGION_WORDS; i += 512) {
+			s_b1[i] = 0;
+			s_b2[i] = 0;
+		}
+		__syncthreads();
+		// pass 1: touched / touched again
+		for (uint64_t i = begin + threadIdx.x; i < end; i += 512) {
+			const uint32_t b = (uint32_t)(items[i] >> 31) & (REGION_BITS - 1);
+			const uint32_t m = 1u << (b & 31u);
+			const uint32_t old = atomicOr(&s_b1[b >> 5], m);
+			if (old & m) atomicOr(&s_b2[b >> 5], m);
+		}
+		__syncthreads();
+		// rank the contested bits: exclusive prefix over the 4096 words (8 per thread)
+		uint32_t local[8], sum = 0, set1 = 0;
+#pragma unroll
+		for (int j = 0; j < 8; ++j) {
+			local[j] = __popc(s_b2[threadIdx.x * 8 + j]);
+			sum += local[j];
+			set1 += __popc(s_b1[threadIdx.x * 8 + j]);
+		}
+		s_scan[threadIdx.x] = sum;
+		__syncthreads();
+		for (int d = 1; d < 512; d <<= 1) {
+			uint32_t t = (threadIdx.x >= (uint32_t)d) ? s_scan[threadIdx.x - d] : 0;
+			__syncthreads();
+			s_scan[threadIdx.x] += t;
+			__syncthreads();
+		}
+		uint32_t run = s_scan[threadIdx.x] - sum;
+#pragma unroll
+		for (int j = 0; j < 8; ++j) {
+			s_pre[threadIdx.x * 8 + j] = run;
+			run += local[j];
+		}
+		const uint32_t nmulti = s_scan[511];
+		setbits_total += set1;
+		const bool fits = nmulti <= REGION_MULTI_CAP;  // uniform
+		if (!fits && threadIdx.x == 0) atomicAdd(&counters[BC_REGION_OVF], 1ull);
+		for (uint32_t i = threadIdx.x; i < nmulti && i < REGION_MULTI_CAP; i += 512) s_min[i] = INF_STAMP;
+		__syncthreads();
+		if (fits && nmulti) {
+			// pass 2: earliest toucher of every contested bit
+			for (uint64_t i = begin + threadIdx.x; i < end; i += 512) {
+				const unsigned long long it = items[i];
+				const uint32_t b = (uint32_t)(it >> 31) & (REGION_BITS - 1);
+				const uint32_t m = 1u << (b & 31u);
+				const uint32_t w2 = s_b2[b >> 5];
+				if (w2 & m) {
+					const uint32_t rank = s_pre[b >> 5] + __popc(w2 & (m - 1));
+					const unsigned long long stamp = tab[it & 0x7FFFFFFFull].stamp;
+					atomicMin(&s_min[rank], stamp);
+				}
+			}
+			__syncthreads();
+			// pass 3: every later toucher loses that bit check
+			for (uint64_t i = begin + threadIdx.x; i < end; i += 512) {
+				const unsigned long long it = items[i];
+				const uint32_t b = (uint32_t)(it >> 31) & (REGION_BITS - 1);
+				const uint32_t m = 1u << (b & 31u);
+				const uint32_t w2 = s_b2[b >> 5];
+				if (w2 & m) {
+					const uint32_t rank = s_pre[b >> 5] + __popc(w2 & (m - 1));
+					const uint64_t slot = it & 0x7FFFFFFFull;
+					if (tab[slot].stamp > s_min[rank]) atomicAdd(&lost[slot >> 2], 1u << ((slot & 3u) * 8u));
+				}
+			}
+		}
+		__syncthreads();
+	}
+	// set bits of all regions this workgroup handled
+	if (threadIdx.x == 0) s_setbits = 0;
+	__syncthreads();
+	if (setbits_total) atomicAdd(&s_setbits, setbits_total);
+	__syncthreads();
+	if (threadIdx.x == 0 && s_setbits) atomicAdd(&counters[c_setbits], (unsigned long long)s_setbits);
+}
+
+}  // namespace rg

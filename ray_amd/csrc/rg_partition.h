@@ -114,22 +114,27 @@ enum PartCounter { PC_REC_CURSOR = 16, PC_REC_OVF, PC_LOG_CURSOR, PC_LOG_OVF, PC
 
 // ------------------------------------------------------------------------------------------------
 // reads -> super-k-mer records.  One wavefront per read at a time, 64 k-mer positions per step.
+// Lane l of a step owns k-mer p0+l.  The m-mers of the read are mixed once each into a 128-entry ring
+// in LDS (value = 25 bits of a bijective mix | ring index), a lane's minimizer is the minimum over its
+// window of w = k-m+1 ring entries, and a new record starts wherever the minimizer *occurrence* changes
+// (so a record never holds more than w k-mers; the host checks w <= lmax_for()).
 template <int W>
 __global__ __launch_bounds__(256) void k_superkmers(const uint64_t *__restrict__ P, const uint64_t *__restrict__ offsets,
                                                     const uint32_t *__restrict__ lengths, uint64_t nreads, uint64_t read_id_base,
-                                                    int k, int m, int bits, Rec<W> *__restrict__ recs, uint64_t rec_cap,
+                                                    int k, int m, Rec<W> *__restrict__ recs, uint64_t rec_cap,
                                                     unsigned long long *__restrict__ counters,
                                                     unsigned long long *__restrict__ coarse_hist) {
 	constexpr int NB = 2 * W;
 	__shared__ uint32_t s_hk[4][128];
 	__shared__ uint32_t s_cn[4][128];
 	__shared__ uint32_t s_hist[NB_COARSE];
+	const uint32_t *__restrict__ P32 = reinterpret_cast<const uint32_t *>(P);
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	s_hist[threadIdx.x] = 0;
 	__syncthreads();
-	const int w = k - m + 1;
-	const int LMAX = lmax_for(W, k);
-	const uint64_t maskm = (1ull << (2 * m)) - 1;
+	const uint32_t w = (uint32_t)(k - m + 1);
+	const uint32_t maskm = (1u << (2 * m)) - 1;
+	const uint32_t rshift = 32u - 2u * (uint32_t)m;
 	const uint64_t nwaves = (uint64_t)gridDim.x * 4;
 	uint64_t chunk_base = 0;
 	uint32_t chunk_used = REC_CHUNK;
@@ -142,37 +147,37 @@ __global__ __launch_bounds__(256) void k_superkmers(const uint64_t *__restrict__
 		const uint32_t n = L - (uint32_t)k + 1;
 		const uint64_t bit0 = offsets[r] * 8;
 		if (lane == 0) occ += n;
+		uint32_t done_m = 0;  // m-mer positions [0, done_m) are in the ring
 		for (uint32_t p0 = 0; p0 < n; p0 += 64) {
 			const uint32_t cnt = (n - p0 < 64u) ? (n - p0) : 64u;
-			const uint32_t nm = cnt + (uint32_t)w - 1;  // m-mers under the step's k-mers (<= 112)
-			for (uint32_t jl = lane; jl < nm; jl += 64) {
-				uint64_t f = ext64(P, bit0 + 2ull * (p0 + jl)) & maskm;
-				uint32_t c = canon_mmer(f, m);
-				s_hk[wave][jl] = (fmix32(c) & ~127u) | jl;
-				s_cn[wave][jl] = c;
+			const uint32_t need = p0 + cnt + w - 1;
+			for (uint32_t j = done_m + lane; j < need; j += 64) {
+				const uint64_t bit = bit0 + 2ull * j;
+				const uint64_t wi = bit >> 5;
+				const uint32_t f = __builtin_amdgcn_alignbit(P32[wi + 1], P32[wi], (uint32_t)bit & 31u) & maskm;
+				uint32_t y = __brev(f);
+				y = ((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1);
+				const uint32_t rc = (~y) >> rshift;
+				const uint32_t c = f < rc ? f : rc;
+				s_hk[wave][j & 127u] = (fmix32(c) & ~127u) | (j & 127u);
+				s_cn[wave][j & 127u] = c;
 			}
+			done_m = need;
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 			__builtin_amdgcn_wave_barrier();
 			const bool active = lane < cnt;
+			const uint32_t p = p0 + lane;
 			uint32_t v = 0xFFFFFFFFu;
 			if (active)
-				for (int t = 0; t < w; ++t) {
-					uint32_t x = s_hk[wave][lane + t];
+				for (uint32_t t = 0; t < w; ++t) {
+					uint32_t x = s_hk[wave][(p + t) & 127u];
 					v = x < v ? x : v;
 				}
-			const uint32_t jstar = v & 127u;
-			const uint32_t canon = active ? s_cn[wave][jstar] : 0;
-			const uint32_t bucket = bucket24(canon) >> (24 - bits);  // runs share the full bucket id
-			uint32_t prevb = __shfl_up(bucket, 1);
-			bool start = active && (lane == 0 || bucket != prevb);
-			unsigned long long ballot = __ballot(start);
-			// cut runs longer than a record can hold
-			{
-				unsigned long long below = ballot & ((lane == 63) ? ~0ull : ((2ull << lane) - 1));
-				uint32_t runstart = 63u - (uint32_t)__clzll(below | 1ull);
-				if (active && !start && ((lane - runstart) % (uint32_t)LMAX) == 0) start = true;
-				ballot = __ballot(start);
-			}
+			const uint32_t jring = v & 127u;
+			const uint32_t jabs = p + ((jring - p) & 127u);  // read position of the minimizer occurrence
+			const uint32_t prevj = __shfl_up(jabs, 1);
+			const bool start = active && (lane == 0 || jabs != prevj);
+			const unsigned long long ballot = __ballot(start);
 			const uint32_t c = (uint32_t)__popcll(ballot);
 			if (chunk_used + c > REC_CHUNK) {  // wave-uniform
 				if (have_chunk && !dead)
@@ -190,21 +195,20 @@ __global__ __launch_bounds__(256) void k_superkmers(const uint64_t *__restrict__
 			}
 			if (start && !dead) {
 				const uint32_t idx = (uint32_t)__popcll(ballot & ((1ull << lane) - 1));
-				unsigned long long above = (lane == 63) ? 0ull : (ballot >> (lane + 1));
-				const uint32_t next = above ? (lane + 1 + (uint32_t)__ffsll((unsigned long long)above) - 1) : cnt;
+				const unsigned long long above = (lane == 63) ? 0ull : (ballot >> (lane + 1));
+				const uint32_t next = above ? (lane + (uint32_t)__ffsll((unsigned long long)above)) : cnt;
 				const uint32_t len = next - lane;
-				const uint32_t p = p0 + lane;
 				const uint32_t hasL = p > 0, hasR = (p + len) < n;
 				const uint32_t first = p - hasL;  // read position of the record's base 0
 				const uint32_t nbases = hasL + len + (uint32_t)k - 1 + hasR;
 				Rec<W> rec;
 #pragma unroll
 				for (int i = 0; i < NB; ++i) rec.w[i] = (nbases > 32u * i) ? ext64(P, bit0 + 2ull * first + 64ull * i) : 0;
-				const uint32_t moff = (p0 + jstar) - first;
+				const uint32_t moff = jabs - first;
 				rec.w[NB] = (uint64_t)p | ((uint64_t)(len - 1) << 16) | ((uint64_t)hasL << 22) | ((uint64_t)hasR << 23) |
 				            ((uint64_t)moff << 24) | ((read_id_base + r) << 31);
 				recs[chunk_base + chunk_used + idx] = rec;
-				atomicAdd(&s_hist[bucket >> (bits - 8)], 1u);
+				atomicAdd(&s_hist[bucket24(s_cn[wave][jring]) >> 16], 1u);
 			}
 			chunk_used += c;
 			__builtin_amdgcn_wave_barrier();

@@ -24,6 +24,11 @@ def partition_reads(total_reads, rank, size):
     return first, last
 
 
+def _staged(group):
+    """gloo cannot move device memory: stage through the host (tests / single-GPU rehearsals only)"""
+    return dist.get_backend(group) == "gloo"
+
+
 def exchange_owner_buckets(engine, group=None, device="cuda"):
     """all-to-all(v) of the per-owner buckets; returns (entries sent, entries received)."""
     size = engine.size
@@ -33,16 +38,21 @@ def exchange_owner_buckets(engine, group=None, device="cuda"):
     total = sum(counts)
     send = torch.empty(max(1, total) * RG_ENTRY_BYTES, dtype=torch.uint8, device=device)
     engine.export_owner_buckets(send.data_ptr(), max(1, total))
-    send_counts = torch.tensor(counts, dtype=torch.int64, device=device)
-    recv_counts = torch.empty(size, dtype=torch.int64, device=device)
+    staged = _staged(group) and str(device) != "cpu"
+    xdev = "cpu" if staged else device
+    send_counts = torch.tensor(counts, dtype=torch.int64, device=xdev)
+    recv_counts = torch.empty(size, dtype=torch.int64, device=xdev)
     dist.all_to_all_single(recv_counts, send_counts, group=group)
     recv_list = [int(x) for x in recv_counts.cpu().tolist()]
     n_recv = sum(recv_list)
-    recv = torch.empty(max(1, n_recv) * RG_ENTRY_BYTES, dtype=torch.uint8, device=device)
-    dist.all_to_all_single(recv[: n_recv * RG_ENTRY_BYTES], send[: total * RG_ENTRY_BYTES],
+    recv = torch.empty(max(1, n_recv) * RG_ENTRY_BYTES, dtype=torch.uint8, device=xdev)
+    src = send[: total * RG_ENTRY_BYTES].cpu() if staged else send[: total * RG_ENTRY_BYTES]
+    dist.all_to_all_single(recv[: n_recv * RG_ENTRY_BYTES], src,
                            output_split_sizes=[c * RG_ENTRY_BYTES for c in recv_list],
                            input_split_sizes=[c * RG_ENTRY_BYTES for c in counts], group=group)
-    if device != "cpu":
+    if staged:
+        recv = recv.to(device)
+    if str(device) != "cpu":
         torch.cuda.current_stream().synchronize()
     engine.merge_entries(recv.data_ptr(), n_recv)
     return total, n_recv
@@ -61,7 +71,8 @@ def reduce_histogram(cov, cnt, group=None, device="cuda", size=1):
     dense = torch.zeros(HIST_DENSE, dtype=torch.int64)
     low = cov < HIST_DENSE
     dense[torch.from_numpy(cov[low].astype(np.int64))] = torch.from_numpy(cnt[low].astype(np.int64))
-    dense = dense.to(device)
+    if not _staged(group):
+        dense = dense.to(device)
     dist.all_reduce(dense, op=dist.ReduceOp.SUM, group=group)
     dense = dense.cpu().numpy()
     tail = list(zip(cov[~low].tolist(), cnt[~low].tolist()))

@@ -190,11 +190,15 @@ class GraphBuilder:
     def set_profiling(self, enable=True):
         self._check(self._L.rg_set_profiling(self._h, 1 if enable else 0))
 
-    def sweep_time(self):
-        """(total ms, launches) of the k-mer sweep kernel, from HIP events on the launch stream"""
-        ms, n = C.c_double(), C.c_uint64()
-        self._check(self._L.rg_get_sweep_time(self._h, C.byref(ms), C.byref(n)))
-        return ms.value, n.value
+    def kernel_profile(self):
+        """{kernel name: (total ms, launches)} from HIP events on the launch stream"""
+        buf = C.create_string_buffer(8192)
+        self._check(self._L.rg_get_kernel_profile(self._h, buf, len(buf)))
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, ms, n = line.split()
+            out[name] = (float(ms), int(n))
+        return out
 
     def stats(self):
         s = RgStats()

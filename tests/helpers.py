@@ -29,10 +29,12 @@ def assert_records_equal(a, b, what=""):
 
 
 def gpu_vs_oracle(ro, packed, offsets, lengths, k, bloom_bits=None, W=None, purge=True, batches=1, tmpdir=None,
-                  sweeps=(1 | (8 << 8), 1 | (12 << 8), 1 | (19 << 8), 2)):
+                  sweeps=(1 | 16 | (8 << 8), 1 | 32 | (12 << 8), 1 | 16 | (19 << 8), 2 | 32, 2 | 16)):
     """single-rank parity through the C ABI, once per sweep implementation: the partitioned sweep
     (super-k-mer records + LDS aggregation) with 2^8, 2^12 and 2^19 buckets = one, two and three partition
-    levels, and the direct sweep (one table upsert per occurrence); returns the oracle outputs"""
+    levels, and the direct sweep (one table upsert per occurrence); flag 16 asks for the Bloom-region
+    partitioning (it falls back by itself when the filter is too full), flag 32 for the dense first-touch
+    stamps; returns the oracle outputs"""
     want = oracle_run(ro, packed, offsets, lengths, k, 1, bloom_bits, W, purge)
     for sweep in sweeps:
         want["builder"] = _gpu_check(ro, want, packed, offsets, lengths, k, bloom_bits, W, purge, batches, tmpdir, sweep)
@@ -53,7 +55,7 @@ def _gpu_check(ro, want, packed, offsets, lengths, k, bloom_bits, W, purge, batc
     b.count_kmers()
     st = b.stats()
     tag = "sweep 0x%x: " % sweep
-    assert st["sweep_partitioned"] == (1 if (sweep & 0xFF) == 1 else 0), tag + "wrong sweep ran"
+    assert st["sweep_partitioned"] == (1 if (sweep & 3) == 1 else 0), tag + "wrong sweep ran"
     assert st["occurrences"] == want["occ"], tag + "occurrences"
     assert b.size_() == want["size"], tag + "size"
     assert_records_equal(b.export(), want["pass1"], tag + "after pass 1")

@@ -47,7 +47,7 @@ def test_multirank_matches_oracle(oracle, k, nranks, bloom):
     packed, offsets, lengths = make_reads_numpy(genome=15000, read_len=100 if k < 63 else 150, n_reads=5001,
                                                 seed=k + nranks, error=0.015)
     want = oracle_run(oracle, packed, offsets, lengths, k, nranks, bloom)
-    for sweep in (1 | (17 << 8), 2):
+    for sweep in (1 | 16 | (17 << 8), 2 | 32):
         builders = run_ranks(packed, offsets, lengths, k, nranks, bloom, sweep=sweep)
         check_ranks(builders, want)
 

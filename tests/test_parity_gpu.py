@@ -50,6 +50,24 @@ def test_reads_added_in_several_batches_and_table_growth(oracle):
     assert want["builder"].stats()["table_slots"] >= 2 * want["builder"].stats()["candidates"] * 0.7
 
 
+def test_bloom_region_partitioning_is_used_and_exact(oracle):
+    """a sparse filter (the regime the reference sizes for) must go through the LDS region path, not fall back"""
+    import ray_amd
+    packed, offsets, lengths = make_reads_numpy(genome=40000, read_len=100, n_reads=9000, seed=71, error=0.02)
+    # 2^25 bits: 256 regions, one scatter level; 50 M and 2^28: two levels; 3 M is so dense that a region's
+    # contested bits exceed the LDS rank table, so the library must notice and redo it with dense stamps
+    for bits, partitioned in ((1 << 25, 1), (50_000_000, 1), (1 << 28, 1), (3_000_000, 0)):
+        want = oracle_run(oracle, packed, offsets, lengths, 31, 1, bits)
+        b = ray_amd.GraphBuilder(31, bloom_bits=bits, sweep=1 | 16)
+        b.add_reads(packed, offsets, lengths)
+        b.count_kmers()
+        st = b.stats()
+        assert st["bloom_partitioned"] == partitioned, bits
+        assert (st["bloom_bits"], st["bloom_set_bits"], st["bloom_insertions"]) == want["bloom"][0]
+        b.add_edges()
+        assert_records_equal(b.export(), want["pass2"], "bloom bits %d" % bits)
+
+
 def test_no_reads_and_no_kmers():
     import ray_amd
     b = ray_amd.GraphBuilder(31)
