@@ -808,7 +808,7 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ1, k_superkmers<W>, 256, 0) != hipSuccess || occ1 < 1) occ1 = 4;
 	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ3, k_aggregate<W>, 256, 0) != hipSuccess || occ3 < 1) occ3 = 4;
 	(void)hipGetLastError();
-	const int grid1 = (int)std::min<uint64_t>((uint64_t)n_cu * occ1, (total_reads + 3) / 4);
+	const int grid1 = (int)std::min<uint64_t>((uint64_t)n_cu * occ1, std::max<uint64_t>(1, (total_reads + 255) / 256));
 	uint64_t launches1 = 0;  // every launch of k_superkmers leaves up to one open chunk per wavefront
 	for (const ReadBatch &b : h->reads)
 		if (b.maxlen >= (uint32_t)k) launches1++;

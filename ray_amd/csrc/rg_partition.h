@@ -113,11 +113,28 @@ __device__ __forceinline__ uint32_t rec_bucket(const Rec<W> &r, int m) {
 enum PartCounter { PC_REC_CURSOR = 16, PC_REC_OVF, PC_LOG_CURSOR, PC_LOG_OVF, PC_LDS_SPILL };
 
 // ------------------------------------------------------------------------------------------------
-// reads -> super-k-mer records.  One wavefront per read at a time, 64 k-mer positions per step.
-// Lane l of a step owns k-mer p0+l.  The m-mers of the read are mixed once each into a 128-entry ring
-// in LDS (value = 25 bits of a bijective mix | ring index), a lane's minimizer is the minimum over its
-// window of w = k-m+1 ring entries, and a new record starts wherever the minimizer *occurrence* changes
-// (so a record never holds more than w k-mers; the host checks w <= lmax_for()).
+// reads -> super-k-mer records.  A wavefront takes 64 consecutive reads at a time (their lengths and
+// offsets arrive in one coalesced load) and walks them one by one, SK_STEP k-mer positions per step,
+// every lane owning two positions.  Per step:
+//   1. the words of the read that the step needs are staged in LDS (one lane per 32-bit word),
+//   2. every m-mer is made canonical and mixed once: x[j] = (24 bits of a bijective mix) | j,
+//   3. the minimum of each window of w = k-m+1 entries comes from a sparse table built with
+//      floor(log2 w) doubling passes over LDS instead of w reads per position,
+//   4. a record starts wherever the minimizer *occurrence* changes (so a record never holds more than
+//      w k-mers; the host checks w <= lmax_for()); the starts are compacted through LDS so that record i
+//      of the step is assembled by lane i and consecutive lanes store consecutive records.
+// The kernel is bound by VALU issue, not by bytes: everything here is about instructions per position.
+static constexpr uint32_t SK_STEP = 128;
+static constexpr uint32_t SK_X = 192;     // m-mers per step: SK_STEP + w - 1 <= 128 + 49
+static constexpr uint32_t SK_XPAD = 256;  // + sentinels that the doubling passes may read (j + 32 <= 223)
+static constexpr uint32_t SK_WORDS = 24;  // staged 32-bit words: 2 * (1 + 128 + 63 + 1) bits + misalignment, + 2 read ahead
+
+__device__ __forceinline__ uint32_t order_mix(uint32_t c) {  // bijective; 0 (poly-A) must not map to the minimum
+	uint32_t h = (c ^ 0x5bd1e995u) * 0x9E3779B1u;
+	h ^= h >> 15;
+	return h * 0x85ebca6bu;
+}
+
 template <int W>
 __global__ __launch_bounds__(256) void k_superkmers(const uint64_t *__restrict__ P, const uint64_t *__restrict__ offsets,
                                                     const uint32_t *__restrict__ lengths, uint64_t nreads, uint64_t read_id_base,
@@ -125,97 +142,188 @@ __global__ __launch_bounds__(256) void k_superkmers(const uint64_t *__restrict__
                                                     unsigned long long *__restrict__ counters,
                                                     unsigned long long *__restrict__ coarse_hist) {
 	constexpr int NB = 2 * W;
-	__shared__ uint32_t s_hk[4][128];
-	__shared__ uint32_t s_cn[4][128];
+	__shared__ uint32_t s_x[4][2][SK_XPAD];
+	__shared__ uint32_t s_cn[4][SK_X];
+	__shared__ uint32_t s_wd[4][SK_WORDS];
+	__shared__ uint32_t s_list[4][SK_STEP + 4];
 	__shared__ uint32_t s_hist[NB_COARSE];
 	const uint32_t *__restrict__ P32 = reinterpret_cast<const uint32_t *>(P);
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	uint32_t *const wd = s_wd[wave];
+	uint32_t *const cn = s_cn[wave];
+	uint32_t *const list = s_list[wave];
 	s_hist[threadIdx.x] = 0;
+	s_x[wave][0][SK_X + lane] = 0xFFFFFFFFu;
+	s_x[wave][1][SK_X + lane] = 0xFFFFFFFFu;
 	__syncthreads();
 	const uint32_t w = (uint32_t)(k - m + 1);
 	const uint32_t maskm = (1u << (2 * m)) - 1;
 	const uint32_t rshift = 32u - 2u * (uint32_t)m;
+	const unsigned long long lt_mask = (1ull << lane) - 1;
 	const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+	const uint64_t ngroups = (nreads + 63) / 64;
 	uint64_t chunk_base = 0;
 	uint32_t chunk_used = REC_CHUNK;
 	bool have_chunk = false, dead = false;
 	unsigned long long occ = 0;
 
-	for (uint64_t r = (uint64_t)blockIdx.x * 4 + wave; r < nreads; r += nwaves) {
-		const uint32_t L = lengths[r];
-		if (L < (uint32_t)k) continue;
-		const uint32_t n = L - (uint32_t)k + 1;
-		const uint64_t bit0 = offsets[r] * 8;
-		if (lane == 0) occ += n;
-		uint32_t done_m = 0;  // m-mer positions [0, done_m) are in the ring
-		for (uint32_t p0 = 0; p0 < n; p0 += 64) {
-			const uint32_t cnt = (n - p0 < 64u) ? (n - p0) : 64u;
-			const uint32_t need = p0 + cnt + w - 1;
-			for (uint32_t j = done_m + lane; j < need; j += 64) {
-				const uint64_t bit = bit0 + 2ull * j;
-				const uint64_t wi = bit >> 5;
-				const uint32_t f = __builtin_amdgcn_alignbit(P32[wi + 1], P32[wi], (uint32_t)bit & 31u) & maskm;
-				uint32_t y = __brev(f);
-				y = ((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1);
-				const uint32_t rc = (~y) >> rshift;
-				const uint32_t c = f < rc ? f : rc;
-				s_hk[wave][j & 127u] = (fmix32(c) & ~127u) | (j & 127u);
-				s_cn[wave][j & 127u] = c;
-			}
-			done_m = need;
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-			__builtin_amdgcn_wave_barrier();
-			const bool active = lane < cnt;
-			const uint32_t p = p0 + lane;
-			uint32_t v = 0xFFFFFFFFu;
-			if (active)
-				for (uint32_t t = 0; t < w; ++t) {
-					uint32_t x = s_hk[wave][(p + t) & 127u];
-					v = x < v ? x : v;
-				}
-			const uint32_t jring = v & 127u;
-			const uint32_t jabs = p + ((jring - p) & 127u);  // read position of the minimizer occurrence
-			const uint32_t prevj = __shfl_up(jabs, 1);
-			const bool start = active && (lane == 0 || jabs != prevj);
-			const unsigned long long ballot = __ballot(start);
-			const uint32_t c = (uint32_t)__popcll(ballot);
-			if (chunk_used + c > REC_CHUNK) {  // wave-uniform
-				if (have_chunk && !dead)
-					for (uint32_t i = chunk_used + lane; i < REC_CHUNK; i += 64) recs[chunk_base + i].w[NB] = REC_INVALID;
-				unsigned long long nb = 0;
-				if (lane == 0) nb = atomicAdd(&counters[PC_REC_CURSOR], (unsigned long long)REC_CHUNK);
-				nb = __shfl(nb, 0);
-				if (nb + REC_CHUNK > rec_cap) {
-					dead = true;
-					if (lane == 0) atomicAdd(&counters[PC_REC_OVF], 1ull);
-				}
-				chunk_base = nb;
-				chunk_used = 0;
-				have_chunk = true;
-			}
-			if (start && !dead) {
-				const uint32_t idx = (uint32_t)__popcll(ballot & ((1ull << lane) - 1));
-				const unsigned long long above = (lane == 63) ? 0ull : (ballot >> (lane + 1));
-				const uint32_t next = above ? (lane + (uint32_t)__ffsll((unsigned long long)above)) : cnt;
-				const uint32_t len = next - lane;
-				const uint32_t hasL = p > 0, hasR = (p + len) < n;
-				const uint32_t first = p - hasL;  // read position of the record's base 0
-				const uint32_t nbases = hasL + len + (uint32_t)k - 1 + hasR;
-				Rec<W> rec;
+	for (uint64_t g = (uint64_t)blockIdx.x * 4 + wave; g < ngroups; g += nwaves) {
+		const uint64_t rb = g * 64;
+		uint32_t myL = 0, myoff_lo = 0, myoff_hi = 0;
+		if (rb + lane < nreads) {
+			myL = lengths[rb + lane];
+			const uint64_t o = offsets[rb + lane] * 8;  // bit offset of the read
+			myoff_lo = (uint32_t)o;
+			myoff_hi = (uint32_t)(o >> 32);
+		}
+		const uint32_t nin = (nreads - rb < 64) ? (uint32_t)(nreads - rb) : 64u;
+		for (uint32_t i = 0; i < nin; ++i) {
+			const uint32_t L = (uint32_t)__builtin_amdgcn_readlane((int)myL, (int)i);
+			if (L < (uint32_t)k) continue;
+			const uint64_t bit0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)myoff_hi, (int)i) << 32) |
+			                      (uint32_t)__builtin_amdgcn_readlane((int)myoff_lo, (int)i);
+			const uint32_t n = L - (uint32_t)k + 1;
+			const uint64_t rid = (read_id_base + rb + i) << 31;
+			occ += n;
+			for (uint32_t p0 = 0; p0 < n; p0 += SK_STEP) {
+				const uint32_t cnt = (n - p0 < SK_STEP) ? (n - p0) : SK_STEP;
+				const uint32_t fb = p0 ? p0 - 1 : 0;  // first base the step can need (left neighbour of k-mer p0)
+				const uint64_t bitf = bit0 + 2ull * fb;
+				const uint64_t w0 = bitf >> 5;
+				const uint32_t sh = (uint32_t)bitf & 31u;  // base j >= fb starts at bit sh + 2 (j - fb) of the staged words
+				const uint32_t lastb = (p0 + cnt + (uint32_t)k - 1 < L - 1) ? (p0 + cnt + (uint32_t)k - 1) : (L - 1);
+				const uint32_t nw = (sh + 2u * (lastb - fb) + 2u + 31u) >> 5;
+				if (lane < SK_WORDS) wd[lane] = (lane < nw) ? P32[w0 + lane] : 0u;
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+				// canonical m-mers p0 .. p0+need-1, mixed
+				const uint32_t need = cnt + w - 1;
+				const uint32_t mb = sh + 2u * (p0 - fb);  // bit of m-mer 0 of the step
+				uint32_t x[3];
 #pragma unroll
-				for (int i = 0; i < NB; ++i) rec.w[i] = (nbases > 32u * i) ? ext64(P, bit0 + 2ull * first + 64ull * i) : 0;
-				const uint32_t moff = jabs - first;
-				rec.w[NB] = (uint64_t)p | ((uint64_t)(len - 1) << 16) | ((uint64_t)hasL << 22) | ((uint64_t)hasR << 23) |
-				            ((uint64_t)moff << 24) | ((read_id_base + r) << 31);
-				recs[chunk_base + chunk_used + idx] = rec;
-				atomicAdd(&s_hist[bucket24(s_cn[wave][jring]) >> 16], 1u);
+				for (uint32_t e = 0; e < 3; ++e) {
+					x[e] = 0xFFFFFFFFu;
+					if (64u * e < need) {
+						const uint32_t j = lane + 64u * e;
+						uint32_t c = 0;
+						if (j < need) {
+							const uint32_t rbit = mb + 2u * j;
+							const uint32_t wi = rbit >> 5;
+							const uint32_t f = __builtin_amdgcn_alignbit(wd[wi + 1], wd[wi], rbit & 31u) & maskm;
+							uint32_t y = __brev(f);
+							y = ((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1);
+							const uint32_t rc = (~y) >> rshift;
+							c = f < rc ? f : rc;
+							x[e] = (order_mix(c) & ~255u) | j;
+						}
+						s_x[wave][0][j] = x[e];
+						cn[j] = c;
+					}
+				}
+				// sparse table: after the pass with stride s, entry j is the minimum of x[j .. j+2s)
+				uint32_t cur = 0, s = 1;
+				for (; 2u * s <= w; s <<= 1) {
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+					__builtin_amdgcn_wave_barrier();
+					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+					const uint32_t *src = s_x[wave][cur];
+					uint32_t *dst = s_x[wave][cur ^ 1u];
+#pragma unroll
+					for (uint32_t e = 0; e < 3; ++e)
+						if (64u * e < need) {
+							const uint32_t j = lane + 64u * e;
+							const uint32_t o = src[j + s];
+							x[e] = o < x[e] ? o : x[e];
+							dst[j] = x[e];
+						}
+					cur ^= 1u;
+				}
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+				// s is now the largest power of two <= w: window [p, p+w) = [p, p+s) u [p+w-s, p+w)
+				const uint32_t *tab = s_x[wave][cur];
+				const uint32_t tail = w - s;
+				uint32_t jr[2];
+				bool act[2];
+#pragma unroll
+				for (uint32_t e = 0; e < 2; ++e) {
+					const uint32_t p = lane + 64u * e;
+					act[e] = p < cnt;
+					const uint32_t o = tab[p + tail];
+					const uint32_t v = o < x[e] ? o : x[e];
+					jr[e] = v & 255u;  // where the minimizer of k-mer p0+p starts, relative to p0
+				}
+				uint32_t prev0 = __shfl_up(jr[0], 1);
+				uint32_t prev1 = __shfl_up(jr[1], 1);
+				const uint32_t last0 = (uint32_t)__builtin_amdgcn_readlane((int)jr[0], 63);
+				if (lane == 0) prev1 = last0;
+				const bool st0 = act[0] && (lane == 0 || jr[0] != prev0);
+				const bool st1 = act[1] && (jr[1] != prev1);
+				const unsigned long long b0 = __ballot(st0), b1 = __ballot(st1);
+				const uint32_t c0 = (uint32_t)__popcll(b0);
+				const uint32_t c = c0 + (uint32_t)__popcll(b1);
+				if (chunk_used + c > REC_CHUNK) {  // wave-uniform
+					if (have_chunk && !dead)
+						for (uint32_t q = chunk_used + lane; q < REC_CHUNK; q += 64) recs[chunk_base + q].w[NB] = REC_INVALID;
+					unsigned long long nbase = 0;
+					if (lane == 0) nbase = atomicAdd(&counters[PC_REC_CURSOR], (unsigned long long)REC_CHUNK);
+					nbase = __shfl(nbase, 0);
+					if (nbase + REC_CHUNK > rec_cap) {
+						dead = true;
+						if (lane == 0) atomicAdd(&counters[PC_REC_OVF], 1ull);
+					}
+					chunk_base = nbase;
+					chunk_used = 0;
+					have_chunk = true;
+				}
+				if (st0) list[(uint32_t)__popcll(b0 & lt_mask)] = lane | (jr[0] << 8);
+				if (st1) list[c0 + (uint32_t)__popcll(b1 & lt_mask)] = (lane + 64u) | (jr[1] << 8);
+				if (lane == 0) list[c] = cnt;
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+				if (!dead)
+					for (uint32_t i0 = 0; i0 < c; i0 += 64) {
+						const uint32_t idx = i0 + lane;
+						if (idx < c) {
+							const uint32_t ent = list[idx];
+							const uint32_t pr = ent & 255u, jm = ent >> 8;
+							const uint32_t len = (list[idx + 1] & 255u) - pr;
+							const uint32_t p = p0 + pr;
+							const uint32_t hasL = p > 0, hasR = (p + len) < n;
+							const uint32_t first = p - hasL;  // read position of the record's base 0
+							const uint32_t nbases = hasL + len + (uint32_t)k - 1 + hasR;
+							const uint32_t rbit = sh + 2u * (first - fb);
+							Rec<W> rec;
+#pragma unroll
+							for (int q = 0; q < NB; ++q) {
+								const uint32_t bq = rbit + 64u * q;
+								const uint32_t wi = bq >> 5, sf = bq & 31u;
+								uint64_t word = 0;
+								if (nbases > 32u * q) {
+									const uint32_t a0 = wd[wi], a1 = wd[wi + 1], a2 = wd[wi + 2];
+									word = (uint64_t)__builtin_amdgcn_alignbit(a1, a0, sf) | ((uint64_t)__builtin_amdgcn_alignbit(a2, a1, sf) << 32);
+								}
+								rec.w[q] = word;
+							}
+							const uint32_t moff = p0 + jm - first;
+							rec.w[NB] = (uint64_t)p | ((uint64_t)(len - 1) << 16) | ((uint64_t)hasL << 22) | ((uint64_t)hasR << 23) |
+							            ((uint64_t)moff << 24) | rid;
+							recs[chunk_base + chunk_used + idx] = rec;
+							atomicAdd(&s_hist[bucket24(cn[jm]) >> 16], 1u);
+						}
+					}
+				chunk_used += c;
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+				__builtin_amdgcn_wave_barrier();
 			}
-			chunk_used += c;
-			__builtin_amdgcn_wave_barrier();
 		}
 	}
 	if (have_chunk && !dead)
-		for (uint32_t i = chunk_used + lane; i < REC_CHUNK; i += 64) recs[chunk_base + i].w[NB] = REC_INVALID;
+		for (uint32_t q = chunk_used + lane; q < REC_CHUNK; q += 64) recs[chunk_base + q].w[NB] = REC_INVALID;
 	if (lane == 0 && occ) atomicAdd(&counters[2 /*C_OCC*/], occ);
 	__syncthreads();
 	if (s_hist[threadIdx.x]) atomicAdd(&coarse_hist[threadIdx.x], (unsigned long long)s_hist[threadIdx.x]);
