@@ -931,8 +931,8 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	// 3. aggregate per bucket into the log.  The log holds one entry per distinct k-mer of a bucket
 	// flush; a quarter of the occurrences is a deterministic size (the pool reuses the block) that only
 	// low-coverage inputs exceed -- they fall back to the direct sweep
-	const unsigned agg_grid = (unsigned)std::min<uint64_t>(NBUCK, (uint64_t)n_cu * occ3);
-	uint64_t log_cap = std::min<uint64_t>(occ_bound, std::max<uint64_t>(occ_bound / 4, 1ull << 20)) + (uint64_t)agg_grid * LOG_CHUNK;
+	const unsigned agg_grid = (unsigned)std::min<uint64_t>((NBUCK + AGG_WAVES - 1) / AGG_WAVES, (uint64_t)n_cu * occ3);
+	uint64_t log_cap = std::min<uint64_t>(occ_bound, std::max<uint64_t>(occ_bound / 4, 1ull << 20)) + (uint64_t)agg_grid * AGG_WAVES * LOG_CHUNK;
 	if (pool_alloc(dev, (void **)&log, log_cap * sizeof(Slot)) != hipSuccess) {
 		(void)hipGetLastError();
 		cleanup();

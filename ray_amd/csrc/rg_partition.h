@@ -306,6 +306,9 @@ __global__ __launch_bounds__(256) void k_superkmers(const uint64_t *__restrict__
 								if (nbases > 32u * q) {
 									const uint32_t a0 = wd[wi], a1 = wd[wi + 1], a2 = wd[wi + 2];
 									word = (uint64_t)__builtin_amdgcn_alignbit(a1, a0, sf) | ((uint64_t)__builtin_amdgcn_alignbit(a2, a1, sf) << 32);
+									// bits past the last base are zeroed: equal super-k-mers are equal records (k_aggregate merges them)
+									const uint32_t rem = nbases - 32u * q;
+									if (rem < 32u) word &= (1ull << (2u * rem)) - 1;
 								}
 								rec.w[q] = word;
 							}
@@ -487,33 +490,75 @@ __global__ __launch_bounds__(256) void k_scan_add(unsigned long long *__restrict
 }
 
 // ------------------------------------------------------------------------------------------------
-// One workgroup per bucket at a time: expand the records and aggregate per canonical k-mer in an LDS
-// hash table (structure of arrays, 24 B per slot for one-word keys), then append the distinct entries
-// to the log.  Slots claimed since the last flush are remembered in a list, so a flush costs O(distinct
-// keys), not O(table).  Log space is reserved LOG_CHUNK entries at a time per workgroup (one global
-// atomic per chunk instead of one per bucket); unused entries of a chunk are marked EMPTY.
-static constexpr uint32_t AGG_SLOTS = 1024;
-static constexpr uint32_t AGG_FLUSH = AGG_SLOTS * 7 / 10;
-static constexpr uint32_t LOG_CHUNK = 2048;
+// One *wavefront* per bucket at a time (a bucket is a few hundred records; thousands of independent
+// wavefronts keep enough loads in flight, and a wavefront needs no s_barrier).  Two LDS hash tables
+// per wavefront:
+//  1. a table of distinct *records*.  At coverage c the same super-k-mer arrives from ~c reads as
+//     bit-identical records (apart from read id and position), so records are merged first: key =
+//     bases + length + neighbour flags, value = multiplicity and smallest (read id, position).  Equal
+//     records produce equal k-mers with equal edge bits, and the smallest stamp of k-mer i over them is
+//     (smallest record stamp) + i, so expanding one representative with a weight is exact.
+//  2. a table of distinct k-mers, fed by expanding every distinct record once (lane per record,
+//     rolling k-mer / reverse complement), then appended to the log.
+// Slots claimed since the last flush are remembered in lists, so a flush costs O(distinct keys).  Log
+// space is reserved LOG_CHUNK entries at a time per wavefront; unused entries of a chunk are EMPTY.
+// Neither table can overfill: their fill is checked at points between which at most 64 keys arrive
+// (the spill path of the k-mer table is for safety only).  The records of the next round (or of the
+// next bucket's first round) are loaded before the current round is processed.
+static constexpr uint32_t AGG_SLOTS = 256;
+static constexpr uint32_t AGG_LIMIT = AGG_SLOTS * 8 / 10;
+static constexpr uint32_t AGG_FLUSH = AGG_LIMIT - 64;
+static constexpr uint32_t RT_SLOTS = 128;
+static constexpr uint32_t RT_FLUSH = RT_SLOTS * 3 / 4 - 64;
+static constexpr uint32_t LOG_CHUNK = 512;
+static constexpr uint32_t AGG_WAVES = 4;  // wavefronts per workgroup
 
 template <int W>
 struct AggTable {
 	uint64_t k0[AGG_SLOTS];
 	uint64_t k1[W == 2 ? AGG_SLOTS : 1];
 	uint64_t stamp[AGG_SLOTS];
-	uint64_t meta[AGG_SLOTS];
+	uint32_t cnt[AGG_SLOTS];
+	uint32_t edges[AGG_SLOTS];
 	uint16_t list[AGG_SLOTS];
+	uint32_t fill;
 };
 
 template <int W>
-__device__ __forceinline__ bool lds_upsert(AggTable<W> &t, uint32_t *fill, uint64_t i0, uint64_t i1, uint64_t stamp, uint32_t emask) {
-	uint32_t s = (uint32_t)slot_hash<W>(i0, i1) & (AGG_SLOTS - 1);
+struct RecTable {
+	unsigned long long fp[RT_SLOTS];  // 0 = free, else a 63-bit fingerprint of the key | 1
+	uint64_t w[2 * W][RT_SLOTS];
+	uint64_t stamp[RT_SLOTS];
+	uint32_t tag[RT_SLOTS];  // header bits 16..30: length, neighbour flags, minimizer offset
+	uint32_t cnt[RT_SLOTS];
+	uint16_t list[RT_SLOTS];
+	uint32_t fill, rmax, rsum;
+};
+
+__device__ __forceinline__ void wave_sync() {  // orders this wavefront's LDS traffic; no s_barrier
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int W>
+__device__ __forceinline__ uint32_t agg_hash(uint64_t i0, uint64_t i1) {
+	uint32_t x = (uint32_t)i0 ^ __builtin_amdgcn_alignbit((uint32_t)(i0 >> 32), (uint32_t)(i0 >> 32), 19);
+	if (W == 2) x ^= __builtin_amdgcn_alignbit((uint32_t)i1, (uint32_t)i1, 7) ^ __builtin_amdgcn_alignbit((uint32_t)(i1 >> 32), (uint32_t)(i1 >> 32), 25);
+	x ^= x >> 15;
+	return (x * 0x9E3779B1u) >> 24;  // 8 bits
+}
+static_assert(AGG_SLOTS == 256, "agg_hash returns 8 bits");
+
+template <int W>
+__device__ __forceinline__ bool lds_upsert(AggTable<W> &t, uint64_t i0, uint64_t i1, uint64_t stamp, uint32_t emask, uint32_t weight) {
+	uint32_t s = agg_hash<W>(i0, i1);
 	for (uint32_t probe = 0; probe < AGG_SLOTS; ++probe) {
 		uint64_t c0 = t.k0[s];
 		if (c0 == EMPTY) {
 			uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long *>(&t.k0[s]), EMPTY, i0);
 			if (prev == EMPTY) {
-				uint32_t idx = atomicAdd(fill, 1u);
+				uint32_t idx = atomicAdd(&t.fill, 1u);
 				t.list[idx] = (uint16_t)s;
 				c0 = i0;
 			} else {
@@ -531,11 +576,9 @@ __device__ __forceinline__ bool lds_upsert(AggTable<W> &t, uint32_t *fill, uint6
 				match = (c1 == i1);
 			}
 			if (match) {
-				if (stamp < t.stamp[s]) atomicMin(reinterpret_cast<unsigned long long *>(&t.stamp[s]), stamp);
-				uint64_t add = 1ull;
-				uint32_t pend = (uint32_t)(t.meta[s] >> PEND_SHIFT) & 0xFFu;
-				if (emask & ~pend) atomicOr(reinterpret_cast<unsigned long long *>(&t.meta[s]), (uint64_t)emask << PEND_SHIFT);
-				atomicAdd(reinterpret_cast<unsigned long long *>(&t.meta[s]), add);
+				atomicMin(reinterpret_cast<unsigned long long *>(&t.stamp[s]), stamp);
+				atomicAdd(&t.cnt[s], weight);
+				atomicOr(&t.edges[s], emask);
 				return true;
 			}
 		}
@@ -545,153 +588,285 @@ __device__ __forceinline__ bool lds_upsert(AggTable<W> &t, uint32_t *fill, uint6
 }
 
 template <int W>
-__global__ __launch_bounds__(256) void k_aggregate(const Rec<W> *__restrict__ recs, const unsigned long long *__restrict__ bucket_begin,
-                                                   uint32_t nbuckets, int k, Slot *__restrict__ log, uint64_t log_cap,
-                                                   unsigned long long *__restrict__ counters) {
+__global__ __launch_bounds__(64 * AGG_WAVES) void k_aggregate(const Rec<W> *__restrict__ recs,
+                                                              const unsigned long long *__restrict__ bucket_begin, uint32_t nbuckets,
+                                                              int k, Slot *__restrict__ log, uint64_t log_cap,
+                                                              unsigned long long *__restrict__ counters) {
 	constexpr int NB = 2 * W;
-	__shared__ AggTable<W> s_t;
-	__shared__ uint32_t s_fill, s_chunk_used;
-	__shared__ unsigned long long s_chunk_base, s_new_base;
+	__shared__ AggTable<W> s_tables[AGG_WAVES];
+	__shared__ RecTable<W> s_rtables[AGG_WAVES];
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	AggTable<W> &T = s_tables[wave];
+	RecTable<W> &R = s_rtables[wave];
 	const uint64_t mask0 = (2 * k >= 64) ? ~0ull : ((1ull << (2 * k)) - 1);
 	const uint64_t mask1 = (k > 32) ? ((1ull << (2 * k - 64)) - 1) : 0ull;
 	const unsigned long long NO_CHUNK = ~0ull;
+	unsigned long long chunk_base = NO_CHUNK;  // wave-uniform
+	uint32_t chunk_used = 0;
 
-	// all threads call this at the same point (the condition is uniform: s_fill is read after a barrier).
-	// The flushed entries continue the workgroup's current log chunk and spill over into a new one.
+	// flush() and expand() are wave-uniform: their conditions come from fill counters read after wave_sync().
+	// flush: the k-mer table's entries continue the wavefront's current log chunk and spill over into a new one.
 	auto flush = [&]() {
-		const uint32_t n = s_fill;
+		const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)T.fill);
 		if (n == 0) return;
-		const uint32_t room = (s_chunk_base == NO_CHUNK) ? 0u : LOG_CHUNK - s_chunk_used;
-		const unsigned long long old_dst = s_chunk_base + s_chunk_used;
+		const uint32_t room = (chunk_base == NO_CHUNK) ? 0u : LOG_CHUNK - chunk_used;
+		const unsigned long long old_dst = chunk_base + chunk_used;
+		unsigned long long new_dst = 0;
 		if (n > room) {
-			__syncthreads();
-			if (threadIdx.x == 0) {
-				unsigned long long g = atomicAdd(&counters[PC_LOG_CURSOR], (unsigned long long)LOG_CHUNK);
-				if (g + LOG_CHUNK > log_cap) atomicAdd(&counters[PC_LOG_OVF], 1ull);
-				s_new_base = g;
+			if (lane == 0) {
+				new_dst = atomicAdd(&counters[PC_LOG_CURSOR], (unsigned long long)LOG_CHUNK);
+				if (new_dst + LOG_CHUNK > log_cap) atomicAdd(&counters[PC_LOG_OVF], 1ull);
 			}
-			__syncthreads();
+			new_dst = __shfl(new_dst, 0);
 		}
-		const unsigned long long new_dst = s_new_base;
-		for (uint32_t i = threadIdx.x; i < n; i += 256) {
-			const uint32_t sl = s_t.list[i];
+		for (uint32_t i = lane; i < n; i += 64) {
+			const uint32_t sl = T.list[i];
 			const unsigned long long dst = (i < room) ? old_dst + i : new_dst + (i - room);
 			if (dst < log_cap) {
 				Slot e;
-				e.k0 = s_t.k0[sl];
-				e.k1 = (W == 2) ? s_t.k1[sl] : EMPTY;
-				e.stamp = s_t.stamp[sl];
-				e.meta = s_t.meta[sl];
+				e.k0 = T.k0[sl];
+				e.k1 = (W == 2) ? T.k1[sl] : EMPTY;
+				e.stamp = T.stamp[sl];
+				e.meta = (uint64_t)T.cnt[sl] | ((uint64_t)(T.edges[sl] & 0xFFu) << PEND_SHIFT);
 				log[dst] = e;
 			}
-			s_t.k0[sl] = EMPTY;
-			if (W == 2) s_t.k1[sl] = EMPTY;
-			s_t.stamp[sl] = INF_STAMP;
-			s_t.meta[sl] = 0;
+			T.k0[sl] = EMPTY;
+			if (W == 2) T.k1[sl] = EMPTY;
+			T.stamp[sl] = INF_STAMP;
+			T.cnt[sl] = 0;
+			T.edges[sl] = 0;
 		}
-		__syncthreads();
-		if (threadIdx.x == 0) {
-			if (n > room) {
-				s_chunk_base = new_dst;
-				s_chunk_used = n - room;
-			} else {
-				s_chunk_used += n;
-			}
-			s_fill = 0;
+		if (n > room) {
+			chunk_base = new_dst;
+			chunk_used = n - room;
+		} else {
+			chunk_used += n;
 		}
-		__syncthreads();
+		if (lane == 0) T.fill = 0;
+		wave_sync();
 	};
 
-	for (uint32_t i = threadIdx.x; i < AGG_SLOTS; i += 256) {
-		s_t.k0[i] = EMPTY;
-		if (W == 2) s_t.k1[i] = EMPTY;
-		s_t.stamp[i] = INF_STAMP;
-		s_t.meta[i] = 0;
-	}
-	if (threadIdx.x == 0) {
-		s_fill = 0;
-		s_chunk_used = 0;
-		s_chunk_base = NO_CHUNK;
-	}
-	__syncthreads();
-
-	for (uint32_t b = blockIdx.x; b < nbuckets; b += gridDim.x) {
-		const uint64_t begin = bucket_begin[b], end = bucket_begin[b + 1];
-		for (uint64_t base = begin; base < end; base += 256) {
-			const uint64_t ri = base + threadIdx.x;
-			if (ri < end) {
-				const Rec<W> rec = recs[ri];
-				uint64_t bw[NB];
+	// expand: every distinct record of the record table goes through the k-mer table once, weighted
+	auto expand = [&]() {
+		const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)R.fill);
+		if (n == 0) return;
+		for (uint32_t e0 = 0; e0 < n; e0 += 64) {
+			if (lane == 0) {
+				R.rmax = 0;
+				R.rsum = 0;
+			}
+			wave_sync();
+			const uint32_t e = e0 + lane;
+			uint32_t len = 0, hasL = 0, hasR = 0, prev = 0, prev_valid = 0, weight = 0;
+			uint64_t bw[NB], f0 = 0, f1 = 0, r0 = 0, r1 = 0, stamp0 = 0, upcoming = 0;
 #pragma unroll
-				for (int i = 0; i < NB; ++i) bw[i] = rec.w[i];
-				const uint64_t hdr = rec.w[NB];
-				const uint32_t pos = (uint32_t)hdr & 0xFFFFu, len = ((uint32_t)(hdr >> 16) & 63u) + 1;
-				const uint32_t hasL = (uint32_t)(hdr >> 22) & 1u, hasR = (uint32_t)(hdr >> 23) & 1u;
-				const uint64_t stamp0 = ((hdr >> 31) << 16) | pos;
-				uint64_t f0 = rec_ext<W>(bw, hasL) & mask0, f1 = 0;
+			for (int i = 0; i < NB; ++i) bw[i] = 0;
+			if (e < n) {
+				const uint32_t sl = R.list[e];
+#pragma unroll
+				for (int i = 0; i < NB; ++i) bw[i] = R.w[i][sl];
+				const uint32_t tag = R.tag[sl];
+				weight = R.cnt[sl];
+				stamp0 = R.stamp[sl];
+				R.fp[sl] = 0;
+				R.cnt[sl] = 0;
+				R.stamp[sl] = INF_STAMP;
+				len = (tag & 63u) + 1;
+				hasL = (tag >> 6) & 1u;
+				hasR = (tag >> 7) & 1u;
+				f0 = rec_ext<W>(bw, hasL) & mask0;
 				if (W == 2 && k > 32) f1 = rec_ext<W>(bw, hasL + 32) & mask1;
-				uint64_t r0, r1;
 				revcomp<W>(f0, f1, k, r0, r1);
-				uint32_t prev = hasL ? rec_base<W>(bw, 0) : 0;
-				bool prev_valid = hasL;
-				for (uint32_t i = 0; i < len; ++i) {
-					const bool has_next = (i + 1 < len) || hasR;
-					const uint32_t nb = has_next ? rec_base<W>(bw, hasL + i + (uint32_t)k) : 0;
-					const bool use_rc = kmer_less<W>(r0, r1, f0, f1);
-					uint32_t em = 0;
-					if (prev_valid) em |= use_rc ? (1u << (7 - prev)) : (1u << prev);
-					if (has_next) em |= use_rc ? (1u << (3 - nb)) : (1u << (4 + nb));
-					uint64_t i0, i1;
-					to_internal<W>(use_rc ? r0 : f0, use_rc ? r1 : f1, i0, i1);
-					if (!lds_upsert<W>(s_t, &s_fill, i0, i1, stamp0 + i, em)) {
-						// LDS table full: this occurrence goes to the log on its own
-						unsigned long long g = atomicAdd(&counters[PC_LOG_CURSOR], 1ull);
-						if (g < log_cap) {
-							Slot e;
-							e.k0 = i0;
-							e.k1 = (W == 2) ? i1 : EMPTY;
-							e.stamp = stamp0 + i;
-							e.meta = 1ull | ((uint64_t)em << PEND_SHIFT);
-							log[g] = e;
-						} else {
-							atomicAdd(&counters[PC_LOG_OVF], 1ull);
-						}
-						atomicAdd(&counters[PC_LDS_SPILL], 1ull);
+				prev = hasL ? (uint32_t)bw[0] & 3u : 0;
+				prev_valid = hasL;
+				if (W == 1) upcoming = rec_ext<W>(bw, hasL + (uint32_t)k);  // the bases after the first k-mer (<= 18 are used)
+				atomicMax(&R.rmax, len);
+				atomicAdd(&R.rsum, len);
+			}
+			wave_sync();
+			const uint32_t rmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)R.rmax);
+			const bool checked = (uint32_t)__builtin_amdgcn_readfirstlane((int)(T.fill + R.rsum)) > AGG_LIMIT;  // else no overfill possible
+			auto step = [&](uint32_t i) {
+				const bool has_next = (i + 1 < len) || hasR;
+				uint32_t nb;
+				if (W == 1) {
+					nb = (uint32_t)upcoming & 3u;
+					upcoming >>= 2;
+				} else {
+					nb = rec_base<W>(bw, hasL + i + (uint32_t)k);
+				}
+				const bool use_rc = kmer_less<W>(r0, r1, f0, f1);
+				uint32_t em = 0;
+				if (prev_valid) em = 1u << (use_rc ? 7u - prev : prev);
+				if (has_next) em |= 1u << (use_rc ? 3u - nb : 4u + nb);
+				uint64_t i0, i1;
+				to_internal<W>(use_rc ? r0 : f0, use_rc ? r1 : f1, i0, i1);
+				if (!lds_upsert<W>(T, i0, i1, stamp0 + i, em, weight)) {
+					// LDS table full: this k-mer goes to the log on its own
+					unsigned long long g = atomicAdd(&counters[PC_LOG_CURSOR], 1ull);
+					if (g < log_cap) {
+						Slot en;
+						en.k0 = i0;
+						en.k1 = (W == 2) ? i1 : EMPTY;
+						en.stamp = stamp0 + i;
+						en.meta = (uint64_t)weight | ((uint64_t)em << PEND_SHIFT);
+						log[g] = en;
+					} else {
+						atomicAdd(&counters[PC_LOG_OVF], 1ull);
 					}
-					// roll to the next k-mer
-					prev = (uint32_t)f0 & 3u;
-					prev_valid = true;
-					if (i + 1 < len) {
-						if (W == 1) {
-							f0 = (f0 >> 2) | ((uint64_t)nb << (2 * (k - 1)));
-							r0 = ((r0 << 2) | (uint64_t)(3u - nb)) & mask0;
-						} else {
-							f0 = (f0 >> 2) | (f1 << 62);
-							if (k > 32) {
-								f1 = (f1 >> 2) | ((uint64_t)nb << (2 * (k - 1) - 64));
-								r1 = ((r1 << 2) | (r0 >> 62)) & mask1;
-								r0 = (r0 << 2) | (uint64_t)(3u - nb);
-							} else {
-								f0 |= (uint64_t)nb << (2 * (k - 1));
-								r0 = ((r0 << 2) | (uint64_t)(3u - nb)) & mask0;
-							}
-						}
+					atomicAdd(&counters[PC_LDS_SPILL], 1ull);
+				}
+				// roll to the next k-mer
+				prev = (uint32_t)f0 & 3u;
+				prev_valid = 1;
+				if (W == 1) {
+					f0 = (f0 >> 2) | ((uint64_t)nb << (2 * (k - 1)));
+					r0 = ((r0 << 2) | (uint64_t)(3u - nb)) & mask0;
+				} else {
+					f0 = (f0 >> 2) | (f1 << 62);
+					if (k > 32) {
+						f1 = (f1 >> 2) | ((uint64_t)nb << (2 * (k - 1) - 64));
+						r1 = ((r1 << 2) | (r0 >> 62)) & mask1;
+						r0 = (r0 << 2) | (uint64_t)(3u - nb);
+					} else {
+						f0 |= (uint64_t)nb << (2 * (k - 1));
+						r0 = ((r0 << 2) | (uint64_t)(3u - nb)) & mask0;
 					}
 				}
+			};
+			if (!checked) {
+				for (uint32_t i = 0; i < len; ++i) step(i);
+				wave_sync();
+			} else {
+				for (uint32_t i = 0; i < rmax; ++i) {
+					if (i < len) step(i);
+					wave_sync();
+					if ((uint32_t)__builtin_amdgcn_readfirstlane((int)T.fill) > AGG_FLUSH) flush();
+				}
 			}
-			__syncthreads();
-			if (s_fill > AGG_FLUSH) flush();
 		}
+		if (lane == 0) R.fill = 0;
+		wave_sync();
+	};
+
+	for (uint32_t i = lane; i < AGG_SLOTS; i += 64) {
+		T.k0[i] = EMPTY;
+		if (W == 2) T.k1[i] = EMPTY;
+		T.stamp[i] = INF_STAMP;
+		T.cnt[i] = 0;
+		T.edges[i] = 0;
+	}
+	for (uint32_t i = lane; i < RT_SLOTS; i += 64) {
+		R.fp[i] = 0;
+		R.cnt[i] = 0;
+		R.stamp[i] = INF_STAMP;
+	}
+	if (lane == 0) {
+		T.fill = 0;
+		R.fill = 0;
+	}
+	wave_sync();
+
+	const uint32_t stride = gridDim.x * AGG_WAVES;
+	uint32_t b = blockIdx.x * AGG_WAVES + wave;
+	uint64_t cb = 0, ce = 0;
+	if (b < nbuckets) {
+		cb = bucket_begin[b];
+		ce = bucket_begin[b + 1];
+	}
+	Rec<W> nxt;
+#pragma unroll
+	for (int i = 0; i <= NB; ++i) nxt.w[i] = 0;
+	bool prefetched = false;  // nxt holds records [cb, cb+64) of the current bucket
+	while (b < nbuckets) {
+		const uint32_t b2 = b + stride;  // the bucket after this one: its bounds are fetched now, used at the last round
+		uint64_t nb_begin = 0, nb_end = 0;
+		if (b2 < nbuckets) {
+			nb_begin = bucket_begin[b2];
+			nb_end = bucket_begin[b2 + 1];
+		}
+		if (!prefetched && cb + lane < ce) nxt = recs[cb + lane];
+		prefetched = false;
+		for (uint64_t base = cb; base < ce; base += 64) {
+			const Rec<W> rec = nxt;
+			bool pending = base + lane < ce;
+			if (base + 64 < ce) {
+				if (base + 64 + lane < ce) nxt = recs[base + 64 + lane];
+			} else {
+				if (nb_begin + lane < nb_end) nxt = recs[nb_begin + lane];
+				prefetched = true;
+			}
+			uint64_t bw[NB], stamp0 = 0;
+			unsigned long long fp = 0;
+			uint32_t tag = 0, sl = 0;
+			{
+				const uint64_t hdr = rec.w[NB];
+				tag = (uint32_t)(hdr >> 16) & 0x7FFFu;
+				stamp0 = ((hdr >> 31) << 16) | ((uint32_t)hdr & 0xFFFFu);
+				uint64_t h = (uint64_t)tag * 0x9E3779B97F4A7C15ull;
+#pragma unroll
+				for (int i = 0; i < NB; ++i) {
+					bw[i] = rec.w[i];
+					h = (h ^ bw[i]) * 0xC2B2AE3D27D4EB4Full;
+					h ^= h >> 29;
+				}
+				h *= 0xBF58476D1CE4E5B9ull;
+				h ^= h >> 32;
+				fp = h | 1ull;
+				sl = (uint32_t)(h >> 40) & (RT_SLOTS - 1);
+			}
+			do {
+				bool owner = false;
+				if (pending) {
+					for (;;) {  // ends: the table is never more than 3/4 full
+						unsigned long long cur = R.fp[sl];
+						if (cur == 0) {
+							cur = atomicCAS(&R.fp[sl], 0ull, fp);
+							if (cur == 0) {
+								owner = true;
+								break;
+							}
+						}
+						if (cur == fp) break;
+						sl = (sl + 1) & (RT_SLOTS - 1);
+					}
+					if (owner) {
+#pragma unroll
+						for (int i = 0; i < NB; ++i) R.w[i][sl] = bw[i];
+						R.tag[sl] = tag;
+						R.list[atomicAdd(&R.fill, 1u)] = (uint16_t)sl;
+					}
+				}
+				wave_sync();
+				if (pending) {
+					bool same = true;
+					if (!owner) {
+						same = (R.tag[sl] == tag);
+#pragma unroll
+						for (int i = 0; i < NB; ++i) same = same && (R.w[i][sl] == bw[i]);
+					}
+					if (same) {
+						atomicAdd(&R.cnt[sl], 1u);
+						atomicMin(reinterpret_cast<unsigned long long *>(&R.stamp[sl]), (unsigned long long)stamp0);
+						pending = false;
+					} else {
+						sl = (sl + 1) & (RT_SLOTS - 1);  // same fingerprint, different record: keep probing
+					}
+				}
+				wave_sync();
+			} while (__any(pending));
+			if ((uint32_t)__builtin_amdgcn_readfirstlane((int)R.fill) > RT_FLUSH) expand();
+		}
+		expand();
 		flush();
+		b = b2;
+		cb = nb_begin;
+		ce = nb_end;
 	}
 	// close the last chunk
-	__syncthreads();
-	{
-		const unsigned long long ob = s_chunk_base;
-		if (ob != NO_CHUNK)
-			for (uint32_t i = s_chunk_used + threadIdx.x; i < LOG_CHUNK; i += 256)
-				if (ob + i < log_cap) log[ob + i].k0 = EMPTY;
-	}
+	if (chunk_base != NO_CHUNK)
+		for (uint32_t i = chunk_used + lane; i < LOG_CHUNK; i += 64)
+			if (chunk_base + i < log_cap) log[chunk_base + i].k0 = EMPTY;
 }
 
 }  // namespace rg
