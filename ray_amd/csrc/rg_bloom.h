@@ -22,7 +22,7 @@ namespace rg {
 static constexpr int REGION_BITS_LOG2 = 17;
 static constexpr uint32_t REGION_BITS = 1u << REGION_BITS_LOG2;
 static constexpr uint32_t REGION_WORDS = REGION_BITS / 32;  // 4096 words per bitmap
-static constexpr uint32_t REGION_MULTI_CAP = 6144;          // contested bits a region can rank (48 KB of stamps)
+static constexpr uint32_t REGION_MULTI_CAP = 4096;          // contested bits a region can rank (32 KB of stamps)
 static constexpr uint64_t ITEM_INVALID = ~0ull;
 static constexpr uint32_t ITEM_CHUNK_KEYS = 512;  // keys (x8 items) a wavefront claims at a time
 static constexpr int SCATTER64_TILE = 4096;
@@ -187,6 +187,10 @@ __global__ __launch_bounds__(256) void k_scatter64(const unsigned long long *__r
 }
 
 // One workgroup per Bloom region at a time.  lost[slot >> 2] holds four 8-bit counters.
+// The items of a region are loaded once, REGION_PER per thread with independent loads (the loop over
+// them is what the kernel waits for), and stay in registers for the three passes; a region with more
+// than 512*REGION_PER items takes further rounds that read again.
+static constexpr int REGION_PER = 32;
 template <int W>
 __global__ __launch_bounds__(512) void k_bloom_region(const unsigned long long *__restrict__ items,
                                                       const unsigned long long *__restrict__ region_begin, uint32_t nregions,
@@ -194,25 +198,42 @@ __global__ __launch_bounds__(512) void k_bloom_region(const unsigned long long *
                                                       unsigned long long *__restrict__ counters, int c_setbits) {
 	__shared__ uint32_t s_b1[REGION_WORDS];       // bit touched
 	__shared__ uint32_t s_b2[REGION_WORDS];       // bit touched more than once
-	__shared__ uint32_t s_pre[REGION_WORDS];      // exclusive prefix of popc(s_b2): rank of a contested bit
+	__shared__ uint16_t s_pre[REGION_WORDS];      // exclusive prefix of popc(s_b2): rank of a contested bit
 	__shared__ unsigned long long s_min[REGION_MULTI_CAP];
-	__shared__ uint32_t s_scan[512];
+	__shared__ uint32_t s_wsum[8];
 	__shared__ uint32_t s_setbits;
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	uint32_t setbits_total = 0;
 	for (uint32_t r = blockIdx.x; r < nregions; r += gridDim.x) {
 		const uint64_t begin = region_begin[r], end = region_begin[r + 1];
 		if (begin == end) continue;  // uniform
+		const bool one_round = end - begin <= 512ull * REGION_PER;
+		unsigned long long mine[REGION_PER];
+		if (one_round) {
+#pragma unroll
+			for (int j = 0; j < REGION_PER; ++j) {
+				const uint64_t i = begin + threadIdx.x + 512ull * j;
+				mine[j] = (i < end) ? items[i] : ITEM_INVALID;
+			}
+		}
 		for (uint32_t i = threadIdx.x; i < REGION_WORDS; i += 512) {
 			s_b1[i] = 0;
 			s_b2[i] = 0;
 		}
 		__syncthreads();
 		// pass 1: touched / touched again
-		for (uint64_t i = begin + threadIdx.x; i < end; i += 512) {
-			const uint32_t b = (uint32_t)(items[i] >> 31) & (REGION_BITS - 1);
+		auto touch = [&](unsigned long long it) {
+			const uint32_t b = (uint32_t)(it >> 31) & (REGION_BITS - 1);
 			const uint32_t m = 1u << (b & 31u);
 			const uint32_t old = atomicOr(&s_b1[b >> 5], m);
 			if (old & m) atomicOr(&s_b2[b >> 5], m);
+		};
+		if (one_round) {
+#pragma unroll
+			for (int j = 0; j < REGION_PER; ++j)
+				if (mine[j] != ITEM_INVALID) touch(mine[j]);
+		} else {
+			for (uint64_t i = begin + threadIdx.x; i < end; i += 512) touch(items[i]);
 		}
 		__syncthreads();
 		// rank the contested bits: exclusive prefix over the 4096 words (8 per thread)
@@ -223,50 +244,104 @@ __global__ __launch_bounds__(512) void k_bloom_region(const unsigned long long *
 			sum += local[j];
 			set1 += __popc(s_b1[threadIdx.x * 8 + j]);
 		}
-		s_scan[threadIdx.x] = sum;
-		__syncthreads();
-		for (int d = 1; d < 512; d <<= 1) {
-			uint32_t t = (threadIdx.x >= (uint32_t)d) ? s_scan[threadIdx.x - d] : 0;
-			__syncthreads();
-			s_scan[threadIdx.x] += t;
-			__syncthreads();
+		uint32_t incl = sum;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			const uint32_t o = __shfl_up(incl, d);
+			if (lane >= (uint32_t)d) incl += o;
 		}
-		uint32_t run = s_scan[threadIdx.x] - sum;
+		if (lane == 63) s_wsum[wave] = incl;
+		__syncthreads();
+		uint32_t run = incl - sum, nmulti = 0;
+#pragma unroll
+		for (uint32_t q = 0; q < 8; ++q) {
+			const uint32_t t = s_wsum[q];
+			if (q < wave) run += t;
+			nmulti += t;
+		}
+		const bool fits = nmulti <= REGION_MULTI_CAP;  // uniform
 #pragma unroll
 		for (int j = 0; j < 8; ++j) {
-			s_pre[threadIdx.x * 8 + j] = run;
+			s_pre[threadIdx.x * 8 + j] = (uint16_t)run;  // only used when it fits (< 65536)
 			run += local[j];
 		}
-		const uint32_t nmulti = s_scan[511];
 		setbits_total += set1;
-		const bool fits = nmulti <= REGION_MULTI_CAP;  // uniform
 		if (!fits && threadIdx.x == 0) atomicAdd(&counters[BC_REGION_OVF], 1ull);
 		for (uint32_t i = threadIdx.x; i < nmulti && i < REGION_MULTI_CAP; i += 512) s_min[i] = INF_STAMP;
 		__syncthreads();
 		if (fits && nmulti) {
-			// pass 2: earliest toucher of every contested bit
-			for (uint64_t i = begin + threadIdx.x; i < end; i += 512) {
-				const unsigned long long it = items[i];
+			// pass 2: earliest toucher of every contested bit; pass 3: every later toucher loses that bit check
+			auto contested_rank = [&](unsigned long long it, uint32_t &rank) -> bool {
 				const uint32_t b = (uint32_t)(it >> 31) & (REGION_BITS - 1);
 				const uint32_t m = 1u << (b & 31u);
 				const uint32_t w2 = s_b2[b >> 5];
-				if (w2 & m) {
-					const uint32_t rank = s_pre[b >> 5] + __popc(w2 & (m - 1));
-					const unsigned long long stamp = tab[it & 0x7FFFFFFFull].stamp;
-					atomicMin(&s_min[rank], stamp);
+				rank = (uint32_t)s_pre[b >> 5] + __popc(w2 & (m - 1));
+				return (w2 & m) != 0;
+			};
+			if (one_round) {
+				// the stamps of the contested items: gathered once, kept with a one-bit-per-item mask
+				uint32_t cmask = 0;
+				unsigned long long st[4];
+				uint32_t rk[4], sl[4], nc = 0;
+#pragma unroll
+				for (int j = 0; j < REGION_PER; ++j) {
+					uint32_t rank;
+					if (mine[j] != ITEM_INVALID && contested_rank(mine[j], rank)) {
+						cmask |= 1u << j;
+#pragma unroll
+						for (uint32_t q = 0; q < 4; ++q)
+							if (q == nc) {
+								rk[q] = rank;
+								sl[q] = (uint32_t)(mine[j] & 0x7FFFFFFFull);
+							}
+						nc++;
+					}
 				}
-			}
-			__syncthreads();
-			// pass 3: every later toucher loses that bit check
-			for (uint64_t i = begin + threadIdx.x; i < end; i += 512) {
-				const unsigned long long it = items[i];
-				const uint32_t b = (uint32_t)(it >> 31) & (REGION_BITS - 1);
-				const uint32_t m = 1u << (b & 31u);
-				const uint32_t w2 = s_b2[b >> 5];
-				if (w2 & m) {
-					const uint32_t rank = s_pre[b >> 5] + __popc(w2 & (m - 1));
-					const uint64_t slot = it & 0x7FFFFFFFull;
-					if (tab[slot].stamp > s_min[rank]) atomicAdd(&lost[slot >> 2], 1u << ((slot & 3u) * 8u));
+				if (nc <= 4) {
+#pragma unroll
+					for (uint32_t q = 0; q < 4; ++q)
+						if (q < nc) st[q] = tab[sl[q]].stamp;
+#pragma unroll
+					for (uint32_t q = 0; q < 4; ++q)
+						if (q < nc) atomicMin(&s_min[rk[q]], st[q]);
+				} else {
+#pragma unroll
+					for (int j = 0; j < REGION_PER; ++j)
+						if (cmask & (1u << j)) {
+							uint32_t rank;
+							contested_rank(mine[j], rank);
+							atomicMin(&s_min[rank], (unsigned long long)tab[mine[j] & 0x7FFFFFFFull].stamp);
+						}
+				}
+				__syncthreads();
+				if (nc <= 4) {
+#pragma unroll
+					for (uint32_t q = 0; q < 4; ++q)
+						if (q < nc && st[q] > s_min[rk[q]]) atomicAdd(&lost[sl[q] >> 2], 1u << ((sl[q] & 3u) * 8u));
+				} else {
+#pragma unroll
+					for (int j = 0; j < REGION_PER; ++j)
+						if (cmask & (1u << j)) {
+							uint32_t rank;
+							contested_rank(mine[j], rank);
+							const uint64_t slot = mine[j] & 0x7FFFFFFFull;
+							if (tab[slot].stamp > s_min[rank]) atomicAdd(&lost[slot >> 2], 1u << ((slot & 3u) * 8u));
+						}
+				}
+			} else {
+				for (uint64_t i = begin + threadIdx.x; i < end; i += 512) {
+					const unsigned long long it = items[i];
+					uint32_t rank;
+					if (contested_rank(it, rank)) atomicMin(&s_min[rank], (unsigned long long)tab[it & 0x7FFFFFFFull].stamp);
+				}
+				__syncthreads();
+				for (uint64_t i = begin + threadIdx.x; i < end; i += 512) {
+					const unsigned long long it = items[i];
+					uint32_t rank;
+					if (contested_rank(it, rank)) {
+						const uint64_t slot = it & 0x7FFFFFFFull;
+						if (tab[slot].stamp > s_min[rank]) atomicAdd(&lost[slot >> 2], 1u << ((slot & 3u) * 8u));
+					}
 				}
 			}
 		}
