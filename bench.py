@@ -19,6 +19,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PMC_SUMMARY = "profiles/r01_v3_c2_pmc.json"
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
@@ -188,12 +189,17 @@ def main():
             "k_level_hist": max(0, st["partition_levels"] - 1) * recs0 * rec_bytes,
             "k_aggregate": recs0 * rec_bytes + st["log_entries"] * 32,       # records in, entries out
             "k_merge": st["log_entries"] * 32 + cand0 * 32,                  # entries in, slots written
+            "k_bloom_items": st["table_slots"] * 32 + cand0 * 64,            # table scan in, 8 items of 8 B per key out
+            "k_scatter64": 2 * cand0 * 64,                                    # items in + out, per level (x launches below)
+            "k_bloom_region": cand0 * 64,                                     # items in (contested stamps are extra)
             "k_bloom_touch": cand0 * (32 + 8 * 8),                           # slot + 8 stamp words
             "k_admit": cand0 * (32 + 8 + 8),                                 # slot + >= 1 stamp word + coverage write
             "bloom_stamp_fill": st["bloom_bits"] * 8,
             "k_histogram": st["table_slots"] * 32,
             "k_publish_edges": st["table_slots"] * 32,
         }
+        if "k_scatter64" in kprof:
+            alg_bytes["k_scatter64"] *= kprof["k_scatter64"][1] / args.steps
         per_kernel = {name: {"ms_per_step": ms / args.steps, "launches_per_step": n / args.steps,
                              "algorithmic_GBps": (alg_bytes[name] / (ms / args.steps / 1e3) / 1e9) if name in alg_bytes and ms else None}
                       for name, (ms, n) in kprof.items()}
@@ -204,6 +210,20 @@ def main():
         sweep_launches = kprof[dom][1] if dom else 0
         bytes_per_occ = (alg_bytes[dom] / occ0) if dom and occ0 else None
         pass1_bytes_per_occ = L / (4.0 * n_per_read) + 8 + Kb + 8         # stream + Bloom + table
+        # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+        # (tools/profile_c2.sh; FETCH_SIZE and WRITE_SIZE in separate runs).  FETCH_SIZE is doubled as
+        # MI355X_MICROARCH.md prescribes for gfx950 (checked here on k_scatter / k_level_hist / k_init_table,
+        # whose byte counts are known exactly).
+        traffic = None
+        try:
+            if args.workload.startswith("C2") and args.scale == 1.0 and world == 1 and dom:
+                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), PMC_SUMMARY)) as fh:
+                    pm = json.load(fh).get(dom)
+                if pm and pm.get("launches"):
+                    traffic = (2.0 * pm.get("FETCH_SIZE_bytes", 0.0) + pm.get("WRITE_SIZE_bytes", 0.0)) / pm["launches"]
+        except (OSError, ValueError):
+            traffic = None
+        launches_dom = (kprof[dom][1] / args.steps) if dom else 0
         out = {
             "metric": "distinct k-mers inserted/sec (whole node)",
             "value": stored / per_step,
@@ -218,7 +238,9 @@ def main():
             "occurrences_per_s": occ / per_step,
             "kmer_occurrences": occ, "distinct_candidates": cand, "vertices_stored": stored,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                         "traffic_unit": "bytes per launch (rocprofv3 PMC, %s)" % PMC_SUMMARY,
+                         "algorithmic_bytes_per_launch": (alg_bytes[dom] / launches_dom) if dom in alg_bytes and launches_dom else None,
                          "kernel": dom, "bytes_per_occurrence": bytes_per_occ,
                          "kernel_ms_per_step": kernel_s * 1e3 if sweep_ms else None,
                          "launches_per_step": sweep_launches / args.steps},

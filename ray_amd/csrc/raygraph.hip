@@ -656,6 +656,9 @@ struct rg_handle {
 	// optional per-kernel timing with HIP events on the launch stream (rg_set_profiling)
 	bool profiling = false;
 	std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof;
+	// rg_histogram is called twice by every caller (size query, then fill): the table is scanned once
+	bool hist_valid = false;
+	std::vector<std::pair<uint32_t, uint64_t>> hist_cache;  // (coverage, stored pairs)
 };
 
 // brackets the launches issued during its lifetime with two HIP events on the handle's stream
@@ -1242,6 +1245,7 @@ int rg_add_reads_device(rg_handle *h, const void *d_packed, uint64_t packed_byte
 }
 
 int rg_count_local(rg_handle *h) {
+	if (h) h->hist_valid = false;
 	if (!h) return RG_ERR_ARG;
 	if (h->phase != PH_CREATED) return fail(h, RG_ERR_STATE, "rg_count_local called twice");
 	HIP_TRY(h, hipSetDevice(h->cfg.device));
@@ -1371,6 +1375,7 @@ int rg_export_owner_buckets(rg_handle *h, void *d_out, uint64_t capacity_entries
 }
 
 int rg_merge_entries(rg_handle *h, const void *d_entries, uint64_t n_entries) {
+	if (h) h->hist_valid = false;
 	if (!h) return RG_ERR_ARG;
 	if (h->phase != PH_COUNTED_LOCAL && h->phase != PH_MERGING) return fail(h, RG_ERR_STATE, "rg_merge_entries needs rg_count_local first");
 	if (h->cfg.size == 1) return fail(h, RG_ERR_STATE, "rg_merge_entries is for size > 1 (the local table is already the partition)");
@@ -1393,6 +1398,7 @@ int rg_merge_entries(rg_handle *h, const void *d_entries, uint64_t n_entries) {
 }
 
 int rg_resolve_admission(rg_handle *h, uint64_t local_reads_for_bloom) {
+	if (h) h->hist_valid = false;
 	if (!h) return RG_ERR_ARG;
 	if (h->cfg.size == 1) {
 		if (h->phase != PH_COUNTED_LOCAL) return fail(h, RG_ERR_STATE, "rg_resolve_admission needs rg_count_local first");
@@ -1487,52 +1493,70 @@ int rg_histogram(rg_handle *h, uint32_t *coverage, uint64_t *count, uint64_t cap
 	if (!h || !n) return RG_ERR_ARG;
 	if (h->phase < PH_RESOLVED) return fail(h, RG_ERR_STATE, "rg_histogram needs the k-mer count first");
 	HIP_TRY(h, hipSetDevice(h->cfg.device));
-	unsigned long long *dense = nullptr;
-	uint32_t *ovf = nullptr;
-	HIP_TRY(h, pool_alloc(h->cfg.device, (void **)&dense, HIST_DENSE * sizeof(unsigned long long)));
-	HIP_TRY(h, pool_alloc(h->cfg.device, (void **)&ovf, HIST_OVF_CAP * sizeof(uint32_t)));
-	HIP_TRY(h, hipMemsetAsync(dense, 0, HIST_DENSE * sizeof(unsigned long long), h->stream));
-	HIP_TRY(h, hipMemsetAsync(h->d_counters + C_OVF, 0, sizeof(unsigned long long), h->stream));
-	ProfScope ps(h, "k_histogram");
-	hipLaunchKernelGGL(k_histogram, dim3(grid_for(h->tab.cap)), dim3(BLOCK), 0, h->stream, h->tab.slots, h->tab.cap, dense, ovf, h->d_counters);
-	HIP_TRY(h, hipGetLastError());
-	std::vector<unsigned long long> hd(HIST_DENSE);
-	HIP_TRY(h, hipMemcpyAsync(hd.data(), dense, HIST_DENSE * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-	int rc = sync_counters(h);
-	if (rc) {
-		pool_free(h->cfg.device, dense);
-		pool_free(h->cfg.device, ovf);
-		return rc;
+	if (!h->hist_valid) {
+		unsigned long long *dense = nullptr;
+		uint32_t *ovf = nullptr;
+		HIP_TRY(h, pool_alloc(h->cfg.device, (void **)&dense, HIST_DENSE * sizeof(unsigned long long)));
+		if (pool_alloc(h->cfg.device, (void **)&ovf, HIST_OVF_CAP * sizeof(uint32_t)) != hipSuccess) {
+			pool_free(h->cfg.device, dense);
+			return fail(h, RG_ERR_NOMEM, "rg_histogram: out of device memory");
+		}
+		auto release = [&]() {
+			pool_free(h->cfg.device, dense);
+			pool_free(h->cfg.device, ovf);
+		};
+		std::vector<unsigned long long> hd(HIST_DENSE);
+		hipError_t e = hipMemsetAsync(dense, 0, HIST_DENSE * sizeof(unsigned long long), h->stream);
+		if (e == hipSuccess) e = hipMemsetAsync(h->d_counters + C_OVF, 0, sizeof(unsigned long long), h->stream);
+		if (e == hipSuccess) {
+			ProfScope ps(h, "k_histogram");
+			hipLaunchKernelGGL(k_histogram, dim3(grid_for(h->tab.cap)), dim3(BLOCK), 0, h->stream, h->tab.slots, h->tab.cap, dense, ovf, h->d_counters);
+			e = hipGetLastError();
+		}
+		if (e == hipSuccess) e = hipMemcpyAsync(hd.data(), dense, HIST_DENSE * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream);
+		if (e != hipSuccess) {
+			release();
+			return fail(h, RG_ERR_HIP, "rg_histogram: %s", hipGetErrorString(e));
+		}
+		int rc = sync_counters(h);
+		if (rc) {
+			release();
+			return rc;
+		}
+		uint64_t novf = h->h_counters[C_OVF];
+		std::vector<uint32_t> ho;
+		if (novf > HIST_OVF_CAP) {
+			release();
+			return fail(h, RG_ERR_CAPACITY, "more than %u vertices with coverage >= %u", HIST_OVF_CAP, HIST_DENSE);
+		}
+		if (novf) {
+			ho.resize(novf);
+			e = hipMemcpy(ho.data(), ovf, novf * sizeof(uint32_t), hipMemcpyDeviceToHost);
+			if (e != hipSuccess) {
+				release();
+				return fail(h, RG_ERR_HIP, "rg_histogram: %s", hipGetErrorString(e));
+			}
+			std::sort(ho.begin(), ho.end());
+		}
+		release();
+		h->hist_cache.clear();
+		for (uint32_t c = 0; c < HIST_DENSE; ++c)
+			if (hd[c]) h->hist_cache.emplace_back(c, hd[c]);
+		for (size_t i = 0; i < ho.size();) {
+			size_t e2 = i;
+			while (e2 < ho.size() && ho[e2] == ho[i]) e2++;
+			h->hist_cache.emplace_back(ho[i], e2 - i);
+			i = e2;
+		}
+		h->hist_valid = true;
 	}
-	uint64_t novf = h->h_counters[C_OVF];
-	std::vector<uint32_t> ho;
-	if (novf > HIST_OVF_CAP) {
-		pool_free(h->cfg.device, dense);
-		pool_free(h->cfg.device, ovf);
-		return fail(h, RG_ERR_CAPACITY, "more than %u vertices with coverage >= %u", HIST_OVF_CAP, HIST_DENSE);
-	}
-	if (novf) {
-		ho.resize(novf);
-		HIP_TRY(h, hipMemcpy(ho.data(), ovf, novf * sizeof(uint32_t), hipMemcpyDeviceToHost));
-		std::sort(ho.begin(), ho.end());
-	}
-	pool_free(h->cfg.device, dense);
-	pool_free(h->cfg.device, ovf);
 	uint64_t m = 0;
-	auto emit = [&](uint32_t c, uint64_t pairs) {
+	for (const auto &cp : h->hist_cache) {
 		if (m < cap && coverage && count) {
-			coverage[m] = c;
-			count[m] = 2 * pairs;  // GridTableIterator visits the key and its reverse complement
+			coverage[m] = cp.first;
+			count[m] = 2 * cp.second;  // GridTableIterator visits the key and its reverse complement
 		}
 		m++;
-	};
-	for (uint32_t c = 0; c < HIST_DENSE; ++c)
-		if (hd[c]) emit(c, hd[c]);
-	for (size_t i = 0; i < ho.size();) {
-		size_t e = i;
-		while (e < ho.size() && ho[e] == ho[i]) e++;
-		emit(ho[i], e - i);
-		i = e;
 	}
 	*n = m;
 	return RG_OK;
