@@ -110,8 +110,21 @@ int rg_histogram(rg_handle *h, uint32_t *coverage, uint64_t *count, uint64_t cap
 int rg_add_edges(rg_handle *h);
 
 /* ---- next row: RAY_SLAVE_MODE_PURGE_NULL_EDGES (EdgePurger/EdgePurgerWorker.cpp:28-102) ------- */
-/* size == 1 only in this version: clears edge bits whose neighbour is not stored */
+/* size == 1: clears edge bits whose neighbour is not stored, in one call */
 int rg_purge_edges(rg_handle *h);
+/* size > 1: the same with one query exchange.  Replaces the per-edge RAY_MPI_TAG_REQUEST_VERTEX_COVERAGE
+ * round trips of EdgePurgerWorker.cpp:36-60,73-96 (served by MessageProcessor.cpp:1224-1256):
+ *   rg_purge_query_counts    counts[r] = neighbour keys this rank must ask owner r about
+ *   rg_purge_export_queries  the keys, grouped by owner in rank order, kmer_words*8 bytes each (opaque)
+ *   -- all-to-all(v) of the keys; every rank answers what it received: --
+ *   rg_purge_answer          answers[i] = 1 if key i is stored here (coverage != 0), else 0
+ *   -- all-to-all(v) of the answers back, same order as the exported keys --
+ *   rg_purge_apply           deletes the edges whose neighbour's coverage is 0 (EdgePurgerWorker.cpp:54-56,91-93)
+ * All pointers are device pointers except counts.  Works for size == 1 too (everything stays local). */
+int rg_purge_query_counts(rg_handle *h, uint64_t *counts);
+int rg_purge_export_queries(rg_handle *h, void *d_queries, uint64_t cap_queries);
+int rg_purge_answer(rg_handle *h, const void *d_queries, uint64_t n, uint8_t *d_answers);
+int rg_purge_apply(rg_handle *h, const uint8_t *d_answers, uint64_t n);
 
 /* ---- the store: GridTable / Vertex ---------------------------------------------------------- */
 /* GridTable::size (GridTable.cpp:80-82): 2 per stored pair */

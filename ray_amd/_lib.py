@@ -30,7 +30,8 @@ class RgStats(C.Structure):
 # every symbol include/raygraph.h declares
 SYMBOLS = ["rg_create", "rg_destroy", "rg_last_error", "rg_add_reads", "rg_add_reads_device", "rg_count_kmers",
            "rg_count_local", "rg_owner_counts", "rg_export_owner_buckets", "rg_merge_entries",
-           "rg_resolve_admission", "rg_histogram", "rg_add_edges", "rg_purge_edges", "rg_size", "rg_export",
+           "rg_resolve_admission", "rg_histogram", "rg_add_edges", "rg_purge_edges", "rg_purge_query_counts",
+           "rg_purge_export_queries", "rg_purge_answer", "rg_purge_apply", "rg_size", "rg_export",
            "rg_find", "rg_degree_distribution", "rg_get_stats", "rg_set_profiling", "rg_get_kernel_profile", "rg_release_cached_memory", "rg_coverage_distribution", "rg_pack_read",
            "rg_version"]
 
@@ -71,6 +72,10 @@ def load():
         "rg_histogram": ([vp, u32p, u64p, u64, u64p], C.c_int),
         "rg_add_edges": ([vp], C.c_int),
         "rg_purge_edges": ([vp], C.c_int),
+        "rg_purge_query_counts": ([vp, u64p], C.c_int),
+        "rg_purge_export_queries": ([vp, vp, u64], C.c_int),
+        "rg_purge_answer": ([vp, vp, u64, vp], C.c_int),
+        "rg_purge_apply": ([vp, vp, u64], C.c_int),
         "rg_size": ([vp, u64p], C.c_int),
         "rg_export": ([vp, vp, u64, u64p], C.c_int),
         "rg_find": ([vp, u64p, u64, u32p, u8p], C.c_int),

@@ -450,6 +450,87 @@ __global__ __launch_bounds__(BLOCK) void k_purge(Slot *__restrict__ tab, uint64_
 	}
 }
 
+// ---- purge across ranks: the neighbour-existence queries of EdgePurgerWorker.cpp:36-44,73-81 in bulk ------
+// neighbour (in canonical internal form) named by edge bit `bit` of the stored key (K0,K1)
+template <int W>
+__device__ __forceinline__ void edge_neighbour(uint64_t K0, uint64_t K1, uint32_t bit, int k, uint64_t mask0, uint64_t mask1,
+                                               uint64_t &i0, uint64_t &i1) {
+	uint64_t n0, n1 = 0;
+	const uint64_t c = bit & 3u;
+	if (bit < 4) {  // parent: shift left one base, base c enters at position 0
+		n0 = ((K0 << 2) | c) & mask0;
+		if (W == 2) n1 = ((K1 << 2) | (K0 >> 62)) & mask1;
+	} else {  // child: shift right one base, base c enters at position k-1
+		n0 = K0 >> 2;
+		if (W == 2) {
+			n0 |= K1 << 62;
+			n1 = K1 >> 2;
+		}
+		const int pos = 2 * (k - 1);
+		if (pos < 64) n0 |= c << pos;
+		else n1 |= c << (pos - 64);
+	}
+	bool rc;
+	canonical_internal<W>(n0, n1, k, i0, i1, rc);
+}
+
+// WRITE == false: counts[owner] += queries; WRITE == true: keys/origin written at cursors[owner]++
+template <int W, bool WRITE>
+__global__ __launch_bounds__(BLOCK) void k_purge_queries(const Slot *__restrict__ tab, uint64_t cap, int k, uint32_t size,
+                                                         unsigned long long *__restrict__ counts_or_cursors,
+                                                         uint64_t *__restrict__ keys, uint64_t *__restrict__ origin) {
+	const uint64_t mask0 = (2 * k >= 64) ? ~0ull : ((1ull << (2 * k)) - 1);
+	const uint64_t mask1 = (k > 32) ? ((1ull << (2 * k - 64)) - 1) : 0ull;
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	for (; i < cap; i += stride) {
+		const Slot v = tab[i];
+		if (v.k0 == EMPTY || (v.meta & COUNT_MASK) == 0) continue;
+		const uint32_t e = (uint32_t)(v.meta >> PUB_SHIFT) & 0xFFu;
+		if (!e) continue;
+		uint64_t K0, K1;
+		from_internal<W>(v.k0, v.k1, K0, K1);
+		for (uint32_t bit = 0; bit < 8; ++bit) {
+			if (!(e & (1u << bit))) continue;
+			uint64_t i0, i1;
+			edge_neighbour<W>(K0, K1, bit, k, mask0, mask1, i0, i1);
+			uint64_t N0, N1;
+			from_internal<W>(i0, i1, N0, N1);
+			const uint32_t owner = (uint32_t)(hash1<W>(N0, N1) % (uint64_t)size);
+			const unsigned long long pos = atomicAdd(&counts_or_cursors[owner], 1ull);
+			if (WRITE) {
+				keys[pos * W] = i0;
+				if (W == 2) keys[pos * W + 1] = i1;
+				origin[pos] = (i << 3) | bit;
+			}
+		}
+	}
+}
+
+// the owner's side of RAY_MPI_TAG_REQUEST_VERTEX_COVERAGE (MessageProcessor.cpp:1224-1256): 1 = stored, 0 = not
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_purge_answer(const Slot *__restrict__ tab, uint64_t mask, const uint64_t *__restrict__ keys,
+                                                        uint64_t n, uint8_t *__restrict__ answers) {
+	uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	for (; q < n; q += stride) {
+		const Slot *p = lookup<W>(tab, mask, keys[q * W], W == 2 ? keys[q * W + 1] : 0);
+		answers[q] = (p && (p->meta & COUNT_MASK) != 0) ? 1 : 0;
+	}
+}
+
+// coverage 0: the edge is deleted (EdgePurgerWorker.cpp:54-56,91-93)
+__global__ __launch_bounds__(BLOCK) void k_purge_apply(Slot *__restrict__ tab, const uint64_t *__restrict__ origin,
+                                                       const uint8_t *__restrict__ answers, uint64_t n) {
+	uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	for (; q < n; q += stride)
+		if (!answers[q]) {
+			const uint64_t o = origin[q];
+			atomicAnd(reinterpret_cast<unsigned long long *>(&tab[o >> 3].meta), ~(1ull << (PUB_SHIFT + (o & 7u))));
+		}
+}
+
 // bulk GridTable::find + Vertex::getCoverage/getEdges
 template <int W>
 __global__ __launch_bounds__(BLOCK) void k_find(const Slot *__restrict__ tab, uint64_t cap, int k, const uint64_t *__restrict__ q,
@@ -657,6 +738,9 @@ struct rg_handle {
 	bool profiling = false;
 	std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof;
 	// rg_histogram is called twice by every caller (size query, then fill): the table is scanned once
+	uint64_t *d_purge_origin = nullptr;  // rg_purge_export_queries .. rg_purge_apply: (slot << 3 | edge bit) per query
+	uint64_t purge_total = 0;
+	std::vector<uint64_t> purge_counts;
 	bool hist_valid = false;
 	std::vector<std::pair<uint32_t, uint64_t>> hist_cache;  // (coverage, stored pairs)
 };
@@ -1181,6 +1265,7 @@ int rg_destroy(rg_handle *h) {
 	if (h->d_counters) pool_free(h->cfg.device, h->d_counters);
 	if (h->h_counters) (void)hipHostFree(h->h_counters);
 	if (h->d_owner) pool_free(h->cfg.device, h->d_owner);
+	if (h->d_purge_origin) pool_free(h->cfg.device, h->d_purge_origin);
 	if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
 	delete h;
 	return RG_OK;
@@ -1583,6 +1668,95 @@ int rg_purge_edges(rg_handle *h) {
 	else hipLaunchKernelGGL(k_purge<2>, dim3(grid_for(h->tab.cap)), dim3(BLOCK), 0, h->stream, h->tab.slots, h->tab.cap, h->cfg.k);
 	HIP_TRY(h, hipGetLastError());
 	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	h->phase = PH_PURGED;
+	return RG_OK;
+}
+
+int rg_purge_query_counts(rg_handle *h, uint64_t *counts) {
+	if (!h || !counts) return RG_ERR_ARG;
+	if (h->phase != PH_EDGES) return fail(h, RG_ERR_STATE, "rg_purge_query_counts needs rg_add_edges first");
+	HIP_TRY(h, hipSetDevice(h->cfg.device));
+	const uint32_t size = (uint32_t)h->cfg.size;
+	HIP_TRY(h, hipMemsetAsync(h->d_owner, 0, sizeof(unsigned long long) * 2 * size, h->stream));
+	{
+		ProfScope ps(h, "k_purge_queries");
+		if (h->W == 1) hipLaunchKernelGGL((k_purge_queries<1, false>), dim3(grid_for(h->tab.cap)), dim3(BLOCK), 0, h->stream, h->tab.slots, h->tab.cap, h->cfg.k, size, h->d_owner, (uint64_t *)nullptr, (uint64_t *)nullptr);
+		else hipLaunchKernelGGL((k_purge_queries<2, false>), dim3(grid_for(h->tab.cap)), dim3(BLOCK), 0, h->stream, h->tab.slots, h->tab.cap, h->cfg.k, size, h->d_owner, (uint64_t *)nullptr, (uint64_t *)nullptr);
+	}
+	HIP_TRY(h, hipGetLastError());
+	std::vector<unsigned long long> tmp(size);
+	HIP_TRY(h, hipMemcpyAsync(tmp.data(), h->d_owner, sizeof(unsigned long long) * size, hipMemcpyDeviceToHost, h->stream));
+	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	h->purge_counts.assign(tmp.begin(), tmp.end());
+	h->purge_total = 0;
+	for (uint32_t r = 0; r < size; ++r) {
+		counts[r] = tmp[r];
+		h->purge_total += tmp[r];
+	}
+	return RG_OK;
+}
+
+int rg_purge_export_queries(rg_handle *h, void *d_queries, uint64_t cap_queries) {
+	if (!h || !d_queries) return RG_ERR_ARG;
+	if (h->phase != PH_EDGES || h->purge_counts.size() != (size_t)h->cfg.size)
+		return fail(h, RG_ERR_STATE, "rg_purge_export_queries needs rg_purge_query_counts first");
+	if (cap_queries < h->purge_total) return fail(h, RG_ERR_CAPACITY, "query buffer holds %llu keys, %llu needed", (unsigned long long)cap_queries, (unsigned long long)h->purge_total);
+	HIP_TRY(h, hipSetDevice(h->cfg.device));
+	const uint32_t size = (uint32_t)h->cfg.size;
+	if (h->d_purge_origin) {
+		pool_free(h->cfg.device, h->d_purge_origin);
+		h->d_purge_origin = nullptr;
+	}
+	if (pool_alloc(h->cfg.device, (void **)&h->d_purge_origin, sizeof(uint64_t) * std::max<uint64_t>(1, h->purge_total)) != hipSuccess) {
+		(void)hipGetLastError();
+		return fail(h, RG_ERR_NOMEM, "rg_purge_export_queries: out of device memory");
+	}
+	std::vector<unsigned long long> cursors(size);
+	unsigned long long run = 0;
+	for (uint32_t r = 0; r < size; ++r) {
+		cursors[r] = run;
+		run += h->purge_counts[r];
+	}
+	HIP_TRY(h, hipMemcpyAsync(h->d_owner + size, cursors.data(), sizeof(unsigned long long) * size, hipMemcpyHostToDevice, h->stream));
+	{
+		ProfScope ps(h, "k_purge_queries");
+		if (h->W == 1) hipLaunchKernelGGL((k_purge_queries<1, true>), dim3(grid_for(h->tab.cap)), dim3(BLOCK), 0, h->stream, h->tab.slots, h->tab.cap, h->cfg.k, size, h->d_owner + size, (uint64_t *)d_queries, h->d_purge_origin);
+		else hipLaunchKernelGGL((k_purge_queries<2, true>), dim3(grid_for(h->tab.cap)), dim3(BLOCK), 0, h->stream, h->tab.slots, h->tab.cap, h->cfg.k, size, h->d_owner + size, (uint64_t *)d_queries, h->d_purge_origin);
+	}
+	HIP_TRY(h, hipGetLastError());
+	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	return RG_OK;
+}
+
+int rg_purge_answer(rg_handle *h, const void *d_queries, uint64_t n, uint8_t *d_answers) {
+	if (!h || (n && (!d_queries || !d_answers))) return RG_ERR_ARG;
+	if (h->phase < PH_EDGES) return fail(h, RG_ERR_STATE, "rg_purge_answer needs rg_add_edges first");
+	if (n == 0) return RG_OK;
+	HIP_TRY(h, hipSetDevice(h->cfg.device));
+	{
+		ProfScope ps(h, "k_purge_answer");
+		if (h->W == 1) hipLaunchKernelGGL(k_purge_answer<1>, dim3(grid_for(n)), dim3(BLOCK), 0, h->stream, h->tab.slots, h->tab.cap - 1, (const uint64_t *)d_queries, n, d_answers);
+		else hipLaunchKernelGGL(k_purge_answer<2>, dim3(grid_for(n)), dim3(BLOCK), 0, h->stream, h->tab.slots, h->tab.cap - 1, (const uint64_t *)d_queries, n, d_answers);
+	}
+	HIP_TRY(h, hipGetLastError());
+	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	return RG_OK;
+}
+
+int rg_purge_apply(rg_handle *h, const uint8_t *d_answers, uint64_t n) {
+	if (!h || (n && !d_answers)) return RG_ERR_ARG;
+	if (h->phase != PH_EDGES || !h->d_purge_origin) return fail(h, RG_ERR_STATE, "rg_purge_apply needs rg_purge_export_queries first");
+	if (n != h->purge_total) return fail(h, RG_ERR_ARG, "rg_purge_apply: %llu answers for %llu queries", (unsigned long long)n, (unsigned long long)h->purge_total);
+	HIP_TRY(h, hipSetDevice(h->cfg.device));
+	if (n) {
+		ProfScope ps(h, "k_purge_apply");
+		hipLaunchKernelGGL(k_purge_apply, dim3(grid_for(n)), dim3(BLOCK), 0, h->stream, h->tab.slots, h->d_purge_origin, d_answers, n);
+		HIP_TRY(h, hipGetLastError());
+	}
+	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	pool_free(h->cfg.device, h->d_purge_origin);
+	h->d_purge_origin = nullptr;
+	h->purge_counts.clear();
 	h->phase = PH_PURGED;
 	return RG_OK;
 }

@@ -58,6 +58,51 @@ def exchange_owner_buckets(engine, group=None, device="cuda"):
     return total, n_recv
 
 
+def _all_to_all_bytes(send, send_counts, unit, group, device, staged):
+    """all-to-all(v) of `unit`-byte items; returns (received bytes on `device`, received counts)"""
+    size = len(send_counts)
+    xdev = "cpu" if staged else device
+    sc = torch.tensor(send_counts, dtype=torch.int64, device=xdev)
+    rc = torch.empty(size, dtype=torch.int64, device=xdev)
+    dist.all_to_all_single(rc, sc, group=group)
+    recv_counts = [int(x) for x in rc.cpu().tolist()]
+    n_send, n_recv = sum(send_counts), sum(recv_counts)
+    recv = torch.empty(max(1, n_recv) * unit, dtype=torch.uint8, device=xdev)
+    src = send[: n_send * unit].cpu() if staged else send[: n_send * unit]
+    dist.all_to_all_single(recv[: n_recv * unit], src, output_split_sizes=[c * unit for c in recv_counts],
+                           input_split_sizes=[c * unit for c in send_counts], group=group)
+    if staged:
+        recv = recv.to(device)
+    return recv, recv_counts
+
+
+def purge_edges_distributed(engine, group=None, device="cuda"):
+    """RAY_SLAVE_MODE_PURGE_NULL_EDGES across ranks: one all-to-all of neighbour keys, one of one-byte
+    answers back (EdgePurgerWorker.cpp:28-102 asks one key per message, MessageProcessor.cpp:1224-1256
+    answers with the coverage).  Returns the number of queries this rank asked."""
+    if engine.size == 1:
+        engine.purge_edges()
+        return 0
+    unit = 8 * engine.kmer_words
+    counts = engine.purge_query_counts()
+    total = sum(counts)
+    keys = torch.empty(max(1, total) * unit, dtype=torch.uint8, device=device)
+    engine.purge_export_queries(keys.data_ptr(), max(1, total))
+    staged = _staged(group) and str(device) != "cpu"
+    asked, asked_counts = _all_to_all_bytes(keys, counts, unit, group, device, staged)
+    n_asked = sum(asked_counts)
+    answers = torch.zeros(max(1, n_asked), dtype=torch.uint8, device=device)
+    if str(device) != "cpu":
+        torch.cuda.current_stream().synchronize()
+    engine.purge_answer(asked.data_ptr(), n_asked, answers.data_ptr())
+    back, back_counts = _all_to_all_bytes(answers, asked_counts, 1, group, device, staged)
+    assert back_counts == counts
+    if str(device) != "cpu":
+        torch.cuda.current_stream().synchronize()
+    engine.purge_apply(back.data_ptr(), total)
+    return total
+
+
 HIST_DENSE = 65536
 
 

@@ -151,6 +151,21 @@ class GraphBuilder:
     def purge_edges(self):
         self._check(self._L.rg_purge_edges(self._h))
 
+    # -- purge across ranks (exchange.purge_edges_distributed drives these)
+    def purge_query_counts(self):
+        out = (C.c_uint64 * self.size)()
+        self._check(self._L.rg_purge_query_counts(self._h, out))
+        return [int(x) for x in out]
+
+    def purge_export_queries(self, device_ptr, capacity_queries):
+        self._check(self._L.rg_purge_export_queries(self._h, device_ptr, capacity_queries))
+
+    def purge_answer(self, queries_ptr, n, answers_ptr):
+        self._check(self._L.rg_purge_answer(self._h, queries_ptr, n, answers_ptr))
+
+    def purge_apply(self, answers_ptr, n):
+        self._check(self._L.rg_purge_apply(self._h, answers_ptr, n))
+
     # -- the store
     def size_(self):
         n = C.c_uint64()

@@ -166,6 +166,62 @@ class ModelEngine:
         self.set_bits = len(touch)
         self.final = final
 
+    # ---- purge across ranks (same surface as GraphBuilder.purge_*; host pointers) ----
+    @property
+    def kmer_words(self):
+        return self.W
+
+    def _neighbour(self, key, bit):
+        """canonical k-mer named by edge bit `bit` of stored key (bits 0-3 parents, 4-7 children)"""
+        k, c = self.k, bit & 3
+        K = key[0] | (key[1] << 64)
+        if bit < 4:
+            N = ((K << 2) | c) & ((1 << (2 * k)) - 1)
+        else:
+            N = (K >> 2) | (c << (2 * (k - 1)))
+        n = (N & M64, N >> 64)
+        rc = tuple(self.ro.complement_vertex(n, k))
+        return n if (n[0], n[1]) < (rc[0], rc[1]) or n == rc else rc
+
+    def purge_query_counts(self):
+        self._queries = [[] for _ in range(self.size)]   # per owner: (canonical neighbour, key, bit)
+        for key in sorted(self.final):
+            cov, em = self.final[key]
+            for bit in range(8):
+                if em >> bit & 1:
+                    nb = self._neighbour(key, bit)
+                    self._queries[self._owner(nb)].append((nb, key, bit))
+        return [len(q) for q in self._queries]
+
+    def purge_export_queries(self, ptr, capacity):
+        flat = [q for per in self._queries for q in per]
+        assert len(flat) <= capacity
+        out = np.zeros((len(flat), self.W), dtype=np.uint64)
+        for i, (nb, _, _) in enumerate(flat):
+            out[i] = to_internal(nb[0], nb[1], self.W)[: self.W]
+        if len(flat):
+            C.memmove(ptr, out.ctypes.data, out.nbytes)
+        self._flat = flat
+
+    def purge_answer(self, qptr, n, aptr):
+        if n == 0:
+            return
+        buf = (C.c_uint8 * (n * 8 * self.W)).from_address(qptr)
+        q = np.frombuffer(buf, dtype=np.uint64).reshape(n, self.W)
+        ans = np.zeros(n, dtype=np.uint8)
+        for i in range(n):
+            key = from_internal(int(q[i, 0]), int(q[i, 1]) if self.W == 2 else 0, self.W)
+            ans[i] = 1 if key in self.final else 0
+        C.memmove(aptr, ans.ctypes.data, n)
+
+    def purge_apply(self, aptr, n):
+        assert n == len(self._flat)
+        ans = np.frombuffer((C.c_uint8 * max(1, n)).from_address(aptr), dtype=np.uint8)[:n] if n else []
+        for a, (_, key, bit) in zip(ans, self._flat):
+            if not a:
+                cov, em = self.final[key]
+                self.final[key] = (cov, em & ~(1 << bit))
+
     def records(self, with_edges=True):
         dt = self.ro.record_dtype(self.W)
         out = np.zeros(len(self.final), dtype=dt)

@@ -17,7 +17,7 @@ def _worker(rank, world, port, k, bloom, out_dir):
     import torch.distributed as dist
     from model import ModelEngine
     from oracle import ray_oracle as ro
-    from ray_amd.exchange import exchange_owner_buckets, partition_reads, reduce_histogram
+    from ray_amd.exchange import exchange_owner_buckets, partition_reads, purge_edges_distributed, reduce_histogram
     from ray_amd.synth import make_reads_numpy
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -33,6 +33,9 @@ def _worker(rank, world, port, k, bloom, out_dir):
     e.resolve_admission(last - first)
     cov, cnt = reduce_histogram(*e.histogram(), device="cpu", size=world)
     np.save(os.path.join(out_dir, "rec%d.npy" % rank), e.records())
+    asked = purge_edges_distributed(e, device="cpu")   # RAY_SLAVE_MODE_PURGE_NULL_EDGES: key all-to-all, answers back
+    assert asked == sum(bin(int(em)).count("1") for em in np.load(os.path.join(out_dir, "rec%d.npy" % rank))["edges"])
+    np.save(os.path.join(out_dir, "purged%d.npy" % rank), e.records())
     if rank == 0:
         np.save(os.path.join(out_dir, "hist.npy"), np.stack([cov.astype(np.uint64), cnt]))
     dist.barrier()
@@ -51,6 +54,13 @@ def test_two_rank_exchange_over_gloo(oracle, tmp_path, k, bloom):
     for r in range(2):
         got = np.load(str(tmp_path / ("rec%d.npy" % r)))
         assert_records_equal(got, want["graph"].export(r), "rank %d" % r)
+    want["graph"].purge_edges()
+    changed = 0
+    for r in range(2):
+        got = np.load(str(tmp_path / ("purged%d.npy" % r)))
+        assert_records_equal(got, want["graph"].export(r), "rank %d after purge" % r)
+        changed += int((got["edges"] != np.load(str(tmp_path / ("rec%d.npy" % r)))["edges"]).sum())
+    assert changed > 0, "the test data must contain edges towards vertices that were not admitted"
     hist = np.load(str(tmp_path / "hist.npy"))
     assert np.array_equal(hist[0], want["hist"][0].astype(np.uint64)) and np.array_equal(hist[1], want["hist"][1])
 

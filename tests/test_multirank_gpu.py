@@ -50,6 +50,35 @@ def test_multirank_matches_oracle(oracle, k, nranks, bloom):
     for sweep in (1 | 16 | (17 << 8), 2 | 32):
         builders = run_ranks(packed, offsets, lengths, k, nranks, bloom, sweep=sweep)
         check_ranks(builders, want)
+    # RAY_SLAVE_MODE_PURGE_NULL_EDGES across ranks: keys to the owners, one-byte answers back
+    want["graph"].purge_edges()
+    purge_ranks(builders)
+    for r, b in enumerate(builders):
+        assert_records_equal(b.export(), want["graph"].export(r), "rank %d after purge" % r)
+
+
+def purge_ranks(builders):
+    import torch
+    R = len(builders)
+    unit = 8 * builders[0].kmer_words
+    asked = []
+    for b in builders:
+        counts = b.purge_query_counts()
+        keys = torch.empty(max(1, sum(counts)) * unit, dtype=torch.uint8, device="cuda")
+        b.purge_export_queries(keys.data_ptr(), max(1, sum(counts)))
+        asked.append((counts, keys))
+    answers = [[None] * R for _ in range(R)]  # answers[src][dst]
+    for dst, b in enumerate(builders):
+        for src, (counts, keys) in enumerate(asked):
+            start, n = sum(counts[:dst]), counts[dst]
+            part = keys[start * unit:(start + n) * unit].clone()
+            ans = torch.zeros(max(1, n), dtype=torch.uint8, device="cuda")
+            b.purge_answer(part.data_ptr(), n, ans.data_ptr())
+            answers[src][dst] = ans[:n]
+    torch.cuda.synchronize()
+    for src, b in enumerate(builders):
+        back = torch.cat(answers[src]) if sum(asked[src][0]) else torch.zeros(1, dtype=torch.uint8, device="cuda")
+        b.purge_apply(back.data_ptr(), sum(asked[src][0]))
 
 
 def check_ranks(builders, want):
