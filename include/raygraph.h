@@ -137,6 +137,38 @@ int rg_export(rg_handle *h, void *host_buf, uint64_t cap_records, uint64_t *n_re
  * 169-173): kmers = n * kmer_words words, either strand; coverage 0 = absent; edges in the
  * orientation of the queried k-mer.  Host pointers. */
 int rg_find(rg_handle *h, const uint64_t *kmers, uint64_t n, uint32_t *coverage, uint8_t *edges);
+/* ---- next rows ----------------------------------------------------------------- */
+/* Read ingest.  rg_add_reads_text: n raw sequences (any bytes) as they stand in a FASTA/FASTQ file,
+ * sequence i = text[starts[i], starts[i]+raw_lengths[i]); the device applies Read::constructor with
+ * Read::trim (SequencesLoader/Read.cpp:31-159: acgt upper-cased, leading/trailing non-ACGT dropped,
+ * inner ones become A) and packs 2 bits per base.  Host pointers; raw_lengths[i] < 65535.
+ * rg_count_sequences / rg_load_sequences: FastaLoader::load (FastaLoader.cpp:26-64) and
+ * FastqLoader::loadWithPeriod (FastqLoader.cpp:84-119) for plain .fasta/.fa/.fna/.fas and .fastq/.fq
+ * files; sequences [first, last) of the file, as SequencesLoader.cpp:287-297 partitions them.
+ * rg_get_reads copies the packed reads back (rg_add_reads layout): *n_reads / *packed_bytes are what
+ * exists; filled only when everything fits the capacities. */
+int rg_add_reads_text(rg_handle *h, const char *text, uint64_t text_bytes, const uint64_t *starts,
+                      const uint32_t *raw_lengths, uint64_t n_reads);
+int rg_count_sequences(const char *path, uint64_t *n);
+int rg_load_sequences(rg_handle *h, const char *path, uint64_t first, uint64_t last, uint64_t *loaded);
+int rg_get_reads(rg_handle *h, uint8_t *packed, uint64_t packed_cap, uint64_t *byte_offsets, uint32_t *lengths,
+                 uint64_t cap_reads, uint64_t *n_reads, uint64_t *packed_bytes);
+/* SequencesIndexer marker selection (SequencesIndexer/IndexerWorker.cpp:67-248,328-362; the build without
+ * CONFIG_USE_COVERAGE_DISTRIBUTION): for every read, in the order added, the forward marker = first
+ * k-mer position whose coverage reaches the read's threshold, the reverse marker = length-k-(last such
+ * position); -1 = none (the reference then leaves the Read's offsets at 0 and attaches nothing).
+ * Replaces one RAY_MPI_TAG_REQUEST_VERTEX_COVERAGE round trip per k-mer (:76-96).  Device pointers,
+ * one int32 per read; size == 1 only in this version. */
+int rg_read_markers(rg_handle *h, int32_t *d_forward, int32_t *d_reverse);
+/* On-disk formats.  records = rg_export output (Vertex::dump layout).
+ * rg_write_genome_graph: Rank<r>.Checkpoint.GenomeGraph.ray (MessageProcessor.cpp:658-678, read back by
+ * :596-655; record = Vertex::write, Vertex.cpp:257-273), vertices in the order of `records`.
+ * rg_write_coverage_checkpoint: Rank0.Checkpoint.CoverageDistribution.ray (MachineHelper.cpp:243-259).
+ * rg_write_graph_partition: <prefix>GraphPartition.txt (EdgePurger/EdgePurger.cpp:172-217), sizes[r] = rg_size of rank r. */
+int rg_write_genome_graph(const void *records, uint64_t n_pairs, int k, int kmer_words, const char *path);
+int rg_write_coverage_checkpoint(const uint32_t *coverage, const uint64_t *count, uint64_t n, const char *path);
+int rg_write_graph_partition(const uint64_t *sizes, int nranks, const char *path);
+
 /* call_RAY_SLAVE_MODE_WRITE_KMERS degree table (MachineHelper/MachineHelper.cpp:548-578):
  * out[parents*5+children] over both strands of every stored vertex */
 int rg_degree_distribution(rg_handle *h, uint64_t out[25]);

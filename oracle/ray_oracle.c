@@ -1112,3 +1112,217 @@ int ro_coverage_distribution(const uint32_t *x, const uint64_t *y, uint64_t n64,
 	*repeat = m_repeatCoverage;
 	return 0;
 }
+
+/* ------------------------------------------------------------------ next rows: on-disk formats */
+
+/* GenomeGraph checkpoint of one rank: MessageProcessor.cpp:658-678 (writer), :596-655 (reader),
+ * record = Vertex::write (Vertex.cpp:257-273) with Kmer::write (Kmer.cpp:366-371).
+ * The reference walks its hash table (order not reproducible); here vertices go in key order, each
+ * as the iterator hands them out: the stored key, then its reverse complement (GridTableIterator.cpp:41-54). */
+int ro_graph_write_genome_graph(const ro_graph *g, int rank, const char *path) {
+	FILE *f = fopen(path, "wb");
+	if (!f) return -1;
+	uint64_t n;
+	ro_vertex **list = sorted_vertices(g, rank, &n);
+	uint64_t theSize = g->tables[rank].size; /* LargeCount: 2 per stored pair */
+	fwrite(&theSize, sizeof(uint64_t), 1, f);
+	uint64_t nb[4][2];
+	for (uint64_t i = 0; i < n; i++) {
+		uint64_t keys[2][2];
+		keys[0][0] = list[i]->key[0];
+		keys[0][1] = list[i]->key[1];
+		ro_complement_vertex(list[i]->key, g->k, keys[1]);
+		for (int s = 0; s < 2; s++) {
+			int coverage = (int)list[i]->coverage;
+			fwrite(keys[s], sizeof(uint64_t), (size_t)g->W, f);
+			fwrite(&coverage, sizeof(int), 1, f);
+			uint8_t e = vertex_get_edges(list[i]->edges, list[i]->key, keys[s], g->W);
+			int numberOfParents = ro_ingoing_edges(keys[s], e, g->k, g->W, nb);
+			fwrite(&numberOfParents, sizeof(int), 1, f);
+			for (int j = 0; j < numberOfParents; j++) fwrite(nb[j], sizeof(uint64_t), (size_t)g->W, f);
+			int numberOfChildren = ro_outgoing_edges(keys[s], e, g->k, g->W, nb);
+			fwrite(&numberOfChildren, sizeof(int), 1, f);
+			for (int j = 0; j < numberOfChildren; j++) fwrite(nb[j], sizeof(uint64_t), (size_t)g->W, f);
+		}
+	}
+	free(list);
+	fclose(f);
+	return 0;
+}
+
+/* CoverageDistribution checkpoint: MachineHelper.cpp:243-259 (writer), :226-241 (reader) */
+int ro_write_coverage_checkpoint(const uint32_t *cov, const uint64_t *cnt, uint64_t n, const char *path) {
+	FILE *f = fopen(path, "wb");
+	if (!f) return -1;
+	int theSize = (int)n;
+	fwrite(&theSize, sizeof(int), 1, f);
+	for (uint64_t i = 0; i < n; i++) {
+		uint32_t coverage = cov[i];
+		uint64_t count = cnt[i];
+		fwrite(&coverage, sizeof(uint32_t), 1, f);
+		fwrite(&count, sizeof(uint64_t), 1, f);
+	}
+	fclose(f);
+	return 0;
+}
+
+/* EdgePurger::writeGraphPartition (EdgePurger.cpp:172-217); C++ stream formatting of a double = %g */
+int ro_graph_write_partition(const ro_graph *g, const char *path) {
+	FILE *f = fopen(path, "w");
+	if (!f) return -1;
+	uint64_t total = 0;
+	for (int i = 0; i < g->nranks; i++) total += g->tables[i].size;
+	uint64_t best = total / (uint64_t)g->nranks;
+	fprintf(f, "#Rank\tNumberOfKmers\tIdealNumberOfKmers\tDifference\tRelativeDifference\n");
+	fprintf(f, "#TotalKmers: %llu\n", (unsigned long long)total);
+	fprintf(f, "#Ranks: %d\n", g->nranks);
+	fprintf(f, "#IdealNumberOfKmers: %llu\n", (unsigned long long)best);
+	for (int i = 0; i < g->nranks; i++) {
+		uint64_t actual = g->tables[i].size;
+		int difference = 0;
+		if (actual < best) {
+			difference = (int)(best - actual);
+			difference = -difference;
+		} else {
+			difference = (int)(actual - best);
+		}
+		double relativeDifference = difference * 100;
+		if (best != 0) relativeDifference /= (double)best;
+		fprintf(f, "%d\t%llu\t%llu\t%d\t%g%%\n", i, (unsigned long long)actual, (unsigned long long)best, difference, relativeDifference);
+	}
+	fclose(f);
+	return 0;
+}
+
+/* ------------------------------------------------------------------ next row: read ingest */
+
+/* FastqLoader::loadWithPeriod (FastqLoader.cpp:84-119): line 1 of every 4 is the sequence; FastaLoader::load
+ * (FastaLoader.cpp:26-64): whitespace-separated tokens, a token starting with '>' opens a record and the
+ * rest of its line is skipped, the other tokens are concatenated; every sequence goes through
+ * Read::constructor(sequence, trim=true).  is_fastq: 1 = FASTQ, 0 = FASTA.
+ * Returns the number of reads; packed/offsets/lengths as ro_graph_set_reads takes them (NULL = count only). */
+uint64_t ro_load_sequences(const char *path, int is_fastq, uint8_t *packed, uint64_t packed_cap, uint64_t *offsets,
+                           uint32_t *lengths, uint64_t cap_reads, uint64_t *packed_bytes) {
+	FILE *f = fopen(path, "r");
+	if (!f) return 0;
+	static char line[RO_MAX_READ_LENGTH + 8];
+	static char seqbuf[RO_MAX_READ_LENGTH + 8];
+	static uint8_t work[RO_MAX_READ_LENGTH];
+	uint64_t n = 0, used = 0;
+#define RO_EMIT(S)                                                              \
+	do {                                                                        \
+		int len_ = ro_read_pack((S), 1, work);                                  \
+		uint64_t bytes_ = (uint64_t)ro_read_required_bytes(len_);               \
+		if (packed && n < cap_reads && used + bytes_ <= packed_cap) {           \
+			memcpy(packed + used, work, (size_t)bytes_);                        \
+			offsets[n] = used;                                                  \
+			lengths[n] = (uint32_t)len_;                                        \
+		}                                                                       \
+		used += bytes_;                                                         \
+		n++;                                                                    \
+	} while (0)
+	if (is_fastq) {
+		int rotatingVariable = 0;
+		while (fgets(line, RO_MAX_READ_LENGTH, f) != NULL) {
+			if (rotatingVariable == 1) RO_EMIT(line);
+			rotatingVariable++;
+			if (rotatingVariable == 4) rotatingVariable = 0;
+		}
+	} else {
+		char token[RO_MAX_READ_LENGTH + 8];
+		int have_id = 0;
+		size_t seqlen = 0;
+		seqbuf[0] = 0;
+		while (fscanf(f, "%65535s", token) == 1) {
+			if (token[0] == '>') {
+				int c;
+				while ((c = fgetc(f)) != EOF && c != '\n') {
+				}
+				if (have_id) RO_EMIT(seqbuf);
+				have_id = 1;
+				seqlen = 0;
+				seqbuf[0] = 0;
+			} else {
+				size_t t = strlen(token);
+				if (seqlen + t < RO_MAX_READ_LENGTH) {
+					memcpy(seqbuf + seqlen, token, t + 1);
+					seqlen += t;
+				}
+			}
+		}
+		RO_EMIT(seqbuf); /* the last record is pushed unconditionally (FastaLoader.cpp:56-61) */
+	}
+#undef RO_EMIT
+	fclose(f);
+	if (packed_bytes) *packed_bytes = used;
+	return n;
+}
+
+/* ------------------------------------------------------------------ next row: SequencesIndexer markers */
+
+/* IndexerWorker::getThreshold (IndexerWorker.cpp:328-362) */
+static int indexer_threshold(const int *data, int n) {
+	int multiplicator = 2;
+	int bestScore = 0;
+	int bestEntry = -1;
+	for (int value = 10; value >= 1; value--) {
+		int bin1 = value;
+		int bin2 = value * multiplicator;
+		int bin1Count = 0;
+		int bin2Count = 0;
+		for (int i = 0; i < n; i++) {
+			int point = data[i];
+			if (point <= bin1) bin1Count++;
+			if (point >= bin2) bin2Count++;
+		}
+		int score = bin1Count + bin2Count;
+		if (bestEntry == -1 || score > bestScore) {
+			bestEntry = value;
+			bestScore = score;
+		}
+	}
+	return multiplicator * bestEntry;
+}
+
+/* IndexerWorker::work (IndexerWorker.cpp:67-248), build without CONFIG_USE_COVERAGE_DISTRIBUTION (the
+ * define is commented out, SeedExtender.cpp:40): the coverage of every k-mer of the read is fetched from
+ * its owner (MessageProcessor.cpp:1224-1256, 0 = absent), the forward marker is the first position whose
+ * coverage reaches the threshold, the reverse marker the last one, stored as length-k-position.
+ * forward[i] / reverse[i] = -1 when no position qualifies (the reference then leaves the Read's offsets 0
+ * and attaches nothing). */
+int ro_graph_read_markers(const ro_graph *g, int32_t *forward, int32_t *reverse) {
+	int k = g->k;
+	int *data = (int *)malloc(sizeof(int) * 65536);
+	char *seq = (char *)malloc(65536 + 1);
+	char word[130];
+	for (uint64_t r = 0; r < g->nreads; r++) {
+		int L = (int)g->lengths[r];
+		int n = 0;
+		ro_read_get_seq(g->packed + g->offsets[r], L, seq);
+		for (int position = 0; !(position > L - k); position++) {
+			uint64_t vertex[2];
+			memcpy(word, seq + position, (size_t)k);
+			word[k] = 0;
+			ro_word_id(word, vertex);
+			data[n++] = (int)request_vertex_coverage(g, vertex);
+		}
+		int threshold = indexer_threshold(data, n);
+		int selectedPosition = -1;
+		for (int i = 0; i < n; i++)
+			if (data[i] >= threshold) {
+				selectedPosition = i;
+				break;
+			}
+		forward[r] = selectedPosition;
+		selectedPosition = -1;
+		for (int i = n - 1; i >= 0; i--)
+			if (data[i] >= threshold) {
+				selectedPosition = i;
+				break;
+			}
+		reverse[r] = selectedPosition == -1 ? -1 : L - k - selectedPosition;
+	}
+	free(data);
+	free(seq);
+	return 0;
+}

@@ -96,6 +96,15 @@ uint64_t ro_graph_kmers_txt(const ro_graph *g, char *out, uint64_t cap);
 int ro_coverage_distribution(const uint32_t *cov, const uint64_t *cnt, uint64_t n, const char *path,
                              int *minimum, int *peak, int *repeat);
 
+/* ---- next rows: on-disk formats, read ingest, SequencesIndexer markers ---- */
+#define RO_MAX_READ_LENGTH 65535 /* RAY_MAXIMUM_READ_LENGTH, Mock/constants.h:100 */
+int ro_graph_write_genome_graph(const ro_graph *g, int rank, const char *path);      /* MessageProcessor.cpp:658-678, Vertex.cpp:257-273 */
+int ro_write_coverage_checkpoint(const uint32_t *cov, const uint64_t *cnt, uint64_t n, const char *path); /* MachineHelper.cpp:243-259 */
+int ro_graph_write_partition(const ro_graph *g, const char *path);                   /* EdgePurger.cpp:172-217 */
+uint64_t ro_load_sequences(const char *path, int is_fastq, uint8_t *packed, uint64_t packed_cap, uint64_t *offsets,
+                           uint32_t *lengths, uint64_t cap_reads, uint64_t *packed_bytes); /* FastqLoader.cpp:84-119, FastaLoader.cpp:26-64 */
+int ro_graph_read_markers(const ro_graph *g, int32_t *forward, int32_t *reverse);    /* SequencesIndexer/IndexerWorker.cpp:67-248,328-362 */
+
 #ifdef __cplusplus
 }
 #endif

@@ -90,6 +90,16 @@ def lib():
         L.ro_coverage_distribution.argtypes = [u32p, u64p, C.c_uint64, C.c_char_p,
                                                C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.ro_coverage_distribution.restype = C.c_int
+        L.ro_graph_write_genome_graph.argtypes = [C.c_void_p, C.c_int, C.c_char_p]
+        L.ro_graph_write_genome_graph.restype = C.c_int
+        L.ro_write_coverage_checkpoint.argtypes = [u32p, u64p, C.c_uint64, C.c_char_p]
+        L.ro_write_coverage_checkpoint.restype = C.c_int
+        L.ro_graph_write_partition.argtypes = [C.c_void_p, C.c_char_p]
+        L.ro_graph_write_partition.restype = C.c_int
+        L.ro_load_sequences.argtypes = [C.c_char_p, C.c_int, u8p, C.c_uint64, u64p, u32p, C.c_uint64, u64p]
+        L.ro_load_sequences.restype = C.c_uint64
+        L.ro_graph_read_markers.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.ro_graph_read_markers.restype = C.c_int
         _lib = L
     return _lib
 
@@ -261,11 +271,44 @@ class Graph:
         lib().ro_graph_kmers_txt(self._g, buf, need)
         return buf.raw[:need].decode()
 
+    def write_genome_graph(self, rank, path):
+        assert lib().ro_graph_write_genome_graph(self._g, rank, path.encode()) == 0
+
+    def write_partition(self, path):
+        assert lib().ro_graph_write_partition(self._g, path.encode()) == 0
+
+    def read_markers(self):
+        n = len(self._keep[2])
+        fwd = np.zeros(max(1, n), dtype=np.int32)
+        rev = np.zeros(max(1, n), dtype=np.int32)
+        lib().ro_graph_read_markers(self._g, fwd.ctypes.data_as(C.POINTER(C.c_int32)), rev.ctypes.data_as(C.POINTER(C.c_int32)))
+        return fwd[:n], rev[:n]
+
     def find(self, words):
         cov = C.c_uint32()
         e = C.c_uint8()
         found = lib().ro_graph_find(self._g, _k2(words), C.byref(cov), C.byref(e))
         return bool(found), cov.value, e.value
+
+
+def write_coverage_checkpoint(cov, cnt, path):
+    cov = np.ascontiguousarray(cov, dtype=np.uint32)
+    cnt = np.ascontiguousarray(cnt, dtype=np.uint64)
+    assert lib().ro_write_coverage_checkpoint(cov.ctypes.data_as(C.POINTER(C.c_uint32)), cnt.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                              len(cov), path.encode()) == 0
+
+
+def load_sequences(path, is_fastq):
+    """(packed, offsets, lengths) of a FASTA / FASTQ file as the reference's loaders build them"""
+    used = C.c_uint64()
+    n = lib().ro_load_sequences(path.encode(), int(is_fastq), None, 0, None, None, 0, C.byref(used))
+    packed = np.zeros(max(1, used.value), dtype=np.uint8)
+    offsets = np.zeros(max(1, n), dtype=np.uint64)
+    lengths = np.zeros(max(1, n), dtype=np.uint32)
+    lib().ro_load_sequences(path.encode(), int(is_fastq), packed.ctypes.data_as(C.POINTER(C.c_uint8)), len(packed),
+                            offsets.ctypes.data_as(C.POINTER(C.c_uint64)), lengths.ctypes.data_as(C.POINTER(C.c_uint32)),
+                            n, C.byref(used))
+    return packed[: used.value], offsets[:n], lengths[:n]
 
 
 def record_dtype(W):

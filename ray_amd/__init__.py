@@ -8,9 +8,11 @@ from . import _lib
 
 _lib.load()
 
-from .graph import GraphBuilder, RayGraphError, coverage_distribution, pack_read, pack_reads  # noqa: E402
+from .graph import (GraphBuilder, RayGraphError, count_sequences, coverage_distribution, pack_read, pack_reads,  # noqa: E402
+                    write_coverage_checkpoint, write_genome_graph, write_graph_partition)
 from .plugins import (CoverageGatherer, GridTable, KmerAcademyBuilder, Parameters, VerticesExtractor,  # noqa: E402
                       build_graph)
 
-__all__ = ["GraphBuilder", "RayGraphError", "coverage_distribution", "pack_read", "pack_reads",
+__all__ = ["GraphBuilder", "RayGraphError", "coverage_distribution", "pack_read", "pack_reads", "count_sequences",
+           "write_coverage_checkpoint", "write_genome_graph", "write_graph_partition",
            "KmerAcademyBuilder", "VerticesExtractor", "CoverageGatherer", "GridTable", "Parameters", "build_graph"]

@@ -1,5 +1,7 @@
 // host_util.cpp -- the master-mode / loader pieces of the path that run on the host in Ray as well
 // (they touch tens of histogram bins or one read at a time; there is nothing to accelerate).
+#include <algorithm>
+#include <cctype>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -96,6 +98,261 @@ int rg_pack_read(const char *sequence, int trim, uint8_t *packed) {
 		packed[i / 4] |= (uint8_t)(code << ((i % 4) * 2));
 	}
 	return (int)s.size();
+}
+
+
+// ---- on-disk formats of the path ---------------------------------------------------
+
+}  // extern "C"
+namespace {
+
+struct K2 {
+	uint64_t w[2];
+};
+
+// Kmer::complementVertex (KmerAcademyBuilder/Kmer.cpp:398-420), word-parallel
+K2 revcomp_host(K2 a, int k, int W) {
+	auto rev2 = [](uint64_t x) {  // reverses the order of the 32 two-bit groups
+		x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+		x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
+		return __builtin_bswap64(x);
+	};
+	K2 r{{0, 0}};
+	if (W == 1) {
+		r.w[0] = (~rev2(a.w[0])) >> (64 - 2 * k);
+		return r;
+	}
+	// 128-bit string reversed and complemented: low word from word 1, high word from word 0
+	const uint64_t lo = ~rev2(a.w[1]), hi = ~rev2(a.w[0]);
+	const int sh = 128 - 2 * k;
+	if (sh >= 64) {
+		r.w[0] = hi >> (sh - 64);
+	} else {
+		r.w[0] = (lo >> sh) | (hi << (64 - sh));
+		r.w[1] = hi >> sh;
+	}
+	return r;
+}
+
+// Vertex::convertBitmap (Vertex.cpp:341-361)
+uint8_t convert_bitmap_host(uint8_t m) {
+	uint32_t s = ((m << 4) | (m >> 4)) & 0xFFu;
+	s = ((s & 0xAAu) >> 1) | ((s & 0x55u) << 1);
+	s = ((s & 0xCCu) >> 2) | ((s & 0x33u) << 2);
+	return (uint8_t)s;
+}
+
+// Kmer::getIngoingEdges / getOutgoingEdges (Kmer.cpp:176-282): neighbour named by base c
+K2 parent_of(K2 a, int c, int k, int W) {
+	K2 r;
+	r.w[0] = (a.w[0] << 2) | (uint64_t)c;
+	r.w[1] = (W == 2) ? ((a.w[1] << 2) | (a.w[0] >> 62)) : 0;
+	if (2 * k < 64) r.w[0] &= (1ull << (2 * k)) - 1;
+	else if (2 * k > 64) r.w[1] &= (1ull << (2 * k - 64)) - 1;
+	if (2 * k <= 64) r.w[1] = 0;
+	return r;
+}
+K2 child_of(K2 a, int c, int k, int W) {
+	K2 r;
+	r.w[0] = a.w[0] >> 2;
+	r.w[1] = 0;
+	if (W == 2) {
+		r.w[0] |= a.w[1] << 62;
+		r.w[1] = a.w[1] >> 2;
+	}
+	const int pos = 2 * (k - 1);
+	if (pos < 64) r.w[0] |= (uint64_t)c << pos;
+	else r.w[1] |= (uint64_t)c << (pos - 64);
+	return r;
+}
+
+}  // namespace
+extern "C" {
+
+// GenomeGraph checkpoint (MessageProcessor.cpp:658-678 writes it, :596-655 reads it): LargeCount n =
+// GridTable::size() (2 per stored pair), then per iterator step -- the stored key, then its reverse
+// complement (GridTableIterator.cpp:41-54) -- Vertex::write (Vertex.cpp:257-273): key words, int coverage,
+// int #parents + their words, int #children + their words (bases A,C,G,T in that order).
+int rg_write_genome_graph(const void *records, uint64_t n_pairs, int k, int kmer_words, const char *path) {
+	if ((n_pairs && !records) || !path || k < 1 || k > 64 || (kmer_words != 1 && kmer_words != 2)) return RG_ERR_ARG;
+	if ((kmer_words == 1 && k > 32)) return RG_ERR_ARG;
+	FILE *f = fopen(path, "wb");
+	if (!f) return RG_ERR_ARG;
+	const int W = kmer_words;
+	const size_t rec = (size_t)W * 8 + 5;
+	const uint64_t theSize = 2 * n_pairs;
+	fwrite(&theSize, sizeof theSize, 1, f);
+	const uint8_t *p = (const uint8_t *)records;
+	for (uint64_t i = 0; i < n_pairs; ++i, p += rec) {
+		K2 key{{0, 0}};
+		memcpy(key.w, p, (size_t)W * 8);
+		uint32_t cov;
+		memcpy(&cov, p + W * 8, 4);
+		const uint8_t stored = p[W * 8 + 4];
+		K2 keys[2] = {key, revcomp_host(key, k, W)};
+		for (int s = 0; s < 2; ++s) {
+			const int coverage = (int)cov;
+			// Vertex::getEdges (Vertex.cpp:169-173): the stored byte is in the lower key's orientation
+			const uint8_t e = (s == 0) ? stored : convert_bitmap_host(stored);
+			fwrite(keys[s].w, 8, (size_t)W, f);
+			fwrite(&coverage, sizeof(int), 1, f);
+			int np = 0, nc = 0;
+			for (int c = 0; c < 4; ++c) {
+				np += (e >> c) & 1;
+				nc += (e >> (4 + c)) & 1;
+			}
+			fwrite(&np, sizeof(int), 1, f);
+			for (int c = 0; c < 4; ++c)
+				if ((e >> c) & 1) {
+					K2 nb = parent_of(keys[s], c, k, W);
+					fwrite(nb.w, 8, (size_t)W, f);
+				}
+			fwrite(&nc, sizeof(int), 1, f);
+			for (int c = 0; c < 4; ++c)
+				if ((e >> (4 + c)) & 1) {
+					K2 nb = child_of(keys[s], c, k, W);
+					fwrite(nb.w, 8, (size_t)W, f);
+				}
+		}
+	}
+	const bool ok = !ferror(f);
+	fclose(f);
+	return ok ? RG_OK : RG_ERR_ARG;
+}
+
+// CoverageDistribution checkpoint (MachineHelper.cpp:243-259 writes it, :226-241 reads it)
+int rg_write_coverage_checkpoint(const uint32_t *coverage, const uint64_t *count, uint64_t n, const char *path) {
+	if ((n && (!coverage || !count)) || !path) return RG_ERR_ARG;
+	FILE *f = fopen(path, "wb");
+	if (!f) return RG_ERR_ARG;
+	const int theSize = (int)n;
+	fwrite(&theSize, sizeof(int), 1, f);
+	for (uint64_t i = 0; i < n; ++i) {
+		fwrite(&coverage[i], sizeof(uint32_t), 1, f);
+		fwrite(&count[i], sizeof(uint64_t), 1, f);
+	}
+	fclose(f);
+	return RG_OK;
+}
+
+// EdgePurger::writeGraphPartition (EdgePurger.cpp:172-217): sizes[r] = GridTable::size() of rank r
+int rg_write_graph_partition(const uint64_t *sizes, int nranks, const char *path) {
+	if (!sizes || nranks < 1 || !path) return RG_ERR_ARG;
+	FILE *f = fopen(path, "w");
+	if (!f) return RG_ERR_ARG;
+	uint64_t total = 0;
+	for (int i = 0; i < nranks; ++i) total += sizes[i];
+	const uint64_t best = total / (uint64_t)nranks;
+	fprintf(f, "#Rank\tNumberOfKmers\tIdealNumberOfKmers\tDifference\tRelativeDifference\n");
+	fprintf(f, "#TotalKmers: %llu\n", (unsigned long long)total);
+	fprintf(f, "#Ranks: %d\n", nranks);
+	fprintf(f, "#IdealNumberOfKmers: %llu\n", (unsigned long long)best);
+	for (int i = 0; i < nranks; ++i) {
+		const uint64_t actual = sizes[i];
+		int difference = (actual < best) ? -(int)(best - actual) : (int)(actual - best);
+		double relativeDifference = difference * 100;
+		if (best != 0) relativeDifference /= (double)best;
+		fprintf(f, "%d\t%llu\t%llu\t%d\t%g%%\n", i, (unsigned long long)actual, (unsigned long long)best, difference, relativeDifference);
+	}
+	fclose(f);
+	return RG_OK;
+}
+
+// ---- read ingest -------------------------------------------------------------------
+
+}  // extern "C"
+namespace {
+
+bool ends_with(const std::string &s, const char *suffix) {
+	const size_t n = strlen(suffix);
+	return s.size() >= n && s.compare(s.size() - n, n, suffix) == 0;
+}
+// LoaderFactory / FastaLoader::checkFileType, FastqLoader::checkFileType: by file name
+int file_kind(const char *path) {
+	const std::string s(path);
+	if (ends_with(s, ".fastq") || ends_with(s, ".fq")) return 1;
+	if (ends_with(s, ".fasta") || ends_with(s, ".fa") || ends_with(s, ".fna") || ends_with(s, ".fas")) return 0;
+	return -1;
+}
+
+// walks the records of a file; emit(sequence text, length) per record, in file order
+template <class F>
+int walk_sequences(const char *path, int kind, F emit) {
+	FILE *f = fopen(path, "r");
+	if (!f) return RG_ERR_ARG;
+	std::vector<char> line(65536 + 8);
+	if (kind == 1) {  // FastqLoader::loadWithPeriod (FastqLoader.cpp:84-119): line 1 of every 4
+		int rotating = 0;
+		while (fgets(line.data(), 65535, f)) {
+			if (rotating == 1) emit(line.data(), strlen(line.data()));
+			if (++rotating == 4) rotating = 0;
+		}
+	} else {  // FastaLoader::load (FastaLoader.cpp:26-64): tokens; '>' opens a record, rest of that line skipped
+		std::string seq;
+		bool have_id = false;
+		char token[65536 + 8];
+		while (fscanf(f, "%65535s", token) == 1) {
+			if (token[0] == '>') {
+				int c;
+				while ((c = fgetc(f)) != EOF && c != '\n') {
+				}
+				if (have_id) emit(seq.c_str(), seq.size());
+				have_id = true;
+				seq.clear();
+			} else {
+				seq += token;
+			}
+		}
+		emit(seq.c_str(), seq.size());  // the last record is pushed unconditionally (:56-61)
+	}
+	fclose(f);
+	return RG_OK;
+}
+
+}  // namespace
+extern "C" {
+
+int rg_count_sequences(const char *path, uint64_t *n) {
+	if (!path || !n) return RG_ERR_ARG;
+	const int kind = file_kind(path);
+	if (kind < 0) return RG_ERR_ARG;
+	uint64_t c = 0;
+	int rc = walk_sequences(path, kind, [&](const char *, size_t) { c++; });
+	*n = c;
+	return rc;
+}
+
+// sequences [first, last) of the file go to the device in slabs and are trimmed and packed there
+int rg_load_sequences(rg_handle *h, const char *path, uint64_t first, uint64_t last, uint64_t *loaded) {
+	if (!h || !path) return RG_ERR_ARG;
+	const int kind = file_kind(path);
+	if (kind < 0) return RG_ERR_ARG;
+	const size_t SLAB = 256u << 20;
+	std::vector<char> text;
+	std::vector<uint64_t> starts;
+	std::vector<uint32_t> lens;
+	text.reserve(std::min<size_t>(SLAB + 65536, 64u << 20));
+	uint64_t idx = 0, done = 0;
+	int status = RG_OK;
+	auto flush = [&]() {
+		if (!starts.empty() && status == RG_OK) status = rg_add_reads_text(h, text.data(), text.size(), starts.data(), lens.data(), starts.size());
+		done += starts.size();
+		text.clear();
+		starts.clear();
+		lens.clear();
+	};
+	int rc = walk_sequences(path, kind, [&](const char *s, size_t len) {
+		const uint64_t i = idx++;
+		if (i < first || i >= last || status != RG_OK) return;
+		starts.push_back(text.size());
+		lens.push_back((uint32_t)std::min<size_t>(len, 0xFFFFFFFFu));
+		text.insert(text.end(), s, s + len);
+		if (text.size() >= SLAB) flush();
+	});
+	if (rc != RG_OK) return rc;
+	flush();
+	if (loaded) *loaded = done;
+	return status;
 }
 
 }  // extern "C"

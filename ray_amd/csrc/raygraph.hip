@@ -450,6 +450,152 @@ __global__ __launch_bounds__(BLOCK) void k_purge(Slot *__restrict__ tab, uint64_
 	}
 }
 
+// ---- read ingest: Read::constructor with Read::trim (SequencesLoader/Read.cpp:31-159) in bulk --------
+__device__ __forceinline__ bool is_acgt_any_case(uint8_t c) {
+	c &= 0xDFu;  // a,c,g,t -> A,C,G,T (Read.cpp:35-44); no other byte maps onto these four
+	return c == 'A' || c == 'C' || c == 'G' || c == 'T';
+}
+// one thread per raw sequence: where its first and last ACGT symbols are (Read.cpp:45-66)
+__global__ __launch_bounds__(BLOCK) void k_trim_reads(const uint8_t *__restrict__ text, const uint64_t *__restrict__ starts,
+                                                      const uint32_t *__restrict__ raw_len, uint64_t n,
+                                                      uint64_t *__restrict__ tstart, uint32_t *__restrict__ tlen,
+                                                      unsigned long long *__restrict__ nbytes) {
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	for (; i < n; i += stride) {
+		const uint8_t *p = text + starts[i];
+		const uint32_t len = raw_len[i];
+		uint32_t first = 0;
+		while (first < len && !is_acgt_any_case(p[first])) first++;
+		uint32_t last = first;  // one past the last ACGT symbol
+		for (uint32_t j = len; j > first; --j)
+			if (is_acgt_any_case(p[j - 1])) {
+				last = j;
+				break;
+			}
+		tstart[i] = starts[i] + first;
+		tlen[i] = last - first;
+		nbytes[i] = (last - first + 3) / 4;  // Read::getRequiredBytes (Read.cpp:206-220)
+	}
+}
+// 64 reads per workgroup, one thread per output byte: 4 symbols -> 2 bits each, anything that is not
+// C, G or T encodes as A (Read.cpp:117-141)
+__global__ __launch_bounds__(BLOCK) void k_pack_reads(const uint8_t *__restrict__ text, const uint64_t *__restrict__ tstart,
+                                                      const uint32_t *__restrict__ tlen, const unsigned long long *__restrict__ off,
+                                                      uint64_t n, uint8_t *__restrict__ out) {
+	__shared__ unsigned long long s_off[65];
+	const uint64_t r0 = (uint64_t)blockIdx.x * 64;
+	const uint32_t nr = (n - r0 < 64) ? (uint32_t)(n - r0) : 64u;
+	if (threadIdx.x <= nr) s_off[threadIdx.x] = off[r0 + threadIdx.x];
+	__syncthreads();
+	const unsigned long long b0 = s_off[0], b1 = s_off[nr];
+	for (unsigned long long b = b0 + threadIdx.x; b < b1; b += blockDim.x) {
+		uint32_t lo = 0, hi = nr;  // largest r with s_off[r] <= b
+		while (hi - lo > 1) {
+			const uint32_t mid = (lo + hi) >> 1;
+			if (s_off[mid] <= b) lo = mid;
+			else hi = mid;
+		}
+		const uint64_t r = r0 + lo;
+		const uint32_t j = (uint32_t)(b - s_off[lo]) * 4;
+		const uint32_t len = tlen[r];
+		const uint8_t *p = text + tstart[r];
+		uint32_t v = 0;
+#pragma unroll
+		for (uint32_t q = 0; q < 4; ++q)
+			if (j + q < len) {
+				const uint8_t c = p[j + q] & 0xDFu;
+				const uint32_t code = (c == 'C') ? 1u : (c == 'G') ? 2u : (c == 'T') ? 3u : 0u;
+				v |= code << (2 * q);
+			}
+		out[b] = (uint8_t)v;
+	}
+}
+
+// ---- SequencesIndexer markers (IndexerWorker.cpp:67-248,328-362; build without CONFIG_USE_COVERAGE_DISTRIBUTION) --
+// One wavefront per read.  The threshold is 2*v for the v in 10..1 that maximises #(coverage <= v) +
+// #(coverage >= 2v) (ties: the larger v); the forward marker is the first position whose coverage reaches
+// it, the reverse marker the last one, stored as length-k-position.  All ten candidates are tracked in one
+// sweep over the read, so every k-mer is looked up once.
+template <int W>
+__global__ __launch_bounds__(256) void k_read_markers(const uint64_t *__restrict__ P, const uint64_t *__restrict__ offsets,
+                                                      const uint32_t *__restrict__ lengths, uint64_t nreads, int k,
+                                                      const Slot *__restrict__ tab, uint64_t mask,
+                                                      int32_t *__restrict__ forward, int32_t *__restrict__ reverse) {
+	__shared__ uint32_t s_le[4][10], s_ge[4][10], s_first[4][10], s_last[4][10];
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	const uint64_t mask0 = (2 * k >= 64) ? ~0ull : ((1ull << (2 * k)) - 1);
+	const uint64_t mask1 = (k > 32) ? ((1ull << (2 * k - 64)) - 1) : 0ull;
+	const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+	for (uint64_t r = (uint64_t)blockIdx.x * 4 + wave; r < nreads; r += nwaves) {
+		const uint32_t L = lengths[r];
+		const uint32_t n = (L >= (uint32_t)k) ? L - (uint32_t)k + 1 : 0;
+		if (lane < 10) {
+			s_le[wave][lane] = 0;
+			s_ge[wave][lane] = 0;
+			s_first[wave][lane] = 0xFFFFFFFFu;
+			s_last[wave][lane] = 0;
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		const uint64_t bit0 = offsets[r] * 8;
+		uint32_t le[10], ge[10], first[10], last1[10];  // last1 = last position + 1 (0 = none)
+#pragma unroll
+		for (int v = 0; v < 10; ++v) {
+			le[v] = 0;
+			ge[v] = 0;
+			first[v] = 0xFFFFFFFFu;
+			last1[v] = 0;
+		}
+		for (uint32_t p = lane; p < n; p += 64) {
+			uint64_t f0 = ext64(P, bit0 + 2ull * p) & mask0, f1 = 0;
+			if (W == 2 && k > 32) f1 = ext64(P, bit0 + 2ull * p + 64) & mask1;
+			uint64_t i0, i1;
+			bool rc;
+			canonical_internal<W>(f0, f1, k, i0, i1, rc);
+			const Slot *q = lookup<W>(tab, mask, i0, i1);
+			// the reference compares the coverage as an int (IndexerWorker.cpp:92)
+			const int cov = q ? (int)(uint32_t)(q->meta & COUNT_MASK) : 0;
+#pragma unroll
+			for (int v = 0; v < 10; ++v) {
+				if (cov <= v + 1) le[v]++;
+				if (cov >= 2 * (v + 1)) {
+					ge[v]++;
+					if (first[v] == 0xFFFFFFFFu) first[v] = p;
+					last1[v] = p + 1;
+				}
+			}
+		}
+#pragma unroll
+		for (int v = 0; v < 10; ++v) {
+			if (le[v]) atomicAdd(&s_le[wave][v], le[v]);
+			if (ge[v]) {
+				atomicAdd(&s_ge[wave][v], ge[v]);
+				atomicMin(&s_first[wave][v], first[v]);
+				atomicMax(&s_last[wave][v], last1[v]);
+			}
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		if (lane == 0) {
+			int bestEntry = -1;
+			uint32_t bestScore = 0;
+			for (int value = 10; value >= 1; --value) {
+				const uint32_t score = s_le[wave][value - 1] + s_ge[wave][value - 1];
+				if (bestEntry == -1 || score > bestScore) {
+					bestEntry = value;
+					bestScore = score;
+				}
+			}
+			const uint32_t fp = s_first[wave][bestEntry - 1], lp1 = s_last[wave][bestEntry - 1];
+			forward[r] = (fp == 0xFFFFFFFFu) ? -1 : (int32_t)fp;
+			reverse[r] = (lp1 == 0) ? -1 : (int32_t)(L - (uint32_t)k - (lp1 - 1));
+		}
+		__builtin_amdgcn_wave_barrier();
+	}
+}
+
 // ---- purge across ranks: the neighbour-existence queries of EdgePurgerWorker.cpp:36-44,73-81 in bulk ------
 // neighbour (in canonical internal form) named by edge bit `bit` of the stored key (K0,K1)
 template <int W>
@@ -1837,6 +1983,142 @@ int rg_find(rg_handle *h, const uint64_t *kmers, uint64_t n, uint32_t *coverage,
 	pool_free(h->cfg.device, dc);
 	pool_free(h->cfg.device, de);
 	if (e != hipSuccess) return fail(h, RG_ERR_HIP, "find failed: %s", hipGetErrorString(e));
+	return RG_OK;
+}
+
+int rg_add_reads_text(rg_handle *h, const char *text, uint64_t text_bytes, const uint64_t *starts, const uint32_t *raw_lengths,
+                      uint64_t n_reads) {
+	if (!h) return RG_ERR_ARG;
+	if (h->phase != PH_CREATED) return fail(h, RG_ERR_STATE, "reads must be added before counting");
+	if (n_reads == 0) return RG_OK;
+	if (!text || !starts || !raw_lengths) return fail(h, RG_ERR_ARG, "null read arrays");
+	for (uint64_t i = 0; i < n_reads; ++i) {
+		// the reference does not trim (and cannot store, uint16_t m_length) a sequence of 65535 symbols or more
+		if (raw_lengths[i] >= 65535u) return fail(h, RG_ERR_ARG, "sequence %llu has %u symbols (limit 65534)", (unsigned long long)i, raw_lengths[i]);
+		if (starts[i] + raw_lengths[i] > text_bytes) return fail(h, RG_ERR_ARG, "sequence %llu outside the text buffer", (unsigned long long)i);
+	}
+	const int dev = h->cfg.device;
+	HIP_TRY(h, hipSetDevice(dev));
+	uint8_t *d_text = nullptr, *d_packed = nullptr;
+	uint64_t *d_starts = nullptr, *d_tstart = nullptr;
+	uint32_t *d_raw = nullptr, *d_tlen = nullptr;
+	unsigned long long *d_nbytes = nullptr, *d_off = nullptr, *d_sums = nullptr;
+	const uint32_t nblk = (uint32_t)((n_reads + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK);
+	auto cleanup = [&](bool keep) {
+		pool_free(dev, d_text);
+		pool_free(dev, d_starts);
+		pool_free(dev, d_tstart);
+		pool_free(dev, d_raw);
+		pool_free(dev, d_nbytes);
+		pool_free(dev, d_sums);
+		if (!keep) {
+			pool_free(dev, d_packed);
+			pool_free(dev, d_tlen);
+			pool_free(dev, d_off);
+		}
+	};
+	hipError_t e = hipSuccess;
+	auto A = [&](void **p, size_t bytes) {
+		if (e == hipSuccess) e = pool_alloc(dev, p, bytes);
+	};
+	A((void **)&d_text, text_bytes + 8);
+	A((void **)&d_starts, n_reads * sizeof(uint64_t));
+	A((void **)&d_tstart, n_reads * sizeof(uint64_t));
+	A((void **)&d_raw, n_reads * sizeof(uint32_t));
+	A((void **)&d_tlen, n_reads * sizeof(uint32_t));
+	A((void **)&d_nbytes, n_reads * sizeof(unsigned long long));
+	A((void **)&d_off, (n_reads + 1) * sizeof(unsigned long long));
+	A((void **)&d_sums, ((size_t)nblk + 1) * sizeof(unsigned long long));
+	if (e == hipSuccess) e = hipMemcpyAsync(d_text, text, text_bytes, hipMemcpyHostToDevice, h->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(d_starts, starts, n_reads * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(d_raw, raw_lengths, n_reads * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream);
+	unsigned long long total = 0;
+	if (e == hipSuccess) {
+		ProfScope ps(h, "k_trim_reads");
+		hipLaunchKernelGGL(k_trim_reads, dim3(grid_for(n_reads)), dim3(BLOCK), 0, h->stream, d_text, d_starts, d_raw, n_reads, d_tstart, d_tlen, d_nbytes);
+		hipLaunchKernelGGL(k_scan_local, dim3(nblk), dim3(256), 0, h->stream, d_nbytes, d_off, n_reads, d_sums);
+		hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(64), 0, h->stream, d_sums, nblk, d_sums + nblk);
+		hipLaunchKernelGGL(k_scan_add, dim3(nblk), dim3(256), 0, h->stream, d_off, n_reads, d_sums, d_sums + nblk, (unsigned long long *)nullptr);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipMemcpyAsync(&total, d_off + n_reads, sizeof total, hipMemcpyDeviceToHost, h->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+	const uint64_t padded = ((total + 7) / 8) * 8 + 16;
+	A((void **)&d_packed, padded);
+	if (e == hipSuccess) e = hipMemsetAsync(d_packed + (padded - 24), 0, 24, h->stream);
+	if (e == hipSuccess) {
+		ProfScope ps(h, "k_pack_reads");
+		hipLaunchKernelGGL(k_pack_reads, dim3((unsigned)((n_reads + 63) / 64)), dim3(BLOCK), 0, h->stream, d_text, d_tstart, d_tlen, d_off, n_reads, d_packed);
+		e = hipGetLastError();
+	}
+	std::vector<uint32_t> tl(n_reads);
+	if (e == hipSuccess) e = hipMemcpyAsync(tl.data(), d_tlen, n_reads * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+	if (e != hipSuccess) {
+		(void)hipGetLastError();
+		cleanup(false);
+		return fail(h, e == hipErrorOutOfMemory ? RG_ERR_NOMEM : RG_ERR_HIP, "rg_add_reads_text: %s", hipGetErrorString(e));
+	}
+	uint32_t maxlen = 0;
+	for (uint64_t i = 0; i < n_reads; ++i) maxlen = std::max(maxlen, tl[i]);
+	cleanup(true);
+	ReadBatch b;
+	b.d_packed = (const uint64_t *)d_packed;
+	b.d_off = (const uint64_t *)d_off;
+	b.d_len = d_tlen;
+	b.n = n_reads;
+	b.first_id = h->cfg.first_read_id + h->n_reads;
+	b.maxlen = maxlen;
+	b.owned = true;
+	h->reads.push_back(b);
+	h->n_reads += n_reads;
+	return RG_OK;
+}
+
+int rg_get_reads(rg_handle *h, uint8_t *packed, uint64_t packed_cap, uint64_t *byte_offsets, uint32_t *lengths, uint64_t cap_reads,
+                 uint64_t *n_reads, uint64_t *packed_bytes) {
+	if (!h || !n_reads || !packed_bytes) return RG_ERR_ARG;
+	HIP_TRY(h, hipSetDevice(h->cfg.device));
+	uint64_t nr = 0, nb = 0;
+	for (const ReadBatch &b : h->reads) {
+		if (b.n == 0) continue;
+		std::vector<uint64_t> off(b.n);
+		std::vector<uint32_t> len(b.n);
+		HIP_TRY(h, hipMemcpy(off.data(), b.d_off, b.n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+		HIP_TRY(h, hipMemcpy(len.data(), b.d_len, b.n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+		uint64_t end = 0;
+		for (uint64_t i = 0; i < b.n; ++i) end = std::max<uint64_t>(end, off[i] + (len[i] + 3) / 4);
+		if (packed && byte_offsets && lengths && nr + b.n <= cap_reads && nb + end <= packed_cap) {
+			if (end) HIP_TRY(h, hipMemcpy(packed + nb, b.d_packed, end, hipMemcpyDeviceToHost));
+			for (uint64_t i = 0; i < b.n; ++i) {
+				byte_offsets[nr + i] = nb + off[i];
+				lengths[nr + i] = len[i];
+			}
+		}
+		nr += b.n;
+		nb += end;
+	}
+	*n_reads = nr;
+	*packed_bytes = nb;
+	return RG_OK;
+}
+
+int rg_read_markers(rg_handle *h, int32_t *d_forward, int32_t *d_reverse) {
+	if (!h || ((!d_forward || !d_reverse) && h->n_reads)) return RG_ERR_ARG;
+	if (h->phase < PH_RESOLVED) return fail(h, RG_ERR_STATE, "rg_read_markers needs the k-mer count first");
+	if (h->cfg.size != 1) return fail(h, RG_ERR_STATE, "rg_read_markers supports size == 1 only in this version");
+	HIP_TRY(h, hipSetDevice(h->cfg.device));
+	uint64_t done = 0;
+	for (const ReadBatch &b : h->reads) {
+		if (b.n == 0) continue;
+		ProfScope ps(h, "k_read_markers");
+		const unsigned grid = (unsigned)std::min<uint64_t>((b.n + 3) / 4, 65536);
+		if (h->W == 1) hipLaunchKernelGGL(k_read_markers<1>, dim3(grid), dim3(256), 0, h->stream, b.d_packed, b.d_off, b.d_len, b.n, h->cfg.k, h->tab.slots, h->tab.cap - 1, d_forward + done, d_reverse + done);
+		else hipLaunchKernelGGL(k_read_markers<2>, dim3(grid), dim3(256), 0, h->stream, b.d_packed, b.d_off, b.d_len, b.n, h->cfg.k, h->tab.slots, h->tab.cap - 1, d_forward + done, d_reverse + done);
+		HIP_TRY(h, hipGetLastError());
+		done += b.n;
+	}
+	HIP_TRY(h, hipStreamSynchronize(h->stream));
 	return RG_OK;
 }
 

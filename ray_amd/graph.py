@@ -1,5 +1,6 @@
 """Thin object wrapper over the C ABI (include/raygraph.h).  No compute happens in Python."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -57,6 +58,42 @@ def coverage_distribution(coverage, count, path=None):
     return mn.value, pk.value, rp.value
 
 
+def count_sequences(path):
+    """number of records of a FASTA / FASTQ file as Ray's loaders count them"""
+    n = C.c_uint64()
+    rc = _lib.load().rg_count_sequences(os.fsencode(path), C.byref(n))
+    if rc:
+        raise RayGraphError(rc, "cannot read %s (plain .fasta/.fa/.fna/.fas/.fastq/.fq only)" % path)
+    return n.value
+
+
+def write_genome_graph(records, k, path):
+    """Rank<r>.Checkpoint.GenomeGraph.ray from GraphBuilder.export() records (MessageProcessor.cpp:658-678)"""
+    records = np.ascontiguousarray(records)
+    W = records.dtype["key"].shape[0]
+    rc = _lib.load().rg_write_genome_graph(records.ctypes.data, len(records), k, W, os.fsencode(path))
+    if rc:
+        raise RayGraphError(rc, "cannot write %s" % path)
+
+
+def write_coverage_checkpoint(coverage, count, path):
+    """Rank0.Checkpoint.CoverageDistribution.ray (MachineHelper.cpp:243-259)"""
+    cov = np.ascontiguousarray(coverage, dtype=np.uint32)
+    cnt = np.ascontiguousarray(count, dtype=np.uint64)
+    rc = _lib.load().rg_write_coverage_checkpoint(cov.ctypes.data_as(C.POINTER(C.c_uint32)), cnt.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                  len(cov), os.fsencode(path))
+    if rc:
+        raise RayGraphError(rc, "cannot write %s" % path)
+
+
+def write_graph_partition(sizes, path):
+    """<prefix>GraphPartition.txt (EdgePurger.cpp:172-217); sizes[r] = GridTable size of rank r"""
+    a = (C.c_uint64 * len(sizes))(*[int(x) for x in sizes])
+    rc = _lib.load().rg_write_graph_partition(a, len(sizes), os.fsencode(path))
+    if rc:
+        raise RayGraphError(rc, "cannot write %s" % path)
+
+
 class GraphBuilder:
     """One rank's share of the distributed de Bruijn graph on one GPU."""
 
@@ -72,7 +109,7 @@ class GraphBuilder:
             msg = self._L.rg_last_error(None).decode()
             self._h = None
             raise RayGraphError(rc, msg)
-        self.k, self.rank, self.size = k, rank, size
+        self.k, self.rank, self.size, self.device = k, rank, size, device
         self.kmer_words = kmer_words if kmer_words else (1 if k <= 31 else 2)
         self._keep = []
 
@@ -112,6 +149,39 @@ class GraphBuilder:
             self._keep.append(keep)
         self._check(self._L.rg_add_reads_device(self._h, packed_ptr, packed_bytes, offsets_ptr, lengths_ptr, n_reads,
                                                 max_length))
+
+    def add_reads_text(self, text, starts, raw_lengths):
+        """raw sequences as they stand in a file; trimmed and packed on the device (Read.cpp:31-159)"""
+        text = bytes(text)
+        starts = np.ascontiguousarray(starts, dtype=np.uint64)
+        raw = np.ascontiguousarray(raw_lengths, dtype=np.uint32)
+        self._check(self._L.rg_add_reads_text(self._h, text, len(text), starts.ctypes.data, raw.ctypes.data, len(raw)))
+
+    def load_sequences(self, path, first=0, last=UINT64_MAX):
+        """sequences [first, last) of a FASTA / FASTQ file (SequencesLoader.cpp:287-297 partitions by these ids)"""
+        n = C.c_uint64()
+        self._check(self._L.rg_load_sequences(self._h, os.fsencode(path), first, last, C.byref(n)))
+        return n.value
+
+    def get_reads(self):
+        """(packed, byte offsets, lengths) of everything added so far, back on the host"""
+        n, nb = C.c_uint64(), C.c_uint64()
+        self._check(self._L.rg_get_reads(self._h, None, 0, None, None, 0, C.byref(n), C.byref(nb)))
+        packed = np.zeros(max(1, nb.value), dtype=np.uint8)
+        off = np.zeros(max(1, n.value), dtype=np.uint64)
+        ln = np.zeros(max(1, n.value), dtype=np.uint32)
+        self._check(self._L.rg_get_reads(self._h, packed.ctypes.data, len(packed), off.ctypes.data, ln.ctypes.data, len(ln),
+                                         C.byref(n), C.byref(nb)))
+        return packed[: nb.value], off[: n.value], ln[: n.value]
+
+    def read_markers(self, n_reads):
+        """SequencesIndexer marker positions (forward, reverse) of every read, -1 = none (IndexerWorker.cpp:67-248)"""
+        import torch
+        dev = "cuda:%d" % self.device
+        fwd = torch.empty(max(1, n_reads), dtype=torch.int32, device=dev)
+        rev = torch.empty(max(1, n_reads), dtype=torch.int32, device=dev)
+        self._check(self._L.rg_read_markers(self._h, fwd.data_ptr(), rev.data_ptr()))
+        return fwd[:n_reads].cpu().numpy(), rev[:n_reads].cpu().numpy()
 
     # -- pass 1
     def count_kmers(self):
