@@ -165,6 +165,10 @@ int rg_read_markers(rg_handle *h, int32_t *d_forward, int32_t *d_reverse);
  * :596-655; record = Vertex::write, Vertex.cpp:257-273), vertices in the order of `records`.
  * rg_write_coverage_checkpoint: Rank0.Checkpoint.CoverageDistribution.ray (MachineHelper.cpp:243-259).
  * rg_write_graph_partition: <prefix>GraphPartition.txt (EdgePurger/EdgePurger.cpp:172-217), sizes[r] = rg_size of rank r. */
+/* rg_write_kmers_txt: kmers.txt (CoverageGatherer/CoverageGatherer.cpp:47-122; header :202-228, written by the
+ * master rank only); both strands of every record, in the order of `records`. */
+int rg_write_kmers_txt(const void *records, uint64_t n_pairs, int k, int kmer_words, const char *path, int write_header,
+                       const char *ray_version, int append);
 int rg_write_genome_graph(const void *records, uint64_t n_pairs, int k, int kmer_words, const char *path);
 int rg_write_coverage_checkpoint(const uint32_t *coverage, const uint64_t *count, uint64_t n, const char *path);
 int rg_write_graph_partition(const uint64_t *sizes, int nranks, const char *path);

@@ -258,6 +258,69 @@ int rg_write_graph_partition(const uint64_t *sizes, int nranks, const char *path
 	return RG_OK;
 }
 
+// kmers.txt: CoverageGatherer::writeKmers (CoverageGatherer/CoverageGatherer.cpp:47-122) with the header of
+// :202-228 (written by the master rank only, :70-71).  One line per strand of every vertex:
+// SEQ;coverage;first base of each parent;last base of each child (A,C,G,T order, Kmer.cpp:200-211,269-280).
+int rg_write_kmers_txt(const void *records, uint64_t n_pairs, int k, int kmer_words, const char *path, int write_header,
+                       const char *ray_version, int append) {
+	if ((n_pairs && !records) || !path || k < 1 || k > 64 || (kmer_words != 1 && kmer_words != 2)) return RG_ERR_ARG;
+	FILE *f = fopen(path, append ? "a" : "w");
+	if (!f) return RG_ERR_ARG;
+	if (write_header) {
+		fprintf(f, "# Generated by Ray %s\n", ray_version ? ray_version : "");
+		fprintf(f, "# The length of k-mers is %i\n", k);
+		fputs("# This file contains the k-mer graph (subgraph of the de Bruijn graph for alphabet={A,C,G,T})\n", f);
+		fputs("# The genome sequence you are looking for is a path in this maze\n", f);
+		fputs("# You can kickstart your assembly algorithm development by loading this file\n", f);
+		fputs("# Note that vertices with a coverage of 1 are not considered.\n", f);
+		fputs("# Format:\n", f);
+		fputs("# k-mer nucleotide sequence; coverage value; first nucleotide of parents; last nucleotide of children\n", f);
+		fputs("# Example in nucleotide space:\n", f);
+		fputs("# ATCG;10;T G;C A\n", f);
+		fputs("#  ATCG has a coverage value of 10\n", f);
+		fputs("#  Ingoing arcs: TATC -> ATCG and GATC -> ATCG\n", f);
+		fputs("#  Outgoing arcs: ATCG -> TCGC and ATCG -> TCGA\n", f);
+	}
+	const int W = kmer_words;
+	const size_t rec = (size_t)W * 8 + 5;
+	const uint8_t *p = (const uint8_t *)records;
+	static const char CODES[] = "ACGT";
+	char line[256];
+	for (uint64_t i = 0; i < n_pairs; ++i, p += rec) {
+		K2 key{{0, 0}};
+		memcpy(key.w, p, (size_t)W * 8);
+		uint32_t cov;
+		memcpy(&cov, p + W * 8, 4);
+		const uint8_t stored = p[W * 8 + 4];
+		K2 keys[2] = {key, revcomp_host(key, k, W)};
+		for (int s = 0; s < 2; ++s) {
+			const uint8_t e = (s == 0) ? stored : convert_bitmap_host(stored);
+			int len = 0;
+			for (int j = 0; j < k; ++j) line[len++] = CODES[(keys[s].w[j / 32] >> (2 * (j % 32))) & 3];  // Kmer::idToWord (Kmer.cpp:312-336)
+			len += snprintf(line + len, sizeof line - (size_t)len, ";%u;", cov);
+			bool firstOne = true;
+			for (int c = 0; c < 4; ++c)
+				if ((e >> c) & 1) {
+					if (!firstOne) line[len++] = ' ';
+					line[len++] = CODES[c];
+					firstOne = false;
+				}
+			line[len++] = ';';
+			firstOne = true;
+			for (int c = 0; c < 4; ++c)
+				if ((e >> (4 + c)) & 1) {
+					if (!firstOne) line[len++] = ' ';
+					line[len++] = CODES[c];
+					firstOne = false;
+				}
+			line[len++] = '\n';
+			fwrite(line, 1, (size_t)len, f);
+		}
+	}
+	fclose(f);
+	return RG_OK;
+}
+
 // ---- read ingest -------------------------------------------------------------------
 
 }  // extern "C"

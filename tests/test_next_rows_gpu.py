@@ -91,3 +91,82 @@ def test_read_markers_match_indexer_worker(oracle, k, bloom):
     gf, gr = b.read_markers(len(lengths))
     assert (wf >= 0).sum() > 100 and (wf < 0).sum() > 0, "both outcomes must occur in the test data"
     assert np.array_equal(gf, wf) and np.array_equal(gr, wr)
+
+
+def test_standalone_driver_writes_rays_files(oracle, tmp_path):
+    """ray_amd/raygraph_build (C++ over the C ABI, no Python in the product path): FASTQ pair + FASTA in, Ray's
+    graph-construction files out; every file against the oracle's restatement of the reference writer."""
+    import os
+    import subprocess
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(here, "ray_amd", "raygraph_build")
+    assert os.path.exists(exe), "build it with make -C ray_amd/csrc"
+    rng = np.random.default_rng(5)
+    genome = "".join(rng.choice(list("ACGT"), size=6000))
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+
+    def reads(n, seed):
+        r = np.random.default_rng(seed)
+        out = []
+        for _ in range(n):
+            p = int(r.integers(0, len(genome) - 100))
+            s = list(genome[p:p + 100])
+            for j in range(100):
+                if r.random() < 0.01:
+                    s[j] = "ACGT"[int(r.integers(0, 4))]
+            s = "".join(s)
+            if r.random() < 0.5:
+                s = "".join(comp[c] for c in reversed(s))
+            out.append(s)
+        return out
+    left, right, single = reads(1500, 1), reads(1500, 2), reads(700, 3)
+    files = []
+    for name, rs in (("left.fastq", left), ("right.fastq", right)):
+        with open(tmp_path / name, "w") as f:
+            for i, s in enumerate(rs):
+                f.write("@r%d\n%s\n+\n%s\n" % (i, s, "I" * len(s)))
+        files.append(str(tmp_path / name))
+    with open(tmp_path / "single.fasta", "w") as f:
+        for i, s in enumerate(single):
+            f.write(">s%d\n%s\n%s\n" % (i, s[:50], s[50:]))
+    files.append(str(tmp_path / "single.fasta"))
+    out = str(tmp_path) + "/out_"
+    ck = tmp_path / "ck"
+    ck.mkdir()
+    res = subprocess.run([exe, "-k", "31", "-p", files[0], files[1], "-s", files[2], "-o", out, "-write-kmers",
+                          "-write-checkpoints", str(ck), "-bloom-filter-bits", "400000"], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+
+    # the oracle on the same files in the same order (read ids run through the files in command-line order)
+    parts = [oracle.load_sequences(files[0], 1), oracle.load_sequences(files[1], 1), oracle.load_sequences(files[2], 0)]
+    packed = np.concatenate([p[0] for p in parts])
+    base = np.cumsum([0] + [len(p[0]) for p in parts])
+    offsets = np.concatenate([p[1] + np.uint64(base[i]) for i, p in enumerate(parts)])
+    lengths = np.concatenate([p[2] for p in parts])
+    g = oracle.Graph(31, bloom_bits=400000)
+    g.set_reads(packed, offsets, lengths)
+    g.count_kmers()
+    cov, cnt = g.histogram()
+    want_dist = str(tmp_path / "want_dist.txt")
+    mpr = oracle.coverage_distribution(cov, cnt, want_dist)
+    assert open(out + "CoverageDistribution.txt", "rb").read() == open(want_dist, "rb").read()
+    assert "minimum coverage %d, peak coverage %d, repeat coverage %d" % tuple(mpr) in res.stdout
+    g.add_edges()
+    g.purge_edges()
+    body = [l for l in open(out + "kmers.txt").read().splitlines() if not l.startswith("#")]
+    assert sorted(body) == sorted(g.kmers_txt().strip().split("\n"))
+    deg = [int(l.split("\t")[2]) for l in open(out + "degreeDistribution.txt").read().splitlines() if not l.startswith("#")]
+    assert deg == [int(x) for x in g.degree_distribution().reshape(-1)]
+    want_part = str(tmp_path / "want_part.txt")
+    g.write_partition(want_part)
+    assert open(out + "GraphPartition.txt").read() == open(want_part).read()
+    # checkpoints: same set of entries as the reference writer's (the driver writes in table order, as Ray does)
+    from test_formats_cpu import read_genome_graph
+    want_gg = str(tmp_path / "want_gg")
+    g.write_genome_graph(0, want_gg)
+    got = read_genome_graph(str(ck / "Rank0.Checkpoint.GenomeGraph.ray"), 1)
+    want = read_genome_graph(want_gg, 1)
+    assert len(got) == len(want) and sorted(got) == sorted(want)
+    want_cc = str(tmp_path / "want_cc")
+    oracle.write_coverage_checkpoint(cov, cnt, want_cc)
+    assert open(ck / "Rank0.Checkpoint.CoverageDistribution.ray", "rb").read() == open(want_cc, "rb").read()
