@@ -30,6 +30,11 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="C2_100Mbp_60x_150bp_k31")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink genome and read count (development only)")
+    ap.add_argument("--error", type=float, default=None, help="substitution error rate instead of the workload's own (sensitivity runs)")
+    ap.add_argument("--emulate-world", type=int, default=1,
+                    help="development: run what one of N ranks does on ONE GPU (records exported by destination, as many "
+                         "full-coverage records counted as N ranks would send here, entries exported by owner and merged; "
+                         "no network).  Not a bench line.")
     ap.add_argument("--cpu-sample-reads", type=int, default=60000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print per-call wall times of the last step to stderr")
@@ -67,7 +72,7 @@ def main():
     import torch.distributed as dist
     import ray_amd
     from ray_amd import synth
-    from ray_amd.exchange import exchange_owner_buckets, reduce_histogram
+    from ray_amd.exchange import exchange_owner_buckets, exchange_records, reduce_histogram
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -88,11 +93,12 @@ def main():
 
     cfg = dict(synth.CONFIGS[args.workload])
     k = cfg["k"]
-    genome = max(2000, int(cfg["genome"] * args.scale)) * world
+    emu = args.emulate_world if world == 1 else 1
+    genome = max(2000, int(cfg["genome"] * args.scale)) * world   # emulation: a rank receives full-coverage buckets, like N = 1
     n_reads = synth.n_reads_for(int(cfg["genome"] * args.scale), cfg["read_len"], cfg["coverage"])
     t0 = time.perf_counter()
     # same genome on every rank (same seed), different reads per rank
-    packed, offsets, lengths = synth.make_reads_torch(genome, cfg["read_len"], n_reads, cfg["seed"], cfg["error"],
+    packed, offsets, lengths = synth.make_reads_torch(genome, cfg["read_len"], n_reads, cfg["seed"], cfg["error"] if args.error is None else args.error,
                                                       device=dev, read_seed=cfg["seed"] * 1000 + rank)
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
@@ -110,13 +116,32 @@ def main():
     def one_step(profile=False):
         del marks[:]
         mark("start")
-        b = ray_amd.GraphBuilder(k, rank=rank, size=world, device=local_rank, first_read_id=first_read_id, stream=stream)
+        b = ray_amd.GraphBuilder(k, rank=rank, size=world * emu, device=local_rank, first_read_id=first_read_id, stream=stream)
         if profile:
             b.set_profiling(True)
         b.add_reads_device(packed.data_ptr(), n_reads * ((cfg["read_len"] + 3) // 4), offsets.data_ptr(),
                            lengths.data_ptr(), n_reads, cfg["read_len"])
         mark("create+add_reads")
-        if world == 1:
+        if emu > 1:
+            from ray_amd.graph import RG_ENTRY_BYTES
+            # records route: this rank's records, all of them counted here in place of the ones N ranks would send
+            b.records_local()
+            rcounts, unit = b.record_counts()
+            rsend = torch.empty(max(1, sum(rcounts)) * unit, dtype=torch.uint8, device=dev)
+            b.export_records(rsend.data_ptr(), max(1, sum(rcounts)))
+            mark("records_local + export")
+            b.count_records(rsend.data_ptr(), sum(rcounts))
+            del rsend
+            mark("count_records")
+            counts = b.owner_counts()
+            send = torch.empty(max(1, sum(counts)) * RG_ENTRY_BYTES, dtype=torch.uint8, device=dev)
+            b.export_owner_buckets(send.data_ptr(), max(1, sum(counts)))
+            mark("owner buckets")
+            b.merge_entries(send.data_ptr(), sum(counts))   # as many entries, all distinct, as N ranks would send here
+            mark("merge")
+            del send
+            b.resolve_admission(n_reads)
+        elif world == 1:
             if args.breakdown:
                 b.count_local()
                 mark("count_local")
@@ -124,8 +149,9 @@ def main():
             else:
                 b.count_kmers()                  # RAY_SLAVE_MODE_ADD_VERTICES
         else:
-            b.count_local()
-            exchange_owner_buckets(b, device=dev)
+            exchange_records(b, device=dev)           # super-k-mer records to the rank that aggregates their bucket
+            mark("records + count")
+            exchange_owner_buckets(b, device=dev)     # aggregated entries to the rank vertexRank names
             b.resolve_admission(n_reads)
         mark("count/resolve")
         cov, cnt = b.histogram()                 # RAY_SLAVE_MODE_SEND_DISTRIBUTION
@@ -232,9 +258,9 @@ def main():
             "ms_per_step": per_step * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": args.workload + ("" if args.scale == 1.0 else "@scale=%g" % args.scale), "k": k,
+            "config": {"workload": args.workload + ("" if args.scale == 1.0 else "@scale=%g" % args.scale) + ("" if args.error is None else "@error=%g" % args.error), "k": k,
                        "read_len": L, "reads_per_gpu": n_reads, "genome_bp": genome,
-                       "parallelism": "owner-partitioned x%d" % world, "bloom": "default 16*k*reads cap 2^33"},
+                       "parallelism": "owner-partitioned x%d" % world + ("" if emu == 1 else " (rank 0 of %d emulated on one GPU, no network)" % emu), "bloom": "default 16*k*reads cap 2^33"},
             "occurrences_per_s": occ / per_step,
             "kmer_occurrences": occ, "distinct_candidates": cand, "vertices_stored": stored,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -78,6 +78,23 @@ int rg_add_reads_device(rg_handle *h, const void *d_packed, uint64_t packed_byte
  * rg_resolve_admission. */
 int rg_count_kmers(rg_handle *h);
 
+/* Record exchange (size > 1), the preferred multi-GPU route: what travels between ranks is the reads cut
+ * into super-k-mer records (2.9 B per k-mer occurrence at k=31 instead of the 8 B key the reference sends per
+ * occurrence, KmerAcademyBuilder.cpp:187-196), *before* aggregation, so that every rank aggregates complete
+ * buckets at the full coverage whatever the number of ranks:
+ *   rg_records_local    reads -> records, counted per destination rank (destination = bucket of the record's
+ *                       minimizer % size; an internal choice, invisible in the results)
+ *   rg_record_counts    counts[r] = records for rank r; *record_bytes = size of one record (24 or 40)
+ *   rg_export_records   the records grouped by destination in rank order, into the caller's device buffer
+ *   -- all-to-all(v) of the records --
+ *   rg_count_records    aggregates the received records (device pointer; must stay valid during the call)
+ * and then, exactly as after rg_count_local: rg_owner_counts / rg_export_owner_buckets (entries to the ranks
+ * vertexRank names) -- all-to-all(v) -- rg_merge_entries, rg_resolve_admission. */
+int rg_records_local(rg_handle *h);
+int rg_record_counts(rg_handle *h, uint64_t *counts, uint32_t *record_bytes);
+int rg_export_records(rg_handle *h, void *d_out, uint64_t capacity_records);
+int rg_count_records(rg_handle *h, const void *d_records, uint64_t n_records);
+
 /* size >= 1, decomposed so that the host can run the owner exchange (an all-to-all) between:
  *  1. rg_count_local        sender half (KmerAcademyBuilder.cpp:143-205): encode, canonical pick,
  *                           aggregate this rank's k-mers per canonical key

@@ -229,16 +229,44 @@ __global__ __launch_bounds__(BLOCK) void k_owner_counts(const Slot *__restrict__
 }
 
 // scatter entries into per-owner buckets; cursors[r] starts at the bucket's first entry
+// Entries grouped by owner.  A workgroup ranks the entries of a tile per owner in LDS and claims its
+// share of every owner's range with one global atomic per (tile, owner): the cursors are a handful of
+// addresses, one atomic per entry on them would serialise the whole kernel.
+static constexpr int OWNER_TILE = 8;  // entries per thread and tile
 template <int W>
 __global__ __launch_bounds__(BLOCK) void k_owner_scatter(const Slot *__restrict__ tab, uint64_t cap, uint32_t size,
                                                          unsigned long long *__restrict__ cursors, Slot *__restrict__ out) {
-	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-	for (; i < cap; i += stride) {
-		Slot v = tab[i];
-		if (v.k0 == EMPTY) continue;
-		unsigned long long pos = atomicAdd(&cursors[owner_of<W>(v, size)], 1ull);
-		out[pos] = v;
+	extern __shared__ unsigned long long s_dyn[];
+	unsigned long long *s_base = s_dyn;                                   // [size]
+	uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_dyn + size);          // [size]
+	const uint64_t tile = (uint64_t)blockDim.x * OWNER_TILE;
+	for (uint64_t t0 = (uint64_t)blockIdx.x * tile; t0 < cap; t0 += (uint64_t)gridDim.x * tile) {
+		for (uint32_t j = threadIdx.x; j < size; j += blockDim.x) s_cnt[j] = 0;
+		__syncthreads();
+		uint32_t own[OWNER_TILE], rank[OWNER_TILE];
+#pragma unroll
+		for (int q = 0; q < OWNER_TILE; ++q) {
+			const uint64_t i = t0 + threadIdx.x + (uint64_t)q * blockDim.x;
+			own[q] = 0xFFFFFFFFu;
+			if (i < cap) {
+				const Slot v = tab[i];
+				if (v.k0 != EMPTY) {
+					own[q] = owner_of<W>(v, size);
+					rank[q] = atomicAdd(&s_cnt[own[q]], 1u);
+				}
+			}
+		}
+		__syncthreads();
+		for (uint32_t j = threadIdx.x; j < size; j += blockDim.x)
+			s_base[j] = s_cnt[j] ? atomicAdd(&cursors[j], (unsigned long long)s_cnt[j]) : 0ull;
+		__syncthreads();
+#pragma unroll
+		for (int q = 0; q < OWNER_TILE; ++q)
+			if (own[q] != 0xFFFFFFFFu) {
+				const uint64_t i = t0 + threadIdx.x + (uint64_t)q * blockDim.x;
+				out[s_base[own[q]] + rank[q]] = tab[i];
+			}
+		__syncthreads();
 	}
 }
 
@@ -884,6 +912,9 @@ struct rg_handle {
 	bool profiling = false;
 	std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof;
 	// rg_histogram is called twice by every caller (size query, then fill): the table is scanned once
+	void *rec_buf = nullptr;             // rg_records_local .. rg_export_records: super-k-mer records of the local reads
+	uint64_t rec_slots = 0;              // slots of rec_buf in use (holes included)
+	std::vector<uint64_t> rec_counts;    // valid records per destination rank
 	uint64_t *d_purge_origin = nullptr;  // rg_purge_export_queries .. rg_purge_apply: (slot << 3 | edge bit) per query
 	uint64_t purge_total = 0;
 	std::vector<uint64_t> purge_counts;
@@ -998,8 +1029,10 @@ static int table_reserve(rg_handle *h, Table &t, uint64_t need, int fill_counter
 // ---- the partitioned sweep (rg_partition.h) ------------------------------------------------------
 // Produces the log of aggregated entries for all reads of the handle.  *ok = false means a capacity
 // estimate was exceeded (nothing is lost: the caller then runs the direct sweep instead).
+// ext != nullptr: the records come from outside (record exchange between ranks: ext_n valid records
+// received from all ranks) instead of from this handle's reads.
 template <int W>
-static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bool *ok) {
+static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bool *ok, const void *ext = nullptr, uint64_t ext_n = 0) {
 	*ok = false;
 	*out_log = nullptr;
 	*out_n = 0;
@@ -1018,6 +1051,11 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 		rec_bound += b.n * ((uint64_t)(per * frac) + (per + 63) / 64 + 2);
 		total_reads += b.n;
 		if (b.first_id + b.n >= (1ull << 33) - 1) return RG_OK;  // read ids must fit the record header
+	}
+	if (ext) {  // a record holds (w+1)/2 k-mers on average, w at most
+		occ_bound = std::max<uint64_t>(ext_n, ext_n * (uint64_t)(w + 1) / 2);
+		rec_bound = ext_n;
+		total_reads = 0;
 	}
 	if (occ_bound == 0) {
 		*ok = true;
@@ -1069,7 +1107,7 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 			return fail(h, e_ == hipErrorOutOfMemory ? RG_ERR_NOMEM : RG_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
 		}                                                                                                   \
 	} while (0)
-	if (pool_alloc(dev, (void **)&buf[0], rec_cap * sizeof(Rec<W>)) != hipSuccess) {  // not enough memory: direct sweep
+	if (!ext && pool_alloc(dev, (void **)&buf[0], rec_cap * sizeof(Rec<W>)) != hipSuccess) {  // not enough memory: direct sweep
 		(void)hipGetLastError();
 		return RG_OK;
 	}
@@ -1082,29 +1120,33 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	PTRY(hipMemsetAsync(d_hist, 0, 256 * sizeof(unsigned long long), h->stream));
 	PTRY(hipMemsetAsync(h->d_counters + PC_REC_CURSOR, 0, 8 * sizeof(unsigned long long), h->stream));
 	// 1. reads -> records (+ first-level histogram)
-	for (const ReadBatch &b : h->reads) {
-		if (b.maxlen < (uint32_t)k) continue;
-		{
-			ProfScope ps(h, "k_superkmers");
-			hipLaunchKernelGGL(k_superkmers<W>, dim3(grid1), dim3(256), 0, h->stream, b.d_packed, b.d_off, b.d_len, b.n, b.first_id, k, m, buf[0],
-			                   rec_cap, h->d_counters, d_hist);
+	uint64_t n_in = ext_n, valid = ext_n;
+	int rc = RG_OK;
+	if (!ext) {
+		for (const ReadBatch &b : h->reads) {
+			if (b.maxlen < (uint32_t)k) continue;
+			{
+				ProfScope ps(h, "k_superkmers");
+				hipLaunchKernelGGL(k_superkmers<W>, dim3(grid1), dim3(256), 0, h->stream, b.d_packed, b.d_off, b.d_len, b.n, b.first_id, k, m, buf[0],
+				                   rec_cap, h->d_counters, d_hist, 0u);
+			}
+			PTRY(hipGetLastError());
 		}
-		PTRY(hipGetLastError());
+		std::vector<unsigned long long> hist(256);
+		PTRY(hipMemcpyAsync(hist.data(), d_hist, 256 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+		rc = sync_counters(h);
+		if (rc) {
+			cleanup();
+			return rc;
+		}
+		if (h->h_counters[PC_REC_OVF]) {
+			cleanup();
+			return RG_OK;
+		}
+		n_in = std::min<uint64_t>(h->h_counters[PC_REC_CURSOR], rec_cap);
+		valid = 0;
+		for (auto c : hist) valid += c;
 	}
-	std::vector<unsigned long long> hist(256), begin;
-	PTRY(hipMemcpyAsync(hist.data(), d_hist, 256 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-	int rc = sync_counters(h);
-	if (rc) {
-		cleanup();
-		return rc;
-	}
-	if (h->h_counters[PC_REC_OVF]) {
-		cleanup();
-		return RG_OK;
-	}
-	const uint64_t n_in = std::min<uint64_t>(h->h_counters[PC_REC_CURSOR], rec_cap);
-	uint64_t valid = 0;
-	for (auto c : hist) valid += c;
 	if (valid == 0) {
 		cleanup();
 		*ok = true;
@@ -1113,7 +1155,8 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	PTRY(pool_alloc(dev, (void **)&buf[1], valid * sizeof(Rec<W>)));
 
 	// 2. partition levels
-	int cur = 0;                                      // buf[cur] holds the level's input
+	int cur = 0;                                      // buf[cur] holds the level's input (level 0 of received records: ext)
+	const Rec<W> *level_in = ext ? (const Rec<W> *)ext : buf[0];
 	std::vector<unsigned long long> seg_begin = {0, n_in};  // host copy of the current segmentation
 	std::vector<uint32_t> tile_first;
 	int used_bits = 0;
@@ -1131,12 +1174,13 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 		PTRY(hipMemcpyAsync(d_seg, seg_begin.data(), (S + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
 		PTRY(hipMemcpyAsync(d_tile, tile_first.data(), (S + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
 		const uint64_t nout = (uint64_t)S << db;  // buckets after this level
-		if (level > 0) {  // level 0's histogram came out of k_superkmers
+		if (level > 0 || ext) {  // level 0's histogram came out of k_superkmers
 			PTRY(hipMemsetAsync(d_hist, 0, nout * sizeof(unsigned long long), h->stream));
 			ProfScope ps(h, "k_level_hist");
-			hipLaunchKernelGGL(k_level_hist<W>, dim3((unsigned)ntiles), dim3(256), 0, h->stream, buf[cur], m, S, d_seg, d_tile, shift, db, d_hist);
+			hipLaunchKernelGGL(k_level_hist<W>, dim3((unsigned)ntiles), dim3(256), 0, h->stream, level_in, m, S, d_seg, d_tile, shift, db, d_hist);
 			PTRY(hipGetLastError());
 		}
+		if (!buf[cur ^ 1]) PTRY(pool_alloc(dev, (void **)&buf[cur ^ 1], valid * sizeof(Rec<W>)));
 		// exclusive scan -> d_begin[nout+1]; the scatter's cursors are a copy of it (reusing d_hist)
 		const uint32_t nblk = (uint32_t)((nout + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK);
 		hipLaunchKernelGGL(k_scan_local, dim3(nblk), dim3(256), 0, h->stream, d_hist, d_begin, nout, d_sums);
@@ -1145,12 +1189,13 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 		PTRY(hipGetLastError());
 		{
 			ProfScope ps(h, "k_scatter");
-			hipLaunchKernelGGL(k_scatter<W>, dim3((unsigned)ntiles), dim3(256), 0, h->stream, buf[cur], m, S, d_seg, d_tile, shift, db, d_hist,
-			                   buf[cur ^ 1]);
+			hipLaunchKernelGGL(k_scatter<W>, dim3((unsigned)ntiles), dim3(256), 0, h->stream, level_in, m, S, d_seg, d_tile, shift, db, d_hist,
+			                   buf[cur ^ 1], 0u);
 		}
 		PTRY(hipGetLastError());
 		used_bits += db;
 		cur ^= 1;
+		level_in = buf[cur];
 		if (level < 2 && dbits[level + 1] > 0) {  // the next level needs this segmentation on the host
 			seg_begin.resize(nout + 1);
 			PTRY(hipMemcpyAsync(seg_begin.data(), d_begin, (nout + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
@@ -1173,7 +1218,7 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	}
 	{
 		ProfScope ps(h, "k_aggregate");
-		hipLaunchKernelGGL(k_aggregate<W>, dim3(agg_grid), dim3(256), 0, h->stream, buf[cur], d_begin, (uint32_t)NBUCK, k, log, log_cap,
+		hipLaunchKernelGGL(k_aggregate<W>, dim3(agg_grid), dim3(256), 0, h->stream, level_in, d_begin, (uint32_t)NBUCK, k, log, log_cap,
 		                   h->d_counters);
 	}
 	hipError_t e = hipGetLastError();
@@ -1201,8 +1246,123 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	return RG_OK;
 }
 
-static int sweep_partitioned(rg_handle *h, Slot **out_log, uint64_t *out_n, bool *ok) {
-	return h->W == 1 ? sweep_partitioned_t<1>(h, out_log, out_n, ok) : sweep_partitioned_t<2>(h, out_log, out_n, ok);
+static int sweep_partitioned(rg_handle *h, Slot **out_log, uint64_t *out_n, bool *ok, const void *ext = nullptr, uint64_t ext_n = 0) {
+	return h->W == 1 ? sweep_partitioned_t<1>(h, out_log, out_n, ok, ext, ext_n) : sweep_partitioned_t<2>(h, out_log, out_n, ok, ext, ext_n);
+}
+
+// ---- record exchange between ranks: stage 1 on the sender (reads -> records, counted per destination) ----
+template <int W>
+static int records_local_t(rg_handle *h) {
+	const int dev = h->cfg.device;
+	const int k = h->cfg.k;
+	const int m = k < MMER_MAX ? k : MMER_MAX;
+	const int w = k - m + 1;
+	const uint32_t size = (uint32_t)h->cfg.size;
+	if (w > lmax_for(W, k)) return fail(h, RG_ERR_STATE, "k-mer length %d cannot be cut into records", k);
+	if (size > 256) return fail(h, RG_ERR_STATE, "the record exchange supports at most 256 ranks (use rg_count_local + rg_export_owner_buckets)");
+	uint64_t rec_bound = 0, total_reads = 0, launches1 = 0;
+	for (const ReadBatch &b : h->reads) {
+		if (b.maxlen < (uint32_t)k) continue;
+		const uint64_t per = (uint64_t)b.maxlen - k + 1;
+		rec_bound += b.n * per;  // exact upper bound: a record holds at least one k-mer
+		total_reads += b.n;
+		launches1++;
+		if (b.first_id + b.n >= (1ull << 33) - 1) return fail(h, RG_ERR_CAPACITY, "read ids above 2^33 do not fit a record");
+	}
+	h->rec_counts.assign(size, 0);
+	h->rec_slots = 0;
+	if (rec_bound == 0) return RG_OK;
+	// the expected number of records is 2/(w+1) per k-mer; three times that has never been seen to overflow, and if it
+	// does the exact bound is used in a second attempt
+	int n_cu = 256, occ1 = 4;
+	(void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ1, k_superkmers<W>, 256, 0) != hipSuccess || occ1 < 1) occ1 = 4;
+	(void)hipGetLastError();
+	const int grid1 = (int)std::min<uint64_t>((uint64_t)n_cu * occ1, std::max<uint64_t>(1, (total_reads + 255) / 256));
+	unsigned long long *d_hist = nullptr;
+	HIP_TRY(h, pool_alloc(dev, (void **)&d_hist, 256 * sizeof(unsigned long long)));
+	for (int attempt = 0; attempt < 2; ++attempt) {
+		double frac = attempt ? 1.0 : std::min(1.0, 3.0 / (w + 1));
+		const uint64_t rec_cap = (uint64_t)(rec_bound * frac) + total_reads * 3 + launches1 * (uint64_t)grid1 * 4 * REC_CHUNK;
+		Rec<W> *buf = nullptr;
+		if (pool_alloc(dev, (void **)&buf, rec_cap * sizeof(Rec<W>)) != hipSuccess) {
+			(void)hipGetLastError();
+			pool_free(dev, d_hist);
+			return fail(h, RG_ERR_NOMEM, "out of device memory for %llu records", (unsigned long long)rec_cap);
+		}
+		hipError_t e = hipMemsetAsync(d_hist, 0, 256 * sizeof(unsigned long long), h->stream);
+		if (e == hipSuccess) e = hipMemsetAsync(h->d_counters + PC_REC_CURSOR, 0, 8 * sizeof(unsigned long long), h->stream);
+		if (e == hipSuccess) e = hipMemsetAsync(h->d_counters + C_OCC, 0, sizeof(unsigned long long), h->stream);
+		for (const ReadBatch &b : h->reads) {
+			if (b.maxlen < (uint32_t)k || e != hipSuccess) continue;
+			ProfScope ps(h, "k_superkmers");
+			hipLaunchKernelGGL(k_superkmers<W>, dim3(grid1), dim3(256), 0, h->stream, b.d_packed, b.d_off, b.d_len, b.n, b.first_id, k, m, buf, rec_cap,
+			                   h->d_counters, d_hist, size);
+			e = hipGetLastError();
+		}
+		std::vector<unsigned long long> hist(256);
+		if (e == hipSuccess) e = hipMemcpyAsync(hist.data(), d_hist, 256 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream);
+		int rc = (e == hipSuccess) ? sync_counters(h) : fail(h, RG_ERR_HIP, "k_superkmers: %s", hipGetErrorString(e));
+		if (rc) {
+			pool_free(dev, buf);
+			pool_free(dev, d_hist);
+			return rc;
+		}
+		if (h->h_counters[PC_REC_OVF]) {
+			pool_free(dev, buf);
+			continue;
+		}
+		h->rec_buf = buf;
+		h->rec_slots = std::min<uint64_t>(h->h_counters[PC_REC_CURSOR], rec_cap);
+		for (uint32_t r = 0; r < size; ++r) h->rec_counts[r] = hist[r];
+		pool_free(dev, d_hist);
+		return RG_OK;
+	}
+	pool_free(dev, d_hist);
+	return fail(h, RG_ERR_CAPACITY, "record buffer overflow");
+}
+
+// stage 2 on the sender: one scatter pass by destination rank straight into the caller's send buffer
+template <int W>
+static int export_records_t(rg_handle *h, void *d_out) {
+	const int dev = h->cfg.device;
+	const int k = h->cfg.k;
+	const int m = k < MMER_MAX ? k : MMER_MAX;
+	const uint32_t size = (uint32_t)h->cfg.size;
+	const uint64_t n_in = h->rec_slots;
+	if (n_in == 0) return RG_OK;
+	unsigned long long *d_seg = nullptr, *d_cur = nullptr;
+	uint32_t *d_tile = nullptr;
+	hipError_t e = pool_alloc(dev, (void **)&d_seg, 2 * sizeof(unsigned long long));
+	if (e == hipSuccess) e = pool_alloc(dev, (void **)&d_tile, 2 * sizeof(uint32_t));
+	if (e == hipSuccess) e = pool_alloc(dev, (void **)&d_cur, 256 * sizeof(unsigned long long));
+	const unsigned long long seg[2] = {0, n_in};
+	const uint64_t ntiles = (n_in + SCATTER_TILE - 1) / SCATTER_TILE;
+	const uint32_t tile_first[2] = {0, (uint32_t)ntiles};
+	std::vector<unsigned long long> cursors(256, 0);
+	unsigned long long run = 0;
+	for (uint32_t r = 0; r < size; ++r) {
+		cursors[r] = run;
+		run += h->rec_counts[r];
+	}
+	if (e == hipSuccess) e = hipMemcpyAsync(d_seg, seg, sizeof seg, hipMemcpyHostToDevice, h->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(d_tile, tile_first, sizeof tile_first, hipMemcpyHostToDevice, h->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(d_cur, cursors.data(), 256 * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream);
+	if (e == hipSuccess) {
+		ProfScope ps(h, "k_scatter");
+		hipLaunchKernelGGL(k_scatter<W>, dim3((unsigned)ntiles), dim3(256), 0, h->stream, (const Rec<W> *)h->rec_buf, m, 1u, d_seg, d_tile, 0, 8, d_cur,
+		                   (Rec<W> *)d_out, size);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+	pool_free(dev, d_seg);
+	pool_free(dev, d_tile);
+	pool_free(dev, d_cur);
+	pool_free(dev, h->rec_buf);
+	h->rec_buf = nullptr;
+	h->rec_slots = 0;
+	if (e != hipSuccess) return fail(h, RG_ERR_HIP, "record export: %s", hipGetErrorString(e));
+	return RG_OK;
 }
 
 // ---- Bloom admission through region partitioning (rg_bloom.h) -----------------------------------
@@ -1412,6 +1572,7 @@ int rg_destroy(rg_handle *h) {
 	if (h->h_counters) (void)hipHostFree(h->h_counters);
 	if (h->d_owner) pool_free(h->cfg.device, h->d_owner);
 	if (h->d_purge_origin) pool_free(h->cfg.device, h->d_purge_origin);
+	if (h->rec_buf) pool_free(h->cfg.device, h->rec_buf);
 	if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
 	delete h;
 	return RG_OK;
@@ -1565,6 +1726,77 @@ int rg_count_local(rg_handle *h) {
 	return RG_OK;
 }
 
+int rg_records_local(rg_handle *h) {
+	if (!h) return RG_ERR_ARG;
+	if (h->phase != PH_CREATED) return fail(h, RG_ERR_STATE, "rg_records_local called after counting started");
+	if (h->rec_buf) return fail(h, RG_ERR_STATE, "rg_records_local called twice");
+	HIP_TRY(h, hipSetDevice(h->cfg.device));
+	int rc = h->W == 1 ? records_local_t<1>(h) : records_local_t<2>(h);
+	if (rc) return rc;
+	h->stats.reads = h->n_reads;
+	h->stats.occurrences = h->rec_slots ? h->h_counters[C_OCC] : 0;
+	return RG_OK;
+}
+
+int rg_record_counts(rg_handle *h, uint64_t *counts, uint32_t *record_bytes) {
+	if (!h || !counts) return RG_ERR_ARG;
+	if (h->rec_counts.size() != (size_t)h->cfg.size) return fail(h, RG_ERR_STATE, "rg_record_counts needs rg_records_local first");
+	for (int r = 0; r < h->cfg.size; ++r) counts[r] = h->rec_counts[r];
+	if (record_bytes) *record_bytes = (uint32_t)(8 * (2 * h->W + 1));
+	return RG_OK;
+}
+
+int rg_export_records(rg_handle *h, void *d_out, uint64_t capacity_records) {
+	if (!h) return RG_ERR_ARG;
+	if (h->rec_counts.size() != (size_t)h->cfg.size) return fail(h, RG_ERR_STATE, "rg_export_records needs rg_records_local first");
+	uint64_t total = 0;
+	for (uint64_t c : h->rec_counts) total += c;
+	if (total > capacity_records) return fail(h, RG_ERR_CAPACITY, "record buffer holds %llu records, need %llu", (unsigned long long)capacity_records, (unsigned long long)total);
+	if (total && !d_out) return fail(h, RG_ERR_ARG, "null record buffer");
+	HIP_TRY(h, hipSetDevice(h->cfg.device));
+	return h->W == 1 ? export_records_t<1>(h, d_out) : export_records_t<2>(h, d_out);
+}
+
+int rg_count_records(rg_handle *h, const void *d_records, uint64_t n_records) {
+	if (h) h->hist_valid = false;
+	if (!h || (n_records && !d_records)) return RG_ERR_ARG;
+	if (h->phase != PH_CREATED) return fail(h, RG_ERR_STATE, "rg_count_records called after counting started");
+	if (h->cfg.size == 1) return fail(h, RG_ERR_STATE, "rg_count_records is for size > 1 (use rg_count_kmers)");
+	HIP_TRY(h, hipSetDevice(h->cfg.device));
+	Slot *log = nullptr;
+	uint64_t n_log = 0;
+	bool ok = false;
+	const uint32_t flags = (uint32_t)h->cfg.reserved0 & 0xFFu;
+	if (!(flags & 2u)) {
+		int rc = sweep_partitioned(h, &log, &n_log, &ok, d_records ? d_records : (const void *)h /* non-null, never read */, n_records);
+		if (rc) return rc;
+	}
+	if (ok) {
+		h->stats.sweep_partitioned = 1;
+		h->local.slots = log;  // the log plays the local table's role: a flat array of entries
+		h->local.cap = n_log;
+		h->local.fill_known = n_log;
+		h->local.fill_pending = 0;
+	} else {
+		// an estimate was exceeded (or the direct route was asked for): one table upsert per occurrence
+		const int w = h->cfg.k - std::min(h->cfg.k, MMER_MAX) + 1;
+		int rc = table_reserve(h, h->local, std::max<uint64_t>(1, n_records * (uint64_t)w), C_FILL_LOCAL);
+		if (rc) return rc;
+		if (n_records) {
+			ProfScope ps(h, "k_count_records");
+			if (h->W == 1) hipLaunchKernelGGL(k_count_records<1>, dim3(grid_for(n_records)), dim3(256), 0, h->stream, (const Rec<1> *)d_records, n_records, h->cfg.k, h->local.slots, h->local.cap - 1, h->d_counters, (int)C_FILL_LOCAL);
+			else hipLaunchKernelGGL(k_count_records<2>, dim3(grid_for(n_records)), dim3(256), 0, h->stream, (const Rec<2> *)d_records, n_records, h->cfg.k, h->local.slots, h->local.cap - 1, h->d_counters, (int)C_FILL_LOCAL);
+			HIP_TRY(h, hipGetLastError());
+		}
+		rc = sync_counters(h);
+		if (rc) return rc;
+		h->local.fill_known = h->h_counters[C_FILL_LOCAL];
+		h->local.fill_pending = 0;
+	}
+	h->phase = PH_COUNTED_LOCAL;
+	return RG_OK;
+}
+
 int rg_owner_counts(rg_handle *h, uint64_t *counts) {
 	if (!h || !counts) return RG_ERR_ARG;
 	if (h->phase != PH_COUNTED_LOCAL) return fail(h, RG_ERR_STATE, "rg_owner_counts needs rg_count_local first");
@@ -1598,8 +1830,8 @@ int rg_export_owner_buckets(rg_handle *h, void *d_out, uint64_t capacity_entries
 	if (total == 0) return RG_OK;
 	if (!d_out) return fail(h, RG_ERR_ARG, "null bucket buffer");
 	HIP_TRY(h, hipMemcpyAsync(h->d_owner + size, cursors.data(), sizeof(unsigned long long) * size, hipMemcpyHostToDevice, h->stream));
-	if (h->W == 1) hipLaunchKernelGGL(k_owner_scatter<1>, dim3(grid_for(T.cap)), dim3(BLOCK), 0, h->stream, T.slots, T.cap, size, h->d_owner + size, (Slot *)d_out);
-	else hipLaunchKernelGGL(k_owner_scatter<2>, dim3(grid_for(T.cap)), dim3(BLOCK), 0, h->stream, T.slots, T.cap, size, h->d_owner + size, (Slot *)d_out);
+	if (h->W == 1) hipLaunchKernelGGL(k_owner_scatter<1>, dim3(grid_for(T.cap)), dim3(BLOCK), size * 12, h->stream, T.slots, T.cap, size, h->d_owner + size, (Slot *)d_out);
+	else hipLaunchKernelGGL(k_owner_scatter<2>, dim3(grid_for(T.cap)), dim3(BLOCK), size * 12, h->stream, T.slots, T.cap, size, h->d_owner + size, (Slot *)d_out);
 	HIP_TRY(h, hipGetLastError());
 	HIP_TRY(h, hipStreamSynchronize(h->stream));
 	return RG_OK;

@@ -140,7 +140,9 @@ __global__ __launch_bounds__(256) void k_superkmers(const uint64_t *__restrict__
                                                     const uint32_t *__restrict__ lengths, uint64_t nreads, uint64_t read_id_base,
                                                     int k, int m, Rec<W> *__restrict__ recs, uint64_t rec_cap,
                                                     unsigned long long *__restrict__ counters,
-                                                    unsigned long long *__restrict__ coarse_hist) {
+                                                    unsigned long long *__restrict__ coarse_hist, uint32_t modulo) {
+	// coarse_hist[256]: records per first-level digit (top 8 bits of the bucket), or, with modulo != 0, per
+	// destination rank bucket % modulo (record exchange between ranks, modulo <= 256)
 	constexpr int NB = 2 * W;
 	__shared__ uint32_t s_x[4][2][SK_XPAD];
 	__shared__ uint32_t s_cn[4][SK_X];
@@ -316,7 +318,8 @@ __global__ __launch_bounds__(256) void k_superkmers(const uint64_t *__restrict__
 							rec.w[NB] = (uint64_t)p | ((uint64_t)(len - 1) << 16) | ((uint64_t)hasL << 22) | ((uint64_t)hasR << 23) |
 							            ((uint64_t)moff << 24) | rid;
 							recs[chunk_base + chunk_used + idx] = rec;
-							atomicAdd(&s_hist[bucket24(cn[jm]) >> 16], 1u);
+							const uint32_t bk = bucket24(cn[jm]);
+							atomicAdd(&s_hist[modulo ? bk % modulo : bk >> 16], 1u);
 						}
 					}
 				chunk_used += c;
@@ -353,7 +356,8 @@ template <int W>
 __global__ __launch_bounds__(256) void k_scatter(const Rec<W> *__restrict__ in, int m, uint32_t S,
                                                  const unsigned long long *__restrict__ seg_begin,
                                                  const uint32_t *__restrict__ tile_first, int shift, int dbits,
-                                                 unsigned long long *__restrict__ cursors, Rec<W> *__restrict__ out) {
+                                                 unsigned long long *__restrict__ cursors, Rec<W> *__restrict__ out, uint32_t modulo) {
+	// modulo != 0: the digit is bucket % modulo (destination rank of the record exchange) instead of bits of the bucket
 	constexpr int NB = 2 * W, PER = SCATTER_TILE / 256;
 	__shared__ Rec<W> s_rec[SCATTER_TILE];
 	__shared__ uint8_t s_dig[SCATTER_TILE];
@@ -376,7 +380,8 @@ __global__ __launch_bounds__(256) void k_scatter(const Rec<W> *__restrict__ in, 
 		if (i < end) {
 			mine[j] = in[i];
 			if (mine[j].w[NB] != REC_INVALID) {
-				dig[j] = (rec_bucket<W>(mine[j], m) >> shift) & dmask;
+				const uint32_t bk = rec_bucket<W>(mine[j], m);
+				dig[j] = modulo ? bk % modulo : (bk >> shift) & dmask;
 				rank[j] = atomicAdd(&s_cnt[dig[j]], 1u);
 			}
 		}
@@ -867,6 +872,71 @@ __global__ __launch_bounds__(64 * AGG_WAVES) void k_aggregate(const Rec<W> *__re
 	if (chunk_base != NO_CHUNK)
 		for (uint32_t i = chunk_used + lane; i < LOG_CHUNK; i += 64)
 			if (chunk_base + i < log_cap) log[chunk_base + i].k0 = EMPTY;
+}
+
+// Fallback of the record path: every k-mer of every record goes straight to the vertex table (one upsert per
+// occurrence), used when an estimate of the partitioned path was exceeded.
+template <int W>
+__global__ __launch_bounds__(256) void k_count_records(const Rec<W> *__restrict__ recs, uint64_t n, int k, Slot *__restrict__ tab,
+                                                       uint64_t mask, unsigned long long *__restrict__ counters, int c_fill) {
+	constexpr int NB = 2 * W;
+	__shared__ uint32_t s_claimed;
+	if (threadIdx.x == 0) s_claimed = 0;
+	__syncthreads();
+	const uint64_t mask0 = (2 * k >= 64) ? ~0ull : ((1ull << (2 * k)) - 1);
+	const uint64_t mask1 = (k > 32) ? ((1ull << (2 * k - 64)) - 1) : 0ull;
+	uint32_t claimed = 0;
+	bool failed = false;
+	for (uint64_t ri = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; ri < n; ri += (uint64_t)gridDim.x * blockDim.x) {
+		const Rec<W> rec = recs[ri];
+		if (rec.w[NB] == REC_INVALID) continue;
+		uint64_t bw[NB];
+#pragma unroll
+		for (int i = 0; i < NB; ++i) bw[i] = rec.w[i];
+		const uint64_t hdr = rec.w[NB];
+		const uint32_t len = ((uint32_t)(hdr >> 16) & 63u) + 1;
+		const uint32_t hasL = (uint32_t)(hdr >> 22) & 1u, hasR = (uint32_t)(hdr >> 23) & 1u;
+		const uint64_t stamp0 = ((hdr >> 31) << 16) | ((uint32_t)hdr & 0xFFFFu);
+		uint64_t f0 = rec_ext<W>(bw, hasL) & mask0, f1 = 0;
+		if (W == 2 && k > 32) f1 = rec_ext<W>(bw, hasL + 32) & mask1;
+		uint64_t r0, r1;
+		revcomp<W>(f0, f1, k, r0, r1);
+		uint32_t prev = hasL ? (uint32_t)bw[0] & 3u : 0;
+		bool prev_valid = hasL;
+		for (uint32_t i = 0; i < len; ++i) {
+			const bool has_next = (i + 1 < len) || hasR;
+			const uint32_t nb = has_next ? rec_base<W>(bw, hasL + i + (uint32_t)k) : 0;
+			const bool use_rc = kmer_less<W>(r0, r1, f0, f1);
+			uint32_t em = 0;
+			if (prev_valid) em = 1u << (use_rc ? 7u - prev : prev);
+			if (has_next) em |= 1u << (use_rc ? 3u - nb : 4u + nb);
+			uint64_t i0, i1;
+			to_internal<W>(use_rc ? r0 : f0, use_rc ? r1 : f1, i0, i1);
+			if (!upsert<W>(tab, mask, i0, i1, stamp0 + i, 1ull, em, claimed)) failed = true;
+			prev = (uint32_t)f0 & 3u;
+			prev_valid = true;
+			if (i + 1 < len) {
+				if (W == 1) {
+					f0 = (f0 >> 2) | ((uint64_t)nb << (2 * (k - 1)));
+					r0 = ((r0 << 2) | (uint64_t)(3u - nb)) & mask0;
+				} else {
+					f0 = (f0 >> 2) | (f1 << 62);
+					if (k > 32) {
+						f1 = (f1 >> 2) | ((uint64_t)nb << (2 * (k - 1) - 64));
+						r1 = ((r1 << 2) | (r0 >> 62)) & mask1;
+						r0 = (r0 << 2) | (uint64_t)(3u - nb);
+					} else {
+						f0 |= (uint64_t)nb << (2 * (k - 1));
+						r0 = ((r0 << 2) | (uint64_t)(3u - nb)) & mask0;
+					}
+				}
+			}
+		}
+	}
+	if (claimed) atomicAdd(&s_claimed, claimed);
+	__syncthreads();
+	if (threadIdx.x == 0 && s_claimed) atomicAdd(&counters[c_fill], (unsigned long long)s_claimed);
+	if (failed) atomicAdd(&counters[1 /*C_ERR*/], 1ull);
 }
 
 }  // namespace rg

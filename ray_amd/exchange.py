@@ -76,6 +76,25 @@ def _all_to_all_bytes(send, send_counts, unit, group, device, staged):
     return recv, recv_counts
 
 
+def exchange_records(engine, group=None, device="cuda"):
+    """first exchange of the preferred multi-GPU route: the local reads cut into super-k-mer records go to the
+    rank that aggregates their bucket, which then counts them; follow with exchange_owner_buckets().
+    Returns (records sent, records received)."""
+    engine.records_local()
+    counts, unit = engine.record_counts()
+    total = sum(counts)
+    send = torch.empty(max(1, total) * unit, dtype=torch.uint8, device=device)
+    engine.export_records(send.data_ptr(), max(1, total))
+    staged = _staged(group) and str(device) != "cpu"
+    recv, recv_counts = _all_to_all_bytes(send, counts, unit, group, device, staged)
+    del send
+    n_recv = sum(recv_counts)
+    if str(device) != "cpu":
+        torch.cuda.current_stream().synchronize()
+    engine.count_records(recv.data_ptr(), n_recv)
+    return total, n_recv
+
+
 def purge_edges_distributed(engine, group=None, device="cuda"):
     """RAY_SLAVE_MODE_PURGE_NULL_EDGES across ranks: one all-to-all of neighbour keys, one of one-byte
     answers back (EdgePurgerWorker.cpp:28-102 asks one key per message, MessageProcessor.cpp:1224-1256

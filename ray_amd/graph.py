@@ -190,6 +190,23 @@ class GraphBuilder:
     def count_local(self):
         self._check(self._L.rg_count_local(self._h))
 
+    # -- record exchange (exchange.exchange_records drives these)
+    def records_local(self):
+        self._check(self._L.rg_records_local(self._h))
+
+    def record_counts(self):
+        """(records per destination rank, bytes per record)"""
+        out = (C.c_uint64 * self.size)()
+        nb = C.c_uint32()
+        self._check(self._L.rg_record_counts(self._h, out, C.byref(nb)))
+        return [int(x) for x in out], nb.value
+
+    def export_records(self, device_ptr, capacity_records):
+        self._check(self._L.rg_export_records(self._h, device_ptr, capacity_records))
+
+    def count_records(self, device_ptr, n_records):
+        self._check(self._L.rg_count_records(self._h, device_ptr, n_records))
+
     def owner_counts(self):
         out = (C.c_uint64 * self.size)()
         self._check(self._L.rg_owner_counts(self._h, out))

@@ -99,6 +99,39 @@ class ModelEngine:
         if self.size == 1:
             self.table = self.local
 
+    # ---- record exchange surface: here a "record" is one locally aggregated 32-byte entry and its destination
+    # any function of the key (the product sends super-k-mer records by minimizer bucket: invisible in results)
+    def _dest(self, key):
+        return self.ro.hash2(key, self.W) % self.size
+
+    def records_local(self):
+        self._rec = [[] for _ in range(self.size)]
+        for key, (stamp, count, em) in self.local.items():
+            i0, i1 = to_internal(key[0], key[1], self.W)
+            self._rec[self._dest(key)].append((i0, i1, stamp, count | (em << 48)))
+        self.local = {}
+
+    def record_counts(self):
+        return [len(r) for r in self._rec], ENTRY.itemsize
+
+    def export_records(self, ptr, capacity):
+        flat = [e for per in self._rec for e in per]
+        assert len(flat) <= capacity
+        out = np.array(flat, dtype=ENTRY) if flat else np.zeros(0, dtype=ENTRY)
+        if len(flat):
+            C.memmove(ptr, out.ctypes.data, out.nbytes)
+
+    def count_records(self, ptr, n):
+        self.local = {}
+        if n:
+            buf = (C.c_uint8 * (n * ENTRY.itemsize)).from_address(ptr)
+            for k0, k1, stamp, meta in np.frombuffer(buf, dtype=ENTRY).tolist():
+                key = from_internal(k0, k1, self.W)
+                e = self.local.setdefault(key, [stamp, 0, 0])
+                e[0] = min(e[0], stamp)
+                e[1] += meta & COUNT_MASK
+                e[2] |= (meta >> 48) & 0xFF
+
     def _owner(self, key):
         return self.ro.hash1(key, self.W) % self.size
 

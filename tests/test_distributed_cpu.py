@@ -11,13 +11,14 @@ import torch.multiprocessing as mp
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _worker(rank, world, port, k, bloom, out_dir):
+def _worker(rank, world, port, k, bloom, out_dir, route):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
     import torch.distributed as dist
     from model import ModelEngine
     from oracle import ray_oracle as ro
-    from ray_amd.exchange import exchange_owner_buckets, partition_reads, purge_edges_distributed, reduce_histogram
+    from ray_amd.exchange import (exchange_owner_buckets, exchange_records, partition_reads, purge_edges_distributed,
+                                  reduce_histogram)
     from ray_amd.synth import make_reads_numpy
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -27,7 +28,12 @@ def _worker(rank, world, port, k, bloom, out_dir):
     first, last = partition_reads(len(lengths), rank, world)
     e = ModelEngine(ro, k, rank, world, bloom, first_read_id=first)
     e.add_reads(packed, offsets[first:last], lengths[first:last])
-    e.count_local()
+    if route == "records":   # records to the rank that aggregates their bucket, then entries to their owners
+        n_local = len(e.local)
+        sent, received = exchange_records(e, device="cpu")
+        assert sent == n_local
+    else:                    # every rank aggregates its own reads, then entries to their owners
+        e.count_local()
     sent, received = exchange_owner_buckets(e, device="cpu")
     assert sent == len(e.local)
     e.resolve_admission(last - first)
@@ -42,13 +48,13 @@ def _worker(rank, world, port, k, bloom, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("k,bloom", [(21, 4000), (21, None)])
-def test_two_rank_exchange_over_gloo(oracle, tmp_path, k, bloom):
+@pytest.mark.parametrize("k,bloom,route", [(21, 4000, "entries"), (21, None, "records")])
+def test_two_rank_exchange_over_gloo(oracle, tmp_path, k, bloom, route):
     sys.path.insert(0, HERE)
     from helpers import assert_records_equal, oracle_run
     from ray_amd.synth import make_reads_numpy
     port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_worker, args=(2, port, k, bloom, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, k, bloom, str(tmp_path), route), nprocs=2, join=True)
     packed, offsets, lengths = make_reads_numpy(genome=1200, read_len=60, n_reads=151, seed=77, error=0.02)
     want = oracle_run(oracle, packed, offsets, lengths, k, 2, bloom)
     for r in range(2):

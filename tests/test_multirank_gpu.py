@@ -12,23 +12,47 @@ from ray_amd.synth import make_reads_numpy
 pytestmark = pytest.mark.gpu
 
 
-def run_ranks(packed, offsets, lengths, k, nranks, bloom, W=0, sweep=0):
+def run_ranks(packed, offsets, lengths, k, nranks, bloom, W=0, sweep=0, route="entries"):
+    """route "entries": every rank aggregates its own reads, then the entries go to their owners;
+    route "records": the super-k-mer records go to the rank that aggregates their bucket first (the preferred
+    multi-GPU route), then the entries go to their owners"""
     import torch
     import ray_amd
     from ray_amd.graph import RG_BLOOM_DEFAULT, RG_ENTRY_BYTES
     n = len(lengths)
-    builders, sends = [], []
+    builders = []
     for r in range(nranks):
         first, last = partition_reads(n, r, nranks)
         b = ray_amd.GraphBuilder(k, rank=r, size=nranks, bloom_bits=RG_BLOOM_DEFAULT if bloom is None else bloom,
                                  kmer_words=W, first_read_id=first, sweep=sweep)
         b.add_reads(packed, offsets[first:last], lengths[first:last])
-        b.count_local()
+        builders.append(b)
+    if route == "records":
+        sent = []
+        for b in builders:
+            b.records_local()
+            counts, unit = b.record_counts()
+            buf = torch.empty(max(1, sum(counts)) * unit, dtype=torch.uint8, device="cuda")
+            b.export_records(buf.data_ptr(), max(1, sum(counts)))
+            sent.append((counts, buf, unit))
+        assert sum(sum(c) for c, _, _ in sent) > 0
+        for dst, b in enumerate(builders):
+            parts = []
+            for counts, buf, unit in sent:
+                start = sum(counts[:dst])
+                parts.append(buf[start * unit:(start + counts[dst]) * unit])
+            recv = torch.cat(parts) if parts else torch.empty(0, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            b.count_records(recv.data_ptr() if recv.numel() else 0, recv.numel() // sent[0][2])
+    else:
+        for b in builders:
+            b.count_local()
+    sends = []
+    for b in builders:
         counts = b.owner_counts()
         buf = torch.empty(max(1, sum(counts)) * RG_ENTRY_BYTES, dtype=torch.uint8, device="cuda")
         b.export_owner_buckets(buf.data_ptr(), max(1, sum(counts)))
         torch.cuda.synchronize()
-        builders.append(b)
         sends.append((counts, buf))
     for dst, b in enumerate(builders):
         for counts, buf in sends:
@@ -47,9 +71,9 @@ def test_multirank_matches_oracle(oracle, k, nranks, bloom):
     packed, offsets, lengths = make_reads_numpy(genome=15000, read_len=100 if k < 63 else 150, n_reads=5001,
                                                 seed=k + nranks, error=0.015)
     want = oracle_run(oracle, packed, offsets, lengths, k, nranks, bloom)
-    for sweep in (1 | 16 | (17 << 8), 2 | 32):
-        builders = run_ranks(packed, offsets, lengths, k, nranks, bloom, sweep=sweep)
-        check_ranks(builders, want)
+    for sweep, route in ((1 | 16 | (17 << 8), "entries"), (2 | 32, "entries"), (1 | 16 | (10 << 8), "records"), (2 | 32, "records")):
+        builders = run_ranks(packed, offsets, lengths, k, nranks, bloom, sweep=sweep, route=route)
+        check_ranks(builders, want, route)
     # RAY_SLAVE_MODE_PURGE_NULL_EDGES across ranks: keys to the owners, one-byte answers back
     want["graph"].purge_edges()
     purge_ranks(builders)
@@ -81,9 +105,10 @@ def purge_ranks(builders):
         b.purge_apply(back.data_ptr(), sum(asked[src][0]))
 
 
-def check_ranks(builders, want):
+def check_ranks(builders, want, route=""):
+    assert sum(b.stats()["occurrences"] for b in builders) == want["occ"]
     for r, b in enumerate(builders):
-        assert_records_equal(b.export(), want["graph"].export(r), "rank %d" % r)
+        assert_records_equal(b.export(), want["graph"].export(r), "%s rank %d" % (route, r))
         st = b.stats()
         assert (st["bloom_bits"], st["bloom_set_bits"], st["bloom_insertions"]) == want["bloom"][r]
     # merged histogram, as rank 0 accumulates RAY_MPI_TAG_COVERAGE_DATA (MessageProcessor.cpp:1048-1061)
