@@ -192,9 +192,9 @@ __global__ __launch_bounds__(BLOCK) void k_merge(const Slot *__restrict__ in, ui
 	for (; i < n; i += stride) {
 		Slot v = in[i];
 		if (v.k0 == EMPTY) continue;  // unused entry of a log chunk
-		uint64_t add = v.meta & COUNT_MASK;
+		uint64_t add = v.meta & COUNT_MASK & ~LOG_UNIQUE;
 		uint32_t em = (uint32_t)(v.meta >> PEND_SHIFT) & 0xFFu;
-		if (!upsert<W>(tab, mask, v.k0, W == 2 ? v.k1 : 0, v.stamp, add, em, claimed)) failed = true;
+		if (!upsert<W>(tab, mask, v.k0, W == 2 ? v.k1 : 0, v.stamp, add, em, claimed, (v.meta & LOG_UNIQUE) != 0)) failed = true;
 	}
 	if (claimed) atomicAdd(&s_claimed, claimed);
 	__syncthreads();
@@ -1218,8 +1218,10 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	}
 	{
 		ProfScope ps(h, "k_aggregate");
+		// entries may be marked unique unless other ranks aggregate the same keys (entry route, size > 1)
+		const uint32_t flag_unique = (h->cfg.size == 1 || ext) ? 1u : 0u;
 		hipLaunchKernelGGL(k_aggregate<W>, dim3(agg_grid), dim3(256), 0, h->stream, level_in, d_begin, (uint32_t)NBUCK, k, log, log_cap,
-		                   h->d_counters);
+		                   h->d_counters, flag_unique);
 	}
 	hipError_t e = hipGetLastError();
 	if (e == hipSuccess) rc = sync_counters(h);

@@ -20,6 +20,8 @@ static constexpr uint64_t EMPTY = ~0ull;      // key word of a free slot
 static constexpr uint64_t INF_STAMP = ~0ull;  // "never arrived"
 static constexpr uint64_t COUNT_MASK = (1ull << 48) - 1;
 static constexpr int PEND_SHIFT = 48;
+// log entries only (never stored in a table): this key occurs in no other entry of the log it travels in
+static constexpr uint64_t LOG_UNIQUE = 1ull << 47;
 static constexpr int PUB_SHIFT = 56;
 static constexpr uint32_t MAX_PROBE = 1u << 22;  // exit condition every lane reaches
 
@@ -163,18 +165,20 @@ __host__ __device__ inline uint32_t convert_bitmap(uint32_t m) {
 // changes EMPTY -> key, stamps only fall, edge bits only rise; a stale EMPTY is settled by the CAS.
 template <int W>
 __device__ __forceinline__ bool upsert(Slot *__restrict__ tab, uint64_t mask, uint64_t i0, uint64_t i1,
-                                       uint64_t stamp, uint64_t add, uint32_t emask, uint32_t &claimed) {
+                                       uint64_t stamp, uint64_t add, uint32_t emask, uint32_t &claimed, bool unique = false) {
 	uint64_t s = slot_hash<W>(i0, i1) & mask;
 	for (uint32_t probe = 0; probe < MAX_PROBE; ++probe) {
 		Slot *p = tab + s;
 		ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(&p->k0);
 		ulonglong2 b = *reinterpret_cast<const ulonglong2 *>(&p->stamp);
 		uint64_t c0 = a.x;
+		bool fresh = false;  // this call made the slot this key's
 		if (c0 == EMPTY) {
 			uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long *>(&p->k0), EMPTY, i0);
 			if (prev == EMPTY) {
 				claimed++;
 				c0 = i0;
+				fresh = (W == 1);
 			} else {
 				c0 = prev;
 			}
@@ -186,10 +190,17 @@ __device__ __forceinline__ bool upsert(Slot *__restrict__ tab, uint64_t mask, ui
 				if (c1 == EMPTY) {
 					uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long *>(&p->k1), EMPTY, i1);
 					c1 = (prev == EMPTY) ? i1 : prev;
+					fresh = (prev == EMPTY);  // whoever sets word 1 owns the slot's key
 				}
 				match = (c1 == i1);
 			}
 			if (match) {
+				if (unique && fresh) {
+					// no other entry of this launch carries the key and the table did not hold it: nobody else
+					// touches the payload, one plain 16-byte store replaces three atomics
+					*reinterpret_cast<ulonglong2 *>(&p->stamp) = make_ulonglong2(stamp, add | ((uint64_t)emask << PEND_SHIFT));
+					return true;
+				}
 				if (stamp < b.x) atomicMin(reinterpret_cast<unsigned long long *>(&p->stamp), stamp);
 				uint32_t pend = (uint32_t)(b.y >> PEND_SHIFT) & 0xFFu;
 				if (emask & ~pend) atomicOr(reinterpret_cast<unsigned long long *>(&p->meta), (uint64_t)emask << PEND_SHIFT);

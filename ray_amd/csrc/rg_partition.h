@@ -117,7 +117,10 @@ enum PartCounter { PC_REC_CURSOR = 16, PC_REC_OVF, PC_LOG_CURSOR, PC_LOG_OVF, PC
 // offsets arrive in one coalesced load) and walks them one by one, SK_STEP k-mer positions per step,
 // every lane owning two positions.  Per step:
 //   1. the words of the read that the step needs are staged in LDS (one lane per 32-bit word),
-//   2. every m-mer is made canonical and mixed once: x[j] = (24 bits of a bijective mix) | j,
+//   2. every m-mer is made canonical and mixed once: x[j] = (32-bit bijective mix) << 32 | j.  The order is
+//      total on canonical m-mers (equal mix = equal m-mer), so the minimizer of a k-mer, hence its bucket,
+//      depends on the k-mer alone and not on the strand or the read it was seen in: every k-mer lives in
+//      exactly one bucket (k_aggregate / k_merge rely on it for their unique-entry fast path),
 //   3. the minimum of each window of w = k-m+1 entries comes from a sparse table built with
 //      floor(log2 w) doubling passes over LDS instead of w reads per position,
 //   4. a record starts wherever the minimizer *occurrence* changes (so a record never holds more than
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(256) void k_superkmers(const uint64_t *__restrict__
 	// coarse_hist[256]: records per first-level digit (top 8 bits of the bucket), or, with modulo != 0, per
 	// destination rank bucket % modulo (record exchange between ranks, modulo <= 256)
 	constexpr int NB = 2 * W;
-	__shared__ uint32_t s_x[4][2][SK_XPAD];
+	__shared__ unsigned long long s_x[4][2][SK_XPAD];
 	__shared__ uint32_t s_cn[4][SK_X];
 	__shared__ uint32_t s_wd[4][SK_WORDS];
 	__shared__ uint32_t s_list[4][SK_STEP + 4];
@@ -155,8 +158,8 @@ __global__ __launch_bounds__(256) void k_superkmers(const uint64_t *__restrict__
 	uint32_t *const cn = s_cn[wave];
 	uint32_t *const list = s_list[wave];
 	s_hist[threadIdx.x] = 0;
-	s_x[wave][0][SK_X + lane] = 0xFFFFFFFFu;
-	s_x[wave][1][SK_X + lane] = 0xFFFFFFFFu;
+	s_x[wave][0][SK_X + lane] = ~0ull;
+	s_x[wave][1][SK_X + lane] = ~0ull;
 	__syncthreads();
 	const uint32_t w = (uint32_t)(k - m + 1);
 	const uint32_t maskm = (1u << (2 * m)) - 1;
@@ -203,10 +206,10 @@ __global__ __launch_bounds__(256) void k_superkmers(const uint64_t *__restrict__
 				// canonical m-mers p0 .. p0+need-1, mixed
 				const uint32_t need = cnt + w - 1;
 				const uint32_t mb = sh + 2u * (p0 - fb);  // bit of m-mer 0 of the step
-				uint32_t x[3];
+				unsigned long long x[3];
 #pragma unroll
 				for (uint32_t e = 0; e < 3; ++e) {
-					x[e] = 0xFFFFFFFFu;
+					x[e] = ~0ull;
 					if (64u * e < need) {
 						const uint32_t j = lane + 64u * e;
 						uint32_t c = 0;
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(256) void k_superkmers(const uint64_t *__restrict__
 							y = ((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1);
 							const uint32_t rc = (~y) >> rshift;
 							c = f < rc ? f : rc;
-							x[e] = (order_mix(c) & ~255u) | j;
+							x[e] = ((unsigned long long)order_mix(c) << 32) | j;
 						}
 						s_x[wave][0][j] = x[e];
 						cn[j] = c;
@@ -230,13 +233,13 @@ __global__ __launch_bounds__(256) void k_superkmers(const uint64_t *__restrict__
 					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 					__builtin_amdgcn_wave_barrier();
 					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-					const uint32_t *src = s_x[wave][cur];
-					uint32_t *dst = s_x[wave][cur ^ 1u];
+					const unsigned long long *src = s_x[wave][cur];
+					unsigned long long *dst = s_x[wave][cur ^ 1u];
 #pragma unroll
 					for (uint32_t e = 0; e < 3; ++e)
 						if (64u * e < need) {
 							const uint32_t j = lane + 64u * e;
-							const uint32_t o = src[j + s];
+							const unsigned long long o = src[j + s];
 							x[e] = o < x[e] ? o : x[e];
 							dst[j] = x[e];
 						}
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(256) void k_superkmers(const uint64_t *__restrict__
 				__builtin_amdgcn_wave_barrier();
 				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 				// s is now the largest power of two <= w: window [p, p+w) = [p, p+s) u [p+w-s, p+w)
-				const uint32_t *tab = s_x[wave][cur];
+				const unsigned long long *tab = s_x[wave][cur];
 				const uint32_t tail = w - s;
 				uint32_t jr[2];
 				bool act[2];
@@ -254,9 +257,9 @@ __global__ __launch_bounds__(256) void k_superkmers(const uint64_t *__restrict__
 				for (uint32_t e = 0; e < 2; ++e) {
 					const uint32_t p = lane + 64u * e;
 					act[e] = p < cnt;
-					const uint32_t o = tab[p + tail];
-					const uint32_t v = o < x[e] ? o : x[e];
-					jr[e] = v & 255u;  // where the minimizer of k-mer p0+p starts, relative to p0
+					const unsigned long long o = tab[p + tail];
+					const unsigned long long v = o < x[e] ? o : x[e];
+					jr[e] = (uint32_t)v & 255u;  // where the minimizer of k-mer p0+p starts, relative to p0
 				}
 				uint32_t prev0 = __shfl_up(jr[0], 1);
 				uint32_t prev1 = __shfl_up(jr[1], 1);
@@ -527,6 +530,7 @@ struct AggTable {
 	uint32_t edges[AGG_SLOTS];
 	uint16_t list[AGG_SLOTS];
 	uint32_t fill;
+	uint32_t spilled;  // a k-mer of the current bucket went to the log on its own (table full)
 };
 
 template <int W>
@@ -596,7 +600,10 @@ template <int W>
 __global__ __launch_bounds__(64 * AGG_WAVES) void k_aggregate(const Rec<W> *__restrict__ recs,
                                                               const unsigned long long *__restrict__ bucket_begin, uint32_t nbuckets,
                                                               int k, Slot *__restrict__ log, uint64_t log_cap,
-                                                              unsigned long long *__restrict__ counters) {
+                                                              unsigned long long *__restrict__ counters, uint32_t flag_unique) {
+	// flag_unique: the caller guarantees that nothing outside this launch's log carries the same keys on their way
+	// to the same table; entries of a bucket that was flushed exactly once are then marked LOG_UNIQUE (every k-mer
+	// lives in exactly one bucket, see k_superkmers)
 	constexpr int NB = 2 * W;
 	__shared__ AggTable<W> s_tables[AGG_WAVES];
 	__shared__ RecTable<W> s_rtables[AGG_WAVES];
@@ -608,12 +615,16 @@ __global__ __launch_bounds__(64 * AGG_WAVES) void k_aggregate(const Rec<W> *__re
 	const unsigned long long NO_CHUNK = ~0ull;
 	unsigned long long chunk_base = NO_CHUNK;  // wave-uniform
 	uint32_t chunk_used = 0;
+	uint32_t bucket_flushes = 0;  // flushes of the current bucket so far (wave-uniform)
 
 	// flush() and expand() are wave-uniform: their conditions come from fill counters read after wave_sync().
 	// flush: the k-mer table's entries continue the wavefront's current log chunk and spill over into a new one.
-	auto flush = [&]() {
+	auto flush = [&](bool last) {
 		const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)T.fill);
 		if (n == 0) return;
+		const uint64_t mark = (flag_unique && last && bucket_flushes == 0 &&
+		                       __builtin_amdgcn_readfirstlane((int)T.spilled) == 0) ? LOG_UNIQUE : 0ull;
+		bucket_flushes++;
 		const uint32_t room = (chunk_base == NO_CHUNK) ? 0u : LOG_CHUNK - chunk_used;
 		const unsigned long long old_dst = chunk_base + chunk_used;
 		unsigned long long new_dst = 0;
@@ -632,7 +643,7 @@ __global__ __launch_bounds__(64 * AGG_WAVES) void k_aggregate(const Rec<W> *__re
 				e.k0 = T.k0[sl];
 				e.k1 = (W == 2) ? T.k1[sl] : EMPTY;
 				e.stamp = T.stamp[sl];
-				e.meta = (uint64_t)T.cnt[sl] | ((uint64_t)(T.edges[sl] & 0xFFu) << PEND_SHIFT);
+				e.meta = (uint64_t)T.cnt[sl] | ((uint64_t)(T.edges[sl] & 0xFFu) << PEND_SHIFT) | mark;
 				log[dst] = e;
 			}
 			T.k0[sl] = EMPTY;
@@ -720,6 +731,7 @@ __global__ __launch_bounds__(64 * AGG_WAVES) void k_aggregate(const Rec<W> *__re
 						atomicAdd(&counters[PC_LOG_OVF], 1ull);
 					}
 					atomicAdd(&counters[PC_LDS_SPILL], 1ull);
+					T.spilled = 1;
 				}
 				// roll to the next k-mer
 				prev = (uint32_t)f0 & 3u;
@@ -746,7 +758,7 @@ __global__ __launch_bounds__(64 * AGG_WAVES) void k_aggregate(const Rec<W> *__re
 				for (uint32_t i = 0; i < rmax; ++i) {
 					if (i < len) step(i);
 					wave_sync();
-					if ((uint32_t)__builtin_amdgcn_readfirstlane((int)T.fill) > AGG_FLUSH) flush();
+					if ((uint32_t)__builtin_amdgcn_readfirstlane((int)T.fill) > AGG_FLUSH) flush(false);
 				}
 			}
 		}
@@ -768,6 +780,7 @@ __global__ __launch_bounds__(64 * AGG_WAVES) void k_aggregate(const Rec<W> *__re
 	}
 	if (lane == 0) {
 		T.fill = 0;
+		T.spilled = 0;
 		R.fill = 0;
 	}
 	wave_sync();
@@ -863,7 +876,9 @@ __global__ __launch_bounds__(64 * AGG_WAVES) void k_aggregate(const Rec<W> *__re
 			if ((uint32_t)__builtin_amdgcn_readfirstlane((int)R.fill) > RT_FLUSH) expand();
 		}
 		expand();
-		flush();
+		flush(true);
+		bucket_flushes = 0;
+		if (lane == 0) T.spilled = 0;
 		b = b2;
 		cb = nb_begin;
 		ce = nb_end;
