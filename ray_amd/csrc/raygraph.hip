@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -1476,9 +1477,24 @@ static int bloom_partitioned(rg_handle *h, uint64_t m_bits, uint64_t keys, bool 
 	BTRY(hipMemsetAsync(h->d_counters + C_SETBITS, 0, sizeof(unsigned long long), h->stream));
 	{
 		ProfScope ps(h, "k_bloom_region");
-		const unsigned grid = (unsigned)std::min<uint64_t>(NBUCK, (uint64_t)n_cu);
-		if (h->W == 1) hipLaunchKernelGGL(k_bloom_region<1>, dim3(grid), dim3(512), 0, h->stream, bufs[cur], d_begin, (uint32_t)NBUCK, T.slots, d_lost, h->d_counters, (int)C_SETBITS);
-		else hipLaunchKernelGGL(k_bloom_region<2>, dim3(grid), dim3(512), 0, h->stream, bufs[cur], d_begin, (uint32_t)NBUCK, T.slots, d_lost, h->d_counters, (int)C_SETBITS);
+		// expected contested bits of a region: 2^17 * P(a bit has two or more touchers) at fill lambda
+		const double lambda = 8.0 * (double)keys / (double)m_bits;
+		const double contested = (double)REGION_BITS * (1.0 - std::exp(-lambda) * (1.0 + lambda));
+		const bool big = contested > 0.8 * REGION_MULTI_CAP;
+		auto launch = [&](auto kernel) {
+			int occ = 1;
+			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 512, 0) != hipSuccess || occ < 1) occ = 1;
+			(void)hipGetLastError();
+			const unsigned grid = (unsigned)std::min<uint64_t>(NBUCK, (uint64_t)n_cu * occ);
+			hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), 0, h->stream, bufs[cur], d_begin, (uint32_t)NBUCK, T.slots, d_lost, h->d_counters, (int)C_SETBITS);
+		};
+		if (h->W == 1) {
+			if (big) launch(k_bloom_region<1, REGION_MULTI_CAP_BIG>);
+			else launch(k_bloom_region<1, REGION_MULTI_CAP>);
+		} else {
+			if (big) launch(k_bloom_region<2, REGION_MULTI_CAP_BIG>);
+			else launch(k_bloom_region<2, REGION_MULTI_CAP>);
+		}
 		BTRY(hipGetLastError());
 	}
 	rc = sync_counters(h);
@@ -1897,7 +1913,9 @@ int rg_resolve_admission(rg_handle *h, uint64_t local_reads_for_bloom) {
 		const uint64_t keys = h->h_counters[C_FILL];
 		const uint32_t flags = (uint32_t)h->cfg.reserved0 & 0xFFu;
 		const double lambda = 8.0 * (double)keys / (double)m_bits;
-		if (!(flags & 32u) && ((flags & 16u) || (lambda <= 0.25 && keys >= (1ull << 20)))) {
+		// worth it while a region's contested bits (expected: 2^17 * P(two or more touchers)) fit the LDS rank table
+		const double contested = (double)REGION_BITS * (1.0 - std::exp(-lambda) * (1.0 + lambda));
+		if (!(flags & 32u) && ((flags & 16u) || (contested <= 0.9 * REGION_MULTI_CAP_BIG && keys >= (1ull << 20)))) {
 			rc0 = bloom_partitioned(h, m_bits, keys, &resolved);
 			if (rc0) return rc0;
 			h->stats.bloom_partitioned = resolved ? 1 : 0;

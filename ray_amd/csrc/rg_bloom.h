@@ -13,7 +13,8 @@
 //   k_admit_lost    a key is a false positive iff all 8 of its bit checks lost (MessageProcessor.cpp:741-750)
 //
 // Same result as the dense method bit for bit; used when the expected fill is low, falls back to
-// the dense method otherwise or when a region holds more contested bits than LDS can rank.
+// the dense method otherwise or when a region holds more contested bits than LDS can rank (4096, or
+// 10240 in the variant picked for fuller filters).
 #pragma once
 #include "rg_device.h"
 
@@ -22,7 +23,8 @@ namespace rg {
 static constexpr int REGION_BITS_LOG2 = 17;
 static constexpr uint32_t REGION_BITS = 1u << REGION_BITS_LOG2;
 static constexpr uint32_t REGION_WORDS = REGION_BITS / 32;  // 4096 words per bitmap
-static constexpr uint32_t REGION_MULTI_CAP = 4096;          // contested bits a region can rank (32 KB of stamps)
+static constexpr uint32_t REGION_MULTI_CAP = 4096;          // contested bits a region can rank (32 KB of stamps): 2 workgroups per CU
+static constexpr uint32_t REGION_MULTI_CAP_BIG = 10240;     // fuller filters: 80 KB of stamps, 1 workgroup per CU
 static constexpr uint64_t ITEM_INVALID = ~0ull;
 static constexpr uint32_t ITEM_CHUNK_KEYS = 512;  // keys (x8 items) a wavefront claims at a time
 static constexpr int SCATTER64_TILE = 4096;
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(256) void k_scatter64(const unsigned long long *__r
 // them is what the kernel waits for), and stay in registers for the three passes; a region with more
 // than 512*REGION_PER items takes further rounds that read again.
 static constexpr int REGION_PER = 32;
-template <int W>
+template <int W, uint32_t CAP>
 __global__ __launch_bounds__(512) void k_bloom_region(const unsigned long long *__restrict__ items,
                                                       const unsigned long long *__restrict__ region_begin, uint32_t nregions,
                                                       const Slot *__restrict__ tab, uint32_t *__restrict__ lost,
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(512) void k_bloom_region(const unsigned long long *
 	__shared__ uint32_t s_b1[REGION_WORDS];       // bit touched
 	__shared__ uint32_t s_b2[REGION_WORDS];       // bit touched more than once
 	__shared__ uint16_t s_pre[REGION_WORDS];      // exclusive prefix of popc(s_b2): rank of a contested bit
-	__shared__ unsigned long long s_min[REGION_MULTI_CAP];
+	__shared__ unsigned long long s_min[CAP];
 	__shared__ uint32_t s_wsum[8];
 	__shared__ uint32_t s_setbits;
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(512) void k_bloom_region(const unsigned long long *
 			if (q < wave) run += t;
 			nmulti += t;
 		}
-		const bool fits = nmulti <= REGION_MULTI_CAP;  // uniform
+		const bool fits = nmulti <= CAP;  // uniform
 #pragma unroll
 		for (int j = 0; j < 8; ++j) {
 			s_pre[threadIdx.x * 8 + j] = (uint16_t)run;  // only used when it fits (< 65536)
@@ -267,7 +269,7 @@ __global__ __launch_bounds__(512) void k_bloom_region(const unsigned long long *
 		}
 		setbits_total += set1;
 		if (!fits && threadIdx.x == 0) atomicAdd(&counters[BC_REGION_OVF], 1ull);
-		for (uint32_t i = threadIdx.x; i < nmulti && i < REGION_MULTI_CAP; i += 512) s_min[i] = INF_STAMP;
+		for (uint32_t i = threadIdx.x; i < nmulti && i < CAP; i += 512) s_min[i] = INF_STAMP;
 		__syncthreads();
 		if (fits && nmulti) {
 			// pass 2: earliest toucher of every contested bit; pass 3: every later toucher loses that bit check
