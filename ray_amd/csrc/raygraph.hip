@@ -1071,7 +1071,13 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	}
 	if (bits < 8) bits = 8;
 	if (bits > MAX_BUCKET_BITS) bits = MAX_BUCKET_BITS;
-	const int dbits[3] = {8, std::min(8, bits - 8), std::max(0, bits - 16)};
+	// one to three levels of at most 8 bits each, split evenly: fewer digits per level = longer runs per (tile, digit)
+	const int nlev = bits <= 8 ? 1 : (bits <= 16 ? 2 : 3);
+	int dbits[3] = {0, 0, 0};
+	for (int l = 0, left = bits; l < nlev; ++l) {
+		dbits[l] = (left + (nlev - l) - 1) / (nlev - l);
+		left -= dbits[l];
+	}
 	const uint64_t NBUCK = 1ull << bits;
 	// persistent grids sized to what is resident at once, so that no second, nearly empty round of
 	// workgroups runs behind the first
@@ -1129,7 +1135,7 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 			{
 				ProfScope ps(h, "k_superkmers");
 				hipLaunchKernelGGL(k_superkmers<W>, dim3(grid1), dim3(256), 0, h->stream, b.d_packed, b.d_off, b.d_len, b.n, b.first_id, k, m, buf[0],
-				                   rec_cap, h->d_counters, d_hist, 0u);
+				                   rec_cap, h->d_counters, d_hist, 0u, (uint32_t)(24 - dbits[0]));
 			}
 			PTRY(hipGetLastError());
 		}
@@ -1300,7 +1306,7 @@ static int records_local_t(rg_handle *h) {
 			if (b.maxlen < (uint32_t)k || e != hipSuccess) continue;
 			ProfScope ps(h, "k_superkmers");
 			hipLaunchKernelGGL(k_superkmers<W>, dim3(grid1), dim3(256), 0, h->stream, b.d_packed, b.d_off, b.d_len, b.n, b.first_id, k, m, buf, rec_cap,
-			                   h->d_counters, d_hist, size);
+			                   h->d_counters, d_hist, size, 16u);
 			e = hipGetLastError();
 		}
 		std::vector<unsigned long long> hist(256);

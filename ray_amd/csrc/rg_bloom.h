@@ -159,21 +159,27 @@ __global__ __launch_bounds__(256) void k_scatter64(const unsigned long long *__r
 	__syncthreads();
 	{
 		const uint32_t c = s_cnt[threadIdx.x];
-		s_scan[threadIdx.x] = c;
-		__syncthreads();
-		for (int d = 1; d < 256; d <<= 1) {
-			uint32_t t = (threadIdx.x >= (uint32_t)d) ? s_scan[threadIdx.x - d] : 0;
-			__syncthreads();
-			s_scan[threadIdx.x] += t;
-			__syncthreads();
+		const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+		uint32_t incl = c;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			const uint32_t o = __shfl_up(incl, d);
+			if (lane >= (uint32_t)d) incl += o;
 		}
-		s_off[threadIdx.x] = s_scan[threadIdx.x] - c;
+		if (lane == 63) s_scan[wv] = incl;
+		__syncthreads();
+		uint32_t before = 0;
+#pragma unroll
+		for (uint32_t q = 0; q < 4; ++q)
+			if (q < wv) before += s_scan[q];
+		s_off[threadIdx.x] = before + incl - c;
+		if (threadIdx.x == 255) s_scan[4] = before + incl;
 		unsigned long long g = 0;
 		if (c) g = atomicAdd(&cursors[((uint64_t)seg << 8) + threadIdx.x], (unsigned long long)c);
 		s_gbase[threadIdx.x] = g;
 	}
 	__syncthreads();
-	const uint32_t total = s_scan[255];
+	const uint32_t total = s_scan[4];
 #pragma unroll
 	for (int j = 0; j < PER; ++j)
 		if (dig[j] != 0xFFFFFFFFu) {

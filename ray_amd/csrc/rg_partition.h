@@ -143,8 +143,8 @@ __global__ __launch_bounds__(256) void k_superkmers(const uint64_t *__restrict__
                                                     const uint32_t *__restrict__ lengths, uint64_t nreads, uint64_t read_id_base,
                                                     int k, int m, Rec<W> *__restrict__ recs, uint64_t rec_cap,
                                                     unsigned long long *__restrict__ counters,
-                                                    unsigned long long *__restrict__ coarse_hist, uint32_t modulo) {
-	// coarse_hist[256]: records per first-level digit (top 8 bits of the bucket), or, with modulo != 0, per
+                                                    unsigned long long *__restrict__ coarse_hist, uint32_t modulo, uint32_t hist_shift) {
+	// coarse_hist[256]: records per first-level digit (bucket >> hist_shift, at most 8 bits), or, with modulo != 0, per
 	// destination rank bucket % modulo (record exchange between ranks, modulo <= 256)
 	constexpr int NB = 2 * W;
 	__shared__ unsigned long long s_x[4][2][SK_XPAD];
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void k_superkmers(const uint64_t *__restrict__
 							            ((uint64_t)moff << 24) | rid;
 							recs[chunk_base + chunk_used + idx] = rec;
 							const uint32_t bk = bucket24(cn[jm]);
-							atomicAdd(&s_hist[modulo ? bk % modulo : bk >> 16], 1u);
+							atomicAdd(&s_hist[modulo ? bk % modulo : bk >> hist_shift], 1u);
 						}
 					}
 				chunk_used += c;
@@ -390,24 +390,31 @@ __global__ __launch_bounds__(256) void k_scatter(const Rec<W> *__restrict__ in, 
 		}
 	}
 	__syncthreads();
-	// exclusive scan of the digit counts (Hillis-Steele) and one cursor claim per non-empty digit
+	// exclusive scan of the 256 digit counts (shuffles inside each wavefront, one barrier across the four) and one
+	// cursor claim per non-empty digit
 	{
-		uint32_t c = s_cnt[threadIdx.x];
-		s_scan[threadIdx.x] = c;
-		__syncthreads();
-		for (int d = 1; d < 256; d <<= 1) {
-			uint32_t t = (threadIdx.x >= (uint32_t)d) ? s_scan[threadIdx.x - d] : 0;
-			__syncthreads();
-			s_scan[threadIdx.x] += t;
-			__syncthreads();
+		const uint32_t c = s_cnt[threadIdx.x];
+		const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+		uint32_t incl = c;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			const uint32_t o = __shfl_up(incl, d);
+			if (lane >= (uint32_t)d) incl += o;
 		}
-		s_off[threadIdx.x] = s_scan[threadIdx.x] - c;
+		if (lane == 63) s_scan[wv] = incl;
+		__syncthreads();
+		uint32_t before = 0;
+#pragma unroll
+		for (uint32_t q = 0; q < 4; ++q)
+			if (q < wv) before += s_scan[q];
+		s_off[threadIdx.x] = before + incl - c;
+		if (threadIdx.x == 255) s_scan[4] = before + incl;
 		unsigned long long g = 0;
 		if (c) g = atomicAdd(&cursors[((uint64_t)seg << dbits) + threadIdx.x], (unsigned long long)c);
 		s_gbase[threadIdx.x] = g;
 	}
 	__syncthreads();
-	const uint32_t total = s_scan[255];
+	const uint32_t total = s_scan[4];
 #pragma unroll
 	for (int j = 0; j < PER; ++j)
 		if (dig[j] != 0xFFFFFFFFu) {
