@@ -222,7 +222,6 @@ def main():
             "k_admit": cand0 * (32 + 8 + 8),                                 # slot + >= 1 stamp word + coverage write
             "bloom_stamp_fill": st["bloom_bits"] * 8,
             "k_histogram": st["table_slots"] * 32,
-            "k_publish_edges": st["table_slots"] * 32,
         }
         if "k_scatter64" in kprof:
             alg_bytes["k_scatter64"] *= kprof["k_scatter64"][1] / args.steps

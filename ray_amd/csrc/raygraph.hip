@@ -305,10 +305,37 @@ __global__ __launch_bounds__(BLOCK) void k_bloom_touch(const Slot *__restrict__ 
 // sight found all 8 bits already set (a false positive) is stored from its first sight: coverage
 // 1 + N.  Otherwise the first sight only feeds the filter: stored iff N >= 2, coverage N.  With
 // the filter off every sight counts: coverage N.  Coverage saturates at 2^32-1 (Vertex.cpp:83-88).
+static constexpr uint32_t HIST_LDS = 4096;
+static constexpr uint32_t HIST_DENSE = 65536;
+static constexpr uint32_t HIST_OVF_CAP = 1u << 20;
+
+// coverage histogram of the stored vertices (CoverageGatherer.cpp:124-158), gathered by the kernel that writes the
+// coverages: bins below HIST_LDS in LDS, below HIST_DENSE in a dense global array, the rest as a list
+__device__ __forceinline__ void hist_add(uint32_t *s_h, uint64_t cov, unsigned long long *__restrict__ dense, uint32_t *__restrict__ ovf,
+                                         unsigned long long *__restrict__ counters) {
+	if (cov == 0) return;
+	if (cov < HIST_LDS) atomicAdd(&s_h[cov], 1u);
+	else if (cov < HIST_DENSE) atomicAdd(&dense[cov], 1ull);
+	else {
+		unsigned long long pos = atomicAdd(&counters[C_OVF], 1ull);
+		if (pos < HIST_OVF_CAP) ovf[pos] = (uint32_t)cov;
+	}
+}
+// final state of a slot after admission: coverage in the count field, the edge bits gathered during the sweep moved
+// to the published field (rg_add_edges only makes them visible: the bits themselves are final once pass 1 ends)
+__device__ __forceinline__ uint64_t admitted_meta(uint64_t meta, uint64_t cov) {
+	const uint64_t pend = (meta >> PEND_SHIFT) & 0xFFull;
+	return (meta & ~COUNT_MASK & ~(0xFFull << PUB_SHIFT)) | cov | (pend << PUB_SHIFT);
+}
+
 template <int W, bool BLOOM>
 __global__ __launch_bounds__(BLOCK) void k_admit(Slot *__restrict__ tab, uint64_t cap, uint64_t m_bits,
                                                  const unsigned long long *__restrict__ bitstamp,
-                                                 unsigned long long *__restrict__ counters) {
+                                                 unsigned long long *__restrict__ counters, unsigned long long *__restrict__ hist_dense,
+                                                 uint32_t *__restrict__ hist_ovf) {
+	__shared__ uint32_t s_h[HIST_LDS];
+	for (uint32_t j = threadIdx.x; j < HIST_LDS; j += blockDim.x) s_h[j] = 0;
+	__syncthreads();
 	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
 	uint32_t retained = 0, inserted = 0;
@@ -336,7 +363,8 @@ __global__ __launch_bounds__(BLOCK) void k_admit(Slot *__restrict__ tab, uint64_
 		}
 		if (cov > 0xFFFFFFFFull) cov = 0xFFFFFFFFull;
 		if (cov) retained++;
-		tab[i].meta = (v.meta & ~COUNT_MASK) | cov;
+		tab[i].meta = admitted_meta(v.meta, cov);
+		hist_add(s_h, cov, hist_dense, hist_ovf, counters);
 	}
 	for (int d = 32; d > 0; d >>= 1) {
 		retained += __shfl_down(retained, d);
@@ -346,13 +374,20 @@ __global__ __launch_bounds__(BLOCK) void k_admit(Slot *__restrict__ tab, uint64_
 		if (retained) atomicAdd(&counters[C_RETAINED], (unsigned long long)retained);
 		if (inserted) atomicAdd(&counters[C_INSERTIONS], (unsigned long long)inserted);
 	}
+	__syncthreads();
+	for (uint32_t j = threadIdx.x; j < HIST_LDS; j += blockDim.x)
+		if (s_h[j]) atomicAdd(&hist_dense[j], (unsigned long long)s_h[j]);
 }
 
 // A7 with the "lost" marks of rg_bloom.h: a key whose 8 bit checks all found the bit set earlier is a
 // false positive
 template <int W>
 __global__ __launch_bounds__(BLOCK) void k_admit_lost(Slot *__restrict__ tab, uint64_t cap, const uint32_t *__restrict__ lost,
-                                                      unsigned long long *__restrict__ counters) {
+                                                      unsigned long long *__restrict__ counters, unsigned long long *__restrict__ hist_dense,
+                                                      uint32_t *__restrict__ hist_ovf) {
+	__shared__ uint32_t s_h[HIST_LDS];
+	for (uint32_t j = threadIdx.x; j < HIST_LDS; j += blockDim.x) s_h[j] = 0;
+	__syncthreads();
 	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
 	uint32_t retained = 0, inserted = 0;
@@ -369,7 +404,8 @@ __global__ __launch_bounds__(BLOCK) void k_admit_lost(Slot *__restrict__ tab, ui
 		}
 		if (cov > 0xFFFFFFFFull) cov = 0xFFFFFFFFull;
 		if (cov) retained++;
-		tab[i].meta = (v.meta & ~COUNT_MASK) | cov;
+		tab[i].meta = admitted_meta(v.meta, cov);
+		hist_add(s_h, cov, hist_dense, hist_ovf, counters);
 	}
 	for (int d = 32; d > 0; d >>= 1) {
 		retained += __shfl_down(retained, d);
@@ -379,12 +415,12 @@ __global__ __launch_bounds__(BLOCK) void k_admit_lost(Slot *__restrict__ tab, ui
 		if (retained) atomicAdd(&counters[C_RETAINED], (unsigned long long)retained);
 		if (inserted) atomicAdd(&counters[C_INSERTIONS], (unsigned long long)inserted);
 	}
+	__syncthreads();
+	for (uint32_t j = threadIdx.x; j < HIST_LDS; j += blockDim.x)
+		if (s_h[j]) atomicAdd(&hist_dense[j], (unsigned long long)s_h[j]);
 }
 
 // A12: coverage histogram of the stored pairs.  Low coverages are binned in LDS per workgroup.
-static constexpr uint32_t HIST_LDS = 4096;
-static constexpr uint32_t HIST_DENSE = 65536;
-static constexpr uint32_t HIST_OVF_CAP = 1u << 20;
 __global__ __launch_bounds__(BLOCK) void k_histogram(const Slot *__restrict__ tab, uint64_t cap,
                                                      unsigned long long *__restrict__ dense, uint32_t *__restrict__ ovf,
                                                      unsigned long long *__restrict__ counters) {
@@ -410,17 +446,6 @@ __global__ __launch_bounds__(BLOCK) void k_histogram(const Slot *__restrict__ ta
 		if (s_h[j]) atomicAdd(&dense[j], (unsigned long long)s_h[j]);
 }
 
-// pass 2 publication: the edge bits gathered during the sweep become the vertex's edge bitmap
-__global__ __launch_bounds__(BLOCK) void k_publish_edges(Slot *__restrict__ tab, uint64_t cap) {
-	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-	for (; i < cap; i += stride) {
-		uint64_t m = tab[i].meta;
-		if (tab[i].k0 == EMPTY || (m & COUNT_MASK) == 0) continue;
-		uint64_t pend = (m >> PEND_SHIFT) & 0xFFull;
-		tab[i].meta = (m & ~(0xFFull << PUB_SHIFT)) | (pend << PUB_SHIFT);
-	}
-}
 
 // multiword helpers in the reference key form
 template <int W>
@@ -709,7 +734,7 @@ __global__ __launch_bounds__(BLOCK) void k_purge_apply(Slot *__restrict__ tab, c
 // bulk GridTable::find + Vertex::getCoverage/getEdges
 template <int W>
 __global__ __launch_bounds__(BLOCK) void k_find(const Slot *__restrict__ tab, uint64_t cap, int k, const uint64_t *__restrict__ q,
-                                                uint64_t n, uint32_t *__restrict__ cov, uint8_t *__restrict__ edges) {
+                                                uint64_t n, uint32_t *__restrict__ cov, uint8_t *__restrict__ edges, uint32_t edge_mask) {
 	const uint64_t mask = cap - 1;
 	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -723,7 +748,7 @@ __global__ __launch_bounds__(BLOCK) void k_find(const Slot *__restrict__ tab, ui
 		if (s) {
 			c = (uint32_t)(s->meta & COUNT_MASK);
 			if (c) {
-				e = (uint32_t)(s->meta >> PUB_SHIFT) & 0xFFu;
+				e = (uint32_t)(s->meta >> PUB_SHIFT) & edge_mask;  // 0 until rg_add_edges: pass 2 has not happened yet
 				if (rc) e = convert_bitmap(e);
 			}
 		}
@@ -733,7 +758,8 @@ __global__ __launch_bounds__(BLOCK) void k_find(const Slot *__restrict__ tab, ui
 }
 
 // 5x5 in/out-degree table over both strands (MachineHelper.cpp:548-578)
-__global__ __launch_bounds__(BLOCK) void k_degrees(const Slot *__restrict__ tab, uint64_t cap, unsigned long long *__restrict__ out) {
+__global__ __launch_bounds__(BLOCK) void k_degrees(const Slot *__restrict__ tab, uint64_t cap, unsigned long long *__restrict__ out,
+                                                   uint32_t edge_mask) {
 	__shared__ uint32_t s_d[25];
 	if (threadIdx.x < 25) s_d[threadIdx.x] = 0;
 	__syncthreads();
@@ -742,7 +768,7 @@ __global__ __launch_bounds__(BLOCK) void k_degrees(const Slot *__restrict__ tab,
 	for (; i < cap; i += stride) {
 		uint64_t m = tab[i].meta;
 		if (tab[i].k0 == EMPTY || (m & COUNT_MASK) == 0) continue;
-		uint32_t e = (uint32_t)(m >> PUB_SHIFT) & 0xFFu;
+		uint32_t e = (uint32_t)(m >> PUB_SHIFT) & edge_mask;
 		uint32_t parents = __popc(e & 0xFu), children = __popc(e >> 4);
 		atomicAdd(&s_d[parents * 5 + children], 1u);
 		atomicAdd(&s_d[children * 5 + parents], 1u);  // the reverse complement swaps the roles
@@ -769,7 +795,8 @@ __global__ __launch_bounds__(BLOCK) void k_export_count(const Slot *__restrict__
 // export, step 2: Vertex::dump records (Vertex.cpp:438-454) in slot order, deterministic
 template <int W>
 __global__ __launch_bounds__(BLOCK) void k_export_write(const Slot *__restrict__ tab, uint64_t cap, uint64_t chunk,
-                                                        const unsigned long long *__restrict__ chunk_start, uint8_t *__restrict__ out) {
+                                                        const unsigned long long *__restrict__ chunk_start, uint8_t *__restrict__ out,
+                                                        uint32_t edge_mask) {
 	constexpr int REC = W * 8 + 5;
 	__shared__ uint32_t s_wave[BLOCK / 64];
 	__shared__ uint32_t s_base;
@@ -801,7 +828,7 @@ __global__ __launch_bounds__(BLOCK) void k_export_write(const Slot *__restrict__
 			from_internal<W>(v.k0, v.k1, K0, K1);
 			uint8_t *p = out + (out0 + blockbase + wbase + before) * REC;
 			uint32_t cov = (uint32_t)(v.meta & COUNT_MASK);
-			uint8_t e = (uint8_t)(v.meta >> PUB_SHIFT);
+			uint8_t e = (uint8_t)((v.meta >> PUB_SHIFT) & edge_mask);
 			for (int b = 0; b < 8; ++b) p[b] = (uint8_t)(K0 >> (8 * b));
 			if (W == 2)
 				for (int b = 0; b < 8; ++b) p[8 + b] = (uint8_t)(K1 >> (8 * b));
@@ -919,6 +946,8 @@ struct rg_handle {
 	uint64_t *d_purge_origin = nullptr;  // rg_purge_export_queries .. rg_purge_apply: (slot << 3 | edge bit) per query
 	uint64_t purge_total = 0;
 	std::vector<uint64_t> purge_counts;
+	unsigned long long *d_hist_dense = nullptr;  // live inside rg_resolve_admission only
+	uint32_t *d_hist_ovf = nullptr;
 	bool hist_valid = false;
 	std::vector<std::pair<uint32_t, uint64_t>> hist_cache;  // (coverage, stored pairs)
 };
@@ -1519,14 +1548,43 @@ static int bloom_partitioned(rg_handle *h, uint64_t m_bits, uint64_t keys, bool 
 	{
 		ProfScope ps(h, "k_admit");
 		const int grid = grid_for(T.cap);
-		if (h->W == 1) hipLaunchKernelGGL(k_admit_lost<1>, dim3(grid), dim3(BLOCK), 0, h->stream, T.slots, T.cap, d_lost, h->d_counters);
-		else hipLaunchKernelGGL(k_admit_lost<2>, dim3(grid), dim3(BLOCK), 0, h->stream, T.slots, T.cap, d_lost, h->d_counters);
+		if (h->W == 1) hipLaunchKernelGGL(k_admit_lost<1>, dim3(grid), dim3(BLOCK), 0, h->stream, T.slots, T.cap, d_lost, h->d_counters, h->d_hist_dense, h->d_hist_ovf);
+		else hipLaunchKernelGGL(k_admit_lost<2>, dim3(grid), dim3(BLOCK), 0, h->stream, T.slots, T.cap, d_lost, h->d_counters, h->d_hist_dense, h->d_hist_ovf);
 		BTRY(hipGetLastError());
 	}
 	BTRY(hipStreamSynchronize(h->stream));
 	cleanup();
 	*ok = true;
 #undef BTRY
+	return RG_OK;
+}
+
+// reads the device histogram (dense bins + overflow list) back and caches it in the handle
+static int collect_histogram(rg_handle *h, const unsigned long long *dense, const uint32_t *ovf) {
+	std::vector<unsigned long long> hd(HIST_DENSE);
+	hipError_t e = hipMemcpyAsync(hd.data(), dense, HIST_DENSE * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream);
+	if (e != hipSuccess) return fail(h, RG_ERR_HIP, "histogram: %s", hipGetErrorString(e));
+	int rc = sync_counters(h);
+	if (rc) return rc;
+	const uint64_t novf = h->h_counters[C_OVF];
+	std::vector<uint32_t> ho;
+	if (novf > HIST_OVF_CAP) return fail(h, RG_ERR_CAPACITY, "more than %u vertices with coverage >= %u", HIST_OVF_CAP, HIST_DENSE);
+	if (novf) {
+		ho.resize(novf);
+		e = hipMemcpy(ho.data(), ovf, novf * sizeof(uint32_t), hipMemcpyDeviceToHost);
+		if (e != hipSuccess) return fail(h, RG_ERR_HIP, "histogram: %s", hipGetErrorString(e));
+		std::sort(ho.begin(), ho.end());
+	}
+	h->hist_cache.clear();
+	for (uint32_t c = 0; c < HIST_DENSE; ++c)
+		if (hd[c]) h->hist_cache.emplace_back(c, hd[c]);
+	for (size_t i = 0; i < ho.size();) {
+		size_t e2 = i;
+		while (e2 < ho.size() && ho[e2] == ho[i]) e2++;
+		h->hist_cache.emplace_back(ho[i], e2 - i);
+		i = e2;
+	}
+	h->hist_valid = true;
 	return RG_OK;
 }
 
@@ -1899,6 +1957,24 @@ int rg_resolve_admission(rg_handle *h, uint64_t local_reads_for_bloom) {
 		int rc = table_reserve(h, T, 1, C_FILL);
 		if (rc) return rc;
 	}
+	// the admission kernel also gathers the coverage histogram and moves the edge bits to their final field
+	HIP_TRY(h, pool_alloc(h->cfg.device, (void **)&h->d_hist_dense, HIST_DENSE * sizeof(unsigned long long)));
+	if (pool_alloc(h->cfg.device, (void **)&h->d_hist_ovf, HIST_OVF_CAP * sizeof(uint32_t)) != hipSuccess) {
+		pool_free(h->cfg.device, h->d_hist_dense);
+		h->d_hist_dense = nullptr;
+		return fail(h, RG_ERR_NOMEM, "rg_resolve_admission: out of device memory");
+	}
+	struct HistGuard {
+		rg_handle *h;
+		~HistGuard() {
+			pool_free(h->cfg.device, h->d_hist_dense);
+			pool_free(h->cfg.device, h->d_hist_ovf);
+			h->d_hist_dense = nullptr;
+			h->d_hist_ovf = nullptr;
+		}
+	} hist_guard{h};
+	HIP_TRY(h, hipMemsetAsync(h->d_hist_dense, 0, HIST_DENSE * sizeof(unsigned long long), h->stream));
+	HIP_TRY(h, hipMemsetAsync(h->d_counters + C_OVF, 0, sizeof(unsigned long long), h->stream));
 	// MessageProcessor.cpp:886-899 + VerticesExtractor.cpp:276-320
 	uint64_t m_bits = h->cfg.bloom_bits;
 	if (m_bits == RG_BLOOM_DEFAULT) {
@@ -1943,8 +2019,8 @@ int rg_resolve_admission(rg_handle *h, uint64_t local_reads_for_bloom) {
 			}
 			{
 				ProfScope ps(h, "k_admit");
-				if (h->W == 1) hipLaunchKernelGGL((k_admit<1, true>), dim3(grid), dim3(BLOCK), 0, h->stream, T.slots, T.cap, m_bits, bitstamp, h->d_counters);
-				else hipLaunchKernelGGL((k_admit<2, true>), dim3(grid), dim3(BLOCK), 0, h->stream, T.slots, T.cap, m_bits, bitstamp, h->d_counters);
+				if (h->W == 1) hipLaunchKernelGGL((k_admit<1, true>), dim3(grid), dim3(BLOCK), 0, h->stream, T.slots, T.cap, m_bits, bitstamp, h->d_counters, h->d_hist_dense, h->d_hist_ovf);
+				else hipLaunchKernelGGL((k_admit<2, true>), dim3(grid), dim3(BLOCK), 0, h->stream, T.slots, T.cap, m_bits, bitstamp, h->d_counters, h->d_hist_dense, h->d_hist_ovf);
 			}
 			e = hipGetLastError();
 		}
@@ -1953,11 +2029,11 @@ int rg_resolve_admission(rg_handle *h, uint64_t local_reads_for_bloom) {
 		if (e != hipSuccess) return fail(h, RG_ERR_HIP, "Bloom resolution failed: %s", hipGetErrorString(e));
 		if (e2 != hipSuccess) return fail(h, RG_ERR_HIP, "Bloom resolution failed: %s", hipGetErrorString(e2));
 	} else if (m_bits == 0) {
-		if (h->W == 1) hipLaunchKernelGGL((k_admit<1, false>), dim3(grid), dim3(BLOCK), 0, h->stream, T.slots, T.cap, 0ull, (const unsigned long long *)nullptr, h->d_counters);
-		else hipLaunchKernelGGL((k_admit<2, false>), dim3(grid), dim3(BLOCK), 0, h->stream, T.slots, T.cap, 0ull, (const unsigned long long *)nullptr, h->d_counters);
+		if (h->W == 1) hipLaunchKernelGGL((k_admit<1, false>), dim3(grid), dim3(BLOCK), 0, h->stream, T.slots, T.cap, 0ull, (const unsigned long long *)nullptr, h->d_counters, h->d_hist_dense, h->d_hist_ovf);
+		else hipLaunchKernelGGL((k_admit<2, false>), dim3(grid), dim3(BLOCK), 0, h->stream, T.slots, T.cap, 0ull, (const unsigned long long *)nullptr, h->d_counters, h->d_hist_dense, h->d_hist_ovf);
 		HIP_TRY(h, hipGetLastError());
 	}
-	int rc = sync_counters(h);
+	int rc = collect_histogram(h, h->d_hist_dense, h->d_hist_ovf);
 	if (rc) return rc;
 	T.fill_known = h->h_counters[C_FILL];
 	T.fill_pending = 0;
@@ -1982,7 +2058,7 @@ int rg_histogram(rg_handle *h, uint32_t *coverage, uint64_t *count, uint64_t cap
 	if (!h || !n) return RG_ERR_ARG;
 	if (h->phase < PH_RESOLVED) return fail(h, RG_ERR_STATE, "rg_histogram needs the k-mer count first");
 	HIP_TRY(h, hipSetDevice(h->cfg.device));
-	if (!h->hist_valid) {
+	if (!h->hist_valid) {  // normally cached by rg_resolve_admission, which gathers it while writing the coverages
 		unsigned long long *dense = nullptr;
 		uint32_t *ovf = nullptr;
 		HIP_TRY(h, pool_alloc(h->cfg.device, (void **)&dense, HIST_DENSE * sizeof(unsigned long long)));
@@ -1990,11 +2066,6 @@ int rg_histogram(rg_handle *h, uint32_t *coverage, uint64_t *count, uint64_t cap
 			pool_free(h->cfg.device, dense);
 			return fail(h, RG_ERR_NOMEM, "rg_histogram: out of device memory");
 		}
-		auto release = [&]() {
-			pool_free(h->cfg.device, dense);
-			pool_free(h->cfg.device, ovf);
-		};
-		std::vector<unsigned long long> hd(HIST_DENSE);
 		hipError_t e = hipMemsetAsync(dense, 0, HIST_DENSE * sizeof(unsigned long long), h->stream);
 		if (e == hipSuccess) e = hipMemsetAsync(h->d_counters + C_OVF, 0, sizeof(unsigned long long), h->stream);
 		if (e == hipSuccess) {
@@ -2002,42 +2073,10 @@ int rg_histogram(rg_handle *h, uint32_t *coverage, uint64_t *count, uint64_t cap
 			hipLaunchKernelGGL(k_histogram, dim3(grid_for(h->tab.cap)), dim3(BLOCK), 0, h->stream, h->tab.slots, h->tab.cap, dense, ovf, h->d_counters);
 			e = hipGetLastError();
 		}
-		if (e == hipSuccess) e = hipMemcpyAsync(hd.data(), dense, HIST_DENSE * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream);
-		if (e != hipSuccess) {
-			release();
-			return fail(h, RG_ERR_HIP, "rg_histogram: %s", hipGetErrorString(e));
-		}
-		int rc = sync_counters(h);
-		if (rc) {
-			release();
-			return rc;
-		}
-		uint64_t novf = h->h_counters[C_OVF];
-		std::vector<uint32_t> ho;
-		if (novf > HIST_OVF_CAP) {
-			release();
-			return fail(h, RG_ERR_CAPACITY, "more than %u vertices with coverage >= %u", HIST_OVF_CAP, HIST_DENSE);
-		}
-		if (novf) {
-			ho.resize(novf);
-			e = hipMemcpy(ho.data(), ovf, novf * sizeof(uint32_t), hipMemcpyDeviceToHost);
-			if (e != hipSuccess) {
-				release();
-				return fail(h, RG_ERR_HIP, "rg_histogram: %s", hipGetErrorString(e));
-			}
-			std::sort(ho.begin(), ho.end());
-		}
-		release();
-		h->hist_cache.clear();
-		for (uint32_t c = 0; c < HIST_DENSE; ++c)
-			if (hd[c]) h->hist_cache.emplace_back(c, hd[c]);
-		for (size_t i = 0; i < ho.size();) {
-			size_t e2 = i;
-			while (e2 < ho.size() && ho[e2] == ho[i]) e2++;
-			h->hist_cache.emplace_back(ho[i], e2 - i);
-			i = e2;
-		}
-		h->hist_valid = true;
+		int rc = (e == hipSuccess) ? collect_histogram(h, dense, ovf) : fail(h, RG_ERR_HIP, "rg_histogram: %s", hipGetErrorString(e));
+		pool_free(h->cfg.device, dense);
+		pool_free(h->cfg.device, ovf);
+		if (rc) return rc;
 	}
 	uint64_t m = 0;
 	for (const auto &cp : h->hist_cache) {
@@ -2054,11 +2093,8 @@ int rg_histogram(rg_handle *h, uint32_t *coverage, uint64_t *count, uint64_t cap
 int rg_add_edges(rg_handle *h) {
 	if (!h) return RG_ERR_ARG;
 	if (h->phase != PH_RESOLVED) return fail(h, RG_ERR_STATE, "rg_add_edges needs the k-mer count first (and runs once)");
-	HIP_TRY(h, hipSetDevice(h->cfg.device));
-	ProfScope ps(h, "k_publish_edges");
-	hipLaunchKernelGGL(k_publish_edges, dim3(grid_for(h->tab.cap)), dim3(BLOCK), 0, h->stream, h->tab.slots, h->tab.cap);
-	HIP_TRY(h, hipGetLastError());
-	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	// The edge bits were gathered by the sweep and put in place by the admission kernel; what pass 2 of the
+	// reference adds (VerticesExtractor.cpp:40-274) is already there, this call makes it visible to readers.
 	h->phase = PH_EDGES;
 	return RG_OK;
 }
@@ -2205,8 +2241,8 @@ int rg_export(rg_handle *h, void *host_buf, uint64_t cap_records, uint64_t *n_re
 		return fail(h, RG_ERR_STATE, "export found %llu stored pairs, expected %llu", run, (unsigned long long)n);
 	}
 	HIP_TRY(h, hipMemcpyAsync(d_chunk, hc.data(), nchunks * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
-	if (h->W == 1) hipLaunchKernelGGL(k_export_write<1>, dim3((int)nchunks), dim3(BLOCK), 0, h->stream, h->tab.slots, cap, chunk, d_chunk, d_out);
-	else hipLaunchKernelGGL(k_export_write<2>, dim3((int)nchunks), dim3(BLOCK), 0, h->stream, h->tab.slots, cap, chunk, d_chunk, d_out);
+	if (h->W == 1) hipLaunchKernelGGL(k_export_write<1>, dim3((int)nchunks), dim3(BLOCK), 0, h->stream, h->tab.slots, cap, chunk, d_chunk, d_out, h->phase >= PH_EDGES ? 0xFFu : 0u);
+	else hipLaunchKernelGGL(k_export_write<2>, dim3((int)nchunks), dim3(BLOCK), 0, h->stream, h->tab.slots, cap, chunk, d_chunk, d_out, h->phase >= PH_EDGES ? 0xFFu : 0u);
 	hipError_t e = hipGetLastError();
 	if (e == hipSuccess) e = hipMemcpyAsync(host_buf, d_out, n * rec, hipMemcpyDeviceToHost, h->stream);
 	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
@@ -2230,8 +2266,8 @@ int rg_find(rg_handle *h, const uint64_t *kmers, uint64_t n, uint32_t *coverage,
 	HIP_TRY(h, pool_alloc(h->cfg.device, (void **)&de, n));
 	hipError_t e = hipMemcpyAsync(dq, kmers, n * h->W * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream);
 	if (e == hipSuccess) {
-		if (h->W == 1) hipLaunchKernelGGL(k_find<1>, dim3(grid_for(n)), dim3(BLOCK), 0, h->stream, h->tab.slots, h->tab.cap, h->cfg.k, dq, n, dc, de);
-		else hipLaunchKernelGGL(k_find<2>, dim3(grid_for(n)), dim3(BLOCK), 0, h->stream, h->tab.slots, h->tab.cap, h->cfg.k, dq, n, dc, de);
+		if (h->W == 1) hipLaunchKernelGGL(k_find<1>, dim3(grid_for(n)), dim3(BLOCK), 0, h->stream, h->tab.slots, h->tab.cap, h->cfg.k, dq, n, dc, de, h->phase >= PH_EDGES ? 0xFFu : 0u);
+		else hipLaunchKernelGGL(k_find<2>, dim3(grid_for(n)), dim3(BLOCK), 0, h->stream, h->tab.slots, h->tab.cap, h->cfg.k, dq, n, dc, de, h->phase >= PH_EDGES ? 0xFFu : 0u);
 		e = hipGetLastError();
 	}
 	if (e == hipSuccess) e = hipMemcpyAsync(coverage, dc, n * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream);
@@ -2387,7 +2423,7 @@ int rg_degree_distribution(rg_handle *h, uint64_t out[25]) {
 	unsigned long long *d = nullptr;
 	HIP_TRY(h, pool_alloc(h->cfg.device, (void **)&d, 25 * sizeof(unsigned long long)));
 	HIP_TRY(h, hipMemsetAsync(d, 0, 25 * sizeof(unsigned long long), h->stream));
-	hipLaunchKernelGGL(k_degrees, dim3(grid_for(h->tab.cap)), dim3(BLOCK), 0, h->stream, h->tab.slots, h->tab.cap, d);
+	hipLaunchKernelGGL(k_degrees, dim3(grid_for(h->tab.cap)), dim3(BLOCK), 0, h->stream, h->tab.slots, h->tab.cap, d, h->phase >= PH_EDGES ? 0xFFu : 0u);
 	unsigned long long tmp[25];
 	hipError_t e = hipMemcpyAsync(tmp, d, sizeof tmp, hipMemcpyDeviceToHost, h->stream);
 	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
