@@ -162,3 +162,16 @@ def test_two_runs_give_identical_exports(oracle):
         b.add_edges()
         outs.append(b.export(sort=True).tobytes())
     assert outs[0] == outs[1]
+
+
+def test_long_reads_many_steps(oracle):
+    """reads of thousands of bases: many 128-position steps per read in k_superkmers, records cut at step
+    boundaries, 16-bit positions; plus reads of exactly k and k+1 bases"""
+    packed, offsets, lengths = make_reads_numpy(genome=20000, read_len=6000, n_reads=120, seed=4, error=0.01, ragged=True)
+    gpu_vs_oracle(oracle, packed, offsets, lengths, 31, bloom_bits=400000, sweeps=(1 | 16 | (9 << 8), 2 | 32))
+    import ray_amd
+    seqs = ["ACGTTGCATGCCGTAAGCTTGACCATGCAAT", "ACGTTGCATGCCGTAAGCTTGACCATGCAATG", "ACGTTGCATGCCGTAAGCTTGACCATGCAAT"[::-1],
+            "A" * 300, "AC" * 200, "T" * 31, "ACGTTGCATGCCGTAAGCTTGACCATGCAATG"]
+    p, o, l = ray_amd.pack_reads(seqs)
+    gpu_vs_oracle(oracle, p, o, l, 31, bloom_bits=0, sweeps=(1 | (8 << 8), 2))
+    gpu_vs_oracle(oracle, p, o, l, 31, bloom_bits=5000, sweeps=(1 | 16 | (8 << 8), 2 | 32))
