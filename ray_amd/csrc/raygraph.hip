@@ -1113,7 +1113,7 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	int n_cu = 256, occ1 = 4, occ3 = 4;
 	(void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
 	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ1, k_superkmers<W>, 256, 0) != hipSuccess || occ1 < 1) occ1 = 4;
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ3, k_aggregate<W>, 256, 0) != hipSuccess || occ3 < 1) occ3 = 4;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ3, k_aggregate<W, false>, 256, 0) != hipSuccess || occ3 < 1) occ3 = 4;
 	(void)hipGetLastError();
 	const int grid1 = (int)std::min<uint64_t>((uint64_t)n_cu * occ1, std::max<uint64_t>(1, (total_reads + 255) / 256));
 	uint64_t launches1 = 0;  // every launch of k_superkmers leaves up to one open chunk per wavefront
@@ -1252,15 +1252,42 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 		cleanup();
 		return RG_OK;
 	}
+	uint32_t *d_retry = nullptr;
+	if (pool_alloc(dev, (void **)&d_retry, NBUCK * sizeof(uint32_t)) != hipSuccess) {
+		(void)hipGetLastError();
+		cleanup();
+		pool_free(dev, log);
+		return RG_OK;
+	}
+	// entries may be marked unique unless other ranks aggregate the same keys (entry route, size > 1)
+	const uint32_t flag_unique = (h->cfg.size == 1 || ext) ? 1u : 0u;
 	{
 		ProfScope ps(h, "k_aggregate");
-		// entries may be marked unique unless other ranks aggregate the same keys (entry route, size > 1)
-		const uint32_t flag_unique = (h->cfg.size == 1 || ext) ? 1u : 0u;
-		hipLaunchKernelGGL(k_aggregate<W>, dim3(agg_grid), dim3(256), 0, h->stream, level_in, d_begin, (uint32_t)NBUCK, k, log, log_cap,
-		                   h->d_counters, flag_unique);
+		hipLaunchKernelGGL((k_aggregate<W, false>), dim3(agg_grid), dim3(256), 0, h->stream, level_in, d_begin, (uint32_t)NBUCK, k, log, log_cap,
+		                   h->d_counters, flag_unique, (const uint32_t *)nullptr, d_retry);
 	}
-	hipError_t e = hipGetLastError();
-	if (e == hipSuccess) rc = sync_counters(h);
+	hipError_t e0 = hipGetLastError();
+	if (e0 == hipSuccess) {
+		rc = sync_counters(h);
+		const uint64_t n_retry = rc ? 0 : h->h_counters[PC_AGG_RETRY];
+		if (n_retry * 2 > NBUCK && !(h->cfg.reserved0 & 1)) {  // (bit 0: the tests insist on the partitioned sweep)
+			// most buckets hold more distinct k-mers than the LDS table: the data is too diverse (errors, low coverage)
+			// for aggregation to pay, the direct sweep is the better tool
+			pool_free(dev, d_retry);
+			cleanup();
+			pool_free(dev, log);
+			return RG_OK;
+		}
+		if (n_retry && !h->h_counters[PC_LOG_OVF]) {  // the buckets whose k-mers did not fit the LDS table: sub-passes
+			ProfScope ps(h, "k_aggregate_retry");
+			const unsigned g2 = (unsigned)std::min<uint64_t>((n_retry + AGG_WAVES - 1) / AGG_WAVES, (uint64_t)n_cu * occ3);
+			hipLaunchKernelGGL((k_aggregate<W, true>), dim3(g2), dim3(256), 0, h->stream, level_in, d_begin, (uint32_t)n_retry, k, log, log_cap,
+			                   h->d_counters, flag_unique, (const uint32_t *)d_retry, (uint32_t *)nullptr);
+		}
+	}
+	hipError_t e = (e0 != hipSuccess) ? e0 : hipGetLastError();
+	if (e == hipSuccess && !rc) rc = sync_counters(h);
+	pool_free(dev, d_retry);
 	cleanup();
 	if (e != hipSuccess || rc) {
 		pool_free(dev, log);
@@ -1277,9 +1304,10 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	h->stats.partition_levels = (uint64_t)((dbits[0] > 0) + (dbits[1] > 0) + (dbits[2] > 0));
 	h->stats.log_entries = *out_n;
 	if (getenv("RG_DEBUG"))
-		fprintf(stderr, "[raygraph] partitioned sweep: %llu reads, %llu occurrences, 2^%d buckets, %llu record slots (%llu valid, cap %llu), log %llu entries (cap %llu), %llu LDS spills\n",
+		fprintf(stderr, "[raygraph] partitioned sweep: %llu reads, %llu occurrences, 2^%d buckets, %llu record slots (%llu valid, cap %llu), log %llu entries (cap %llu), %llu LDS spills, %llu bucket retries\n",
 		        (unsigned long long)total_reads, (unsigned long long)h->h_counters[C_OCC], bits, (unsigned long long)n_in, (unsigned long long)valid,
-		        (unsigned long long)rec_cap, (unsigned long long)*out_n, (unsigned long long)log_cap, (unsigned long long)h->h_counters[PC_LDS_SPILL]);
+		        (unsigned long long)rec_cap, (unsigned long long)*out_n, (unsigned long long)log_cap, (unsigned long long)h->h_counters[PC_LDS_SPILL],
+		        (unsigned long long)h->h_counters[PC_AGG_RETRY]);
 #undef PTRY
 	return RG_OK;
 }

@@ -110,7 +110,7 @@ __device__ __forceinline__ uint32_t rec_bucket(const Rec<W> &r, int m) {
 	return bucket24(canon_mmer(f, m));
 }
 
-enum PartCounter { PC_REC_CURSOR = 16, PC_REC_OVF, PC_LOG_CURSOR, PC_LOG_OVF, PC_LDS_SPILL };
+enum PartCounter { PC_REC_CURSOR = 16, PC_REC_OVF, PC_LOG_CURSOR, PC_LOG_OVF, PC_LDS_SPILL, PC_AGG_RETRY };
 
 // ------------------------------------------------------------------------------------------------
 // reads -> super-k-mer records.  A wavefront takes 64 consecutive reads at a time (their lengths and
@@ -521,8 +521,11 @@ __global__ __launch_bounds__(256) void k_scan_add(unsigned long long *__restrict
 // (the spill path of the k-mer table is for safety only).  The records of the next round (or of the
 // next bucket's first round) are loaded before the current round is processed.
 static constexpr uint32_t AGG_SLOTS = 256;
-static constexpr uint32_t AGG_LIMIT = AGG_SLOTS * 8 / 10;
-static constexpr uint32_t AGG_FLUSH = AGG_LIMIT - 64;
+// the table is declared too small for a (sub-pass of a) bucket when more than AGG_FLUSH of its 256 slots are
+// claimed at a check point; up to 64 keys can arrive between two checks, the few that might not find a slot any
+// more take the spill path
+static constexpr uint32_t AGG_LIMIT = 215;
+static constexpr uint32_t AGG_FLUSH = 200;
 static constexpr uint32_t RT_SLOTS = 128;
 static constexpr uint32_t RT_FLUSH = RT_SLOTS * 3 / 4 - 64;
 static constexpr uint32_t LOG_CHUNK = 512;
@@ -562,13 +565,15 @@ __device__ __forceinline__ uint32_t agg_hash(uint64_t i0, uint64_t i1) {
 	uint32_t x = (uint32_t)i0 ^ __builtin_amdgcn_alignbit((uint32_t)(i0 >> 32), (uint32_t)(i0 >> 32), 19);
 	if (W == 2) x ^= __builtin_amdgcn_alignbit((uint32_t)i1, (uint32_t)i1, 7) ^ __builtin_amdgcn_alignbit((uint32_t)(i1 >> 32), (uint32_t)(i1 >> 32), 25);
 	x ^= x >> 15;
-	return (x * 0x9E3779B1u) >> 24;  // 8 bits
+	return x * 0x9E3779B1u;  // top 8 bits: slot of the LDS table; the 12 bits below: sub-pass of the bucket
 }
-static_assert(AGG_SLOTS == 256, "agg_hash returns 8 bits");
+static_assert(AGG_SLOTS == 256, "the slot is the top 8 bits of agg_hash");
+static constexpr uint32_t AGG_MAX_SUBPASSES = 4096;
 
 template <int W>
-__device__ __forceinline__ bool lds_upsert(AggTable<W> &t, uint64_t i0, uint64_t i1, uint64_t stamp, uint32_t emask, uint32_t weight) {
-	uint32_t s = agg_hash<W>(i0, i1);
+__device__ __forceinline__ bool lds_upsert(AggTable<W> &t, uint32_t hash, uint64_t i0, uint64_t i1, uint64_t stamp, uint32_t emask,
+                                           uint32_t weight) {
+	uint32_t s = hash >> 24;
 	for (uint32_t probe = 0; probe < AGG_SLOTS; ++probe) {
 		uint64_t c0 = t.k0[s];
 		if (c0 == EMPTY) {
@@ -603,14 +608,22 @@ __device__ __forceinline__ bool lds_upsert(AggTable<W> &t, uint64_t i0, uint64_t
 	return false;
 }
 
-template <int W>
+// SLOW == false: every bucket once, no sub-passes; a bucket whose k-mers do not fit the table is dropped unwritten
+// and its number appended to retry_list (counters[PC_AGG_RETRY] of them).  SLOW == true: the buckets of
+// bucket_list, with sub-passes.  Two instantiations so that the common path carries none of the retry machinery.
+template <int W, bool SLOW>
 __global__ __launch_bounds__(64 * AGG_WAVES) void k_aggregate(const Rec<W> *__restrict__ recs,
                                                               const unsigned long long *__restrict__ bucket_begin, uint32_t nbuckets,
                                                               int k, Slot *__restrict__ log, uint64_t log_cap,
-                                                              unsigned long long *__restrict__ counters, uint32_t flag_unique) {
+                                                              unsigned long long *__restrict__ counters, uint32_t flag_unique,
+                                                              const uint32_t *__restrict__ bucket_list, uint32_t *__restrict__ retry_list) {
 	// flag_unique: the caller guarantees that nothing outside this launch's log carries the same keys on their way
-	// to the same table; entries of a bucket that was flushed exactly once are then marked LOG_UNIQUE (every k-mer
-	// lives in exactly one bucket, see k_superkmers)
+	// to the same table; the entries are then marked LOG_UNIQUE (every k-mer lives in exactly one bucket, see
+	// k_superkmers, and a bucket is flushed once per sub-pass, each sub-pass owning a disjoint share of the k-mers).
+	// Sub-passes: when the distinct k-mers of a bucket do not fit the LDS table, nothing is flushed half-way (the
+	// occurrences of a k-mer are spread over the whole bucket, so partial flushes would multiply the log); the
+	// attempt is dropped and the bucket is redone in P = 2, 4, ... passes over its records, pass p taking the k-mers
+	// whose hash selects p.
 	constexpr int NB = 2 * W;
 	__shared__ AggTable<W> s_tables[AGG_WAVES];
 	__shared__ RecTable<W> s_rtables[AGG_WAVES];
@@ -622,16 +635,14 @@ __global__ __launch_bounds__(64 * AGG_WAVES) void k_aggregate(const Rec<W> *__re
 	const unsigned long long NO_CHUNK = ~0ull;
 	unsigned long long chunk_base = NO_CHUNK;  // wave-uniform
 	uint32_t chunk_used = 0;
-	uint32_t bucket_flushes = 0;  // flushes of the current bucket so far (wave-uniform)
+	bool partial_flushes = false;  // last resort for a bucket that more than AGG_MAX_SUBPASSES passes cannot hold
 
 	// flush() and expand() are wave-uniform: their conditions come from fill counters read after wave_sync().
 	// flush: the k-mer table's entries continue the wavefront's current log chunk and spill over into a new one.
-	auto flush = [&](bool last) {
+	auto flush = [&]() {
 		const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)T.fill);
 		if (n == 0) return;
-		const uint64_t mark = (flag_unique && last && bucket_flushes == 0 &&
-		                       __builtin_amdgcn_readfirstlane((int)T.spilled) == 0) ? LOG_UNIQUE : 0ull;
-		bucket_flushes++;
+		const uint64_t mark = (flag_unique && !partial_flushes && __builtin_amdgcn_readfirstlane((int)T.spilled) == 0) ? LOG_UNIQUE : 0ull;
 		const uint32_t room = (chunk_base == NO_CHUNK) ? 0u : LOG_CHUNK - chunk_used;
 		const unsigned long long old_dst = chunk_base + chunk_used;
 		unsigned long long new_dst = 0;
@@ -669,10 +680,38 @@ __global__ __launch_bounds__(64 * AGG_WAVES) void k_aggregate(const Rec<W> *__re
 		wave_sync();
 	};
 
-	// expand: every distinct record of the record table goes through the k-mer table once, weighted
-	auto expand = [&]() {
+	// drop what both tables hold without writing anything (a bucket attempt that overflowed)
+	auto discard = [&]() {
+		const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)T.fill);
+		for (uint32_t i = lane; i < n; i += 64) {
+			const uint32_t sl = T.list[i];
+			T.k0[sl] = EMPTY;
+			if (W == 2) T.k1[sl] = EMPTY;
+			T.stamp[sl] = INF_STAMP;
+			T.cnt[sl] = 0;
+			T.edges[sl] = 0;
+		}
+		const uint32_t nr = (uint32_t)__builtin_amdgcn_readfirstlane((int)R.fill);
+		for (uint32_t i = lane; i < nr; i += 64) {
+			const uint32_t sl = R.list[i];
+			R.fp[sl] = 0;
+			R.cnt[sl] = 0;
+			R.stamp[sl] = INF_STAMP;
+		}
+		if (lane == 0) {
+			T.fill = 0;
+			T.spilled = 0;
+			R.fill = 0;
+		}
+		wave_sync();
+	};
+
+	// expand: every distinct record of the record table goes through the k-mer table once, weighted; of its k-mers
+	// only those of sub-pass `sub` (of `nsub`, a power of two) are taken.  Returns false when the k-mer table would
+	// overfill: the caller then drops the attempt.
+	auto expand = [&](uint32_t sub, uint32_t nsub) -> bool {
 		const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)R.fill);
-		if (n == 0) return;
+		if (n == 0) return true;
 		for (uint32_t e0 = 0; e0 < n; e0 += 64) {
 			if (lane == 0) {
 				R.rmax = 0;
@@ -724,7 +763,10 @@ __global__ __launch_bounds__(64 * AGG_WAVES) void k_aggregate(const Rec<W> *__re
 				if (has_next) em |= 1u << (use_rc ? 3u - nb : 4u + nb);
 				uint64_t i0, i1;
 				to_internal<W>(use_rc ? r0 : f0, use_rc ? r1 : f1, i0, i1);
-				if (!lds_upsert<W>(T, i0, i1, stamp0 + i, em, weight)) {
+				const uint32_t hx = agg_hash<W>(i0, i1);
+				if (SLOW && ((hx >> 12) & (nsub - 1)) != sub) {
+					// another sub-pass owns this k-mer
+				} else if (!lds_upsert<W>(T, hx, i0, i1, stamp0 + i, em, weight)) {
 					// LDS table full: this k-mer goes to the log on its own
 					unsigned long long g = atomicAdd(&counters[PC_LOG_CURSOR], 1ull);
 					if (g < log_cap) {
@@ -765,12 +807,16 @@ __global__ __launch_bounds__(64 * AGG_WAVES) void k_aggregate(const Rec<W> *__re
 				for (uint32_t i = 0; i < rmax; ++i) {
 					if (i < len) step(i);
 					wave_sync();
-					if ((uint32_t)__builtin_amdgcn_readfirstlane((int)T.fill) > AGG_FLUSH) flush(false);
+					if ((uint32_t)__builtin_amdgcn_readfirstlane((int)T.fill) > AGG_FLUSH) {
+						if (!partial_flushes) return false;
+						flush();
+					}
 				}
 			}
 		}
 		if (lane == 0) R.fill = 0;
 		wave_sync();
+		return true;
 	};
 
 	for (uint32_t i = lane; i < AGG_SLOTS; i += 64) {
@@ -793,11 +839,13 @@ __global__ __launch_bounds__(64 * AGG_WAVES) void k_aggregate(const Rec<W> *__re
 	wave_sync();
 
 	const uint32_t stride = gridDim.x * AGG_WAVES;
+	// nbuckets = number of buckets to visit: all of them, or (SLOW) the length of bucket_list
 	uint32_t b = blockIdx.x * AGG_WAVES + wave;
 	uint64_t cb = 0, ce = 0;
 	if (b < nbuckets) {
-		cb = bucket_begin[b];
-		ce = bucket_begin[b + 1];
+		const uint32_t bb = SLOW ? bucket_list[b] : b;
+		cb = bucket_begin[bb];
+		ce = bucket_begin[bb + 1];
 	}
 	Rec<W> nxt;
 #pragma unroll
@@ -807,84 +855,118 @@ __global__ __launch_bounds__(64 * AGG_WAVES) void k_aggregate(const Rec<W> *__re
 		const uint32_t b2 = b + stride;  // the bucket after this one: its bounds are fetched now, used at the last round
 		uint64_t nb_begin = 0, nb_end = 0;
 		if (b2 < nbuckets) {
-			nb_begin = bucket_begin[b2];
-			nb_end = bucket_begin[b2 + 1];
+			const uint32_t bb = SLOW ? bucket_list[b2] : b2;
+			nb_begin = bucket_begin[bb];
+			nb_end = bucket_begin[bb + 1];
 		}
-		if (!prefetched && cb + lane < ce) nxt = recs[cb + lane];
-		prefetched = false;
-		for (uint64_t base = cb; base < ce; base += 64) {
-			const Rec<W> rec = nxt;
-			bool pending = base + lane < ce;
-			if (base + 64 < ce) {
-				if (base + 64 + lane < ce) nxt = recs[base + 64 + lane];
-			} else {
-				if (nb_begin + lane < nb_end) nxt = recs[nb_begin + lane];
-				prefetched = true;
-			}
-			uint64_t bw[NB], stamp0 = 0;
-			unsigned long long fp = 0;
-			uint32_t tag = 0, sl = 0;
-			{
-				const uint64_t hdr = rec.w[NB];
-				tag = (uint32_t)(hdr >> 16) & 0x7FFFu;
-				stamp0 = ((hdr >> 31) << 16) | ((uint32_t)hdr & 0xFFFFu);
-				uint64_t h = (uint64_t)tag * 0x9E3779B97F4A7C15ull;
-#pragma unroll
-				for (int i = 0; i < NB; ++i) {
-					bw[i] = rec.w[i];
-					h = (h ^ bw[i]) * 0xC2B2AE3D27D4EB4Full;
-					h ^= h >> 29;
+		// one pass over the bucket's records for sub-pass `sub` of `nsub`; true = the k-mer table overflowed
+		bool next_ready = false;  // nxt already holds the next bucket's first round
+		auto pass = [&](uint32_t sub, uint32_t nsub) -> bool {
+			bool overflow = false;
+			next_ready = false;
+			if (!prefetched && cb + lane < ce) nxt = recs[cb + lane];
+			prefetched = false;
+			for (uint64_t base = cb; base < ce && !overflow; base += 64) {
+				const Rec<W> rec = nxt;
+				bool pending = base + lane < ce;
+				if (base + 64 < ce) {
+					if (base + 64 + lane < ce) nxt = recs[base + 64 + lane];
+				} else if (sub + 1 == nsub) {  // last round of the last sub-pass: the next bucket's first round
+					if (nb_begin + lane < nb_end) nxt = recs[nb_begin + lane];
+					prefetched = true;
+					next_ready = true;
 				}
-				h *= 0xBF58476D1CE4E5B9ull;
-				h ^= h >> 32;
-				fp = h | 1ull;
-				sl = (uint32_t)(h >> 40) & (RT_SLOTS - 1);
-			}
-			do {
-				bool owner = false;
-				if (pending) {
-					for (;;) {  // ends: the table is never more than 3/4 full
-						unsigned long long cur = R.fp[sl];
-						if (cur == 0) {
-							cur = atomicCAS(&R.fp[sl], 0ull, fp);
+				uint64_t bw[NB], stamp0 = 0;
+				unsigned long long fp = 0;
+				uint32_t tag = 0, sl = 0;
+				{
+					const uint64_t hdr = rec.w[NB];
+					tag = (uint32_t)(hdr >> 16) & 0x7FFFu;
+					stamp0 = ((hdr >> 31) << 16) | ((uint32_t)hdr & 0xFFFFu);
+					uint64_t h = (uint64_t)tag * 0x9E3779B97F4A7C15ull;
+#pragma unroll
+					for (int i = 0; i < NB; ++i) {
+						bw[i] = rec.w[i];
+						h = (h ^ bw[i]) * 0xC2B2AE3D27D4EB4Full;
+						h ^= h >> 29;
+					}
+					h *= 0xBF58476D1CE4E5B9ull;
+					h ^= h >> 32;
+					fp = h | 1ull;
+					sl = (uint32_t)(h >> 40) & (RT_SLOTS - 1);
+				}
+				do {
+					bool owner = false;
+					if (pending) {
+						for (;;) {  // ends: the table is never more than 3/4 full
+							unsigned long long cur = R.fp[sl];
 							if (cur == 0) {
-								owner = true;
-								break;
+								cur = atomicCAS(&R.fp[sl], 0ull, fp);
+								if (cur == 0) {
+									owner = true;
+									break;
+								}
 							}
+							if (cur == fp) break;
+							sl = (sl + 1) & (RT_SLOTS - 1);
 						}
-						if (cur == fp) break;
-						sl = (sl + 1) & (RT_SLOTS - 1);
-					}
-					if (owner) {
+						if (owner) {
 #pragma unroll
-						for (int i = 0; i < NB; ++i) R.w[i][sl] = bw[i];
-						R.tag[sl] = tag;
-						R.list[atomicAdd(&R.fill, 1u)] = (uint16_t)sl;
+							for (int i = 0; i < NB; ++i) R.w[i][sl] = bw[i];
+							R.tag[sl] = tag;
+							R.list[atomicAdd(&R.fill, 1u)] = (uint16_t)sl;
+						}
 					}
-				}
-				wave_sync();
-				if (pending) {
-					bool same = true;
-					if (!owner) {
-						same = (R.tag[sl] == tag);
+					wave_sync();
+					if (pending) {
+						bool same = true;
+						if (!owner) {
+							same = (R.tag[sl] == tag);
 #pragma unroll
-						for (int i = 0; i < NB; ++i) same = same && (R.w[i][sl] == bw[i]);
+							for (int i = 0; i < NB; ++i) same = same && (R.w[i][sl] == bw[i]);
+						}
+						if (same) {
+							atomicAdd(&R.cnt[sl], 1u);
+							atomicMin(reinterpret_cast<unsigned long long *>(&R.stamp[sl]), (unsigned long long)stamp0);
+							pending = false;
+						} else {
+							sl = (sl + 1) & (RT_SLOTS - 1);  // same fingerprint, different record: keep probing
+						}
 					}
-					if (same) {
-						atomicAdd(&R.cnt[sl], 1u);
-						atomicMin(reinterpret_cast<unsigned long long *>(&R.stamp[sl]), (unsigned long long)stamp0);
-						pending = false;
-					} else {
-						sl = (sl + 1) & (RT_SLOTS - 1);  // same fingerprint, different record: keep probing
-					}
+					wave_sync();
+				} while (__any(pending));
+				if ((uint32_t)__builtin_amdgcn_readfirstlane((int)R.fill) > RT_FLUSH) overflow = !expand(sub, nsub);
+			}
+			if (!overflow) overflow = !expand(sub, nsub);
+			return overflow;
+		};
+		partial_flushes = false;
+		if (!SLOW) {
+			if (!pass(0, 1)) {
+				flush();  // once per bucket: the entries are unique in the log
+			} else {      // leave the bucket to the second launch; nothing of it was written
+				discard();
+				if (lane == 0) retry_list[atomicAdd(&counters[PC_AGG_RETRY], 1ull)] = b;
+				prefetched = next_ready;
+			}
+		} else {
+			// Sub-pass 0 is the probe: if its k-mers do not fit the table nothing has been written yet, so the split
+			// is doubled and the bucket starts over.  A later sub-pass that overflows (its share is larger than the
+			// probe's) is redone alone with partial flushes allowed; its entries then lose the unique mark, nothing else.
+			uint32_t nsub = 2, sub = 0;  // a listed bucket is known not to fit in one pass
+			while (sub < nsub) {
+				if (!pass(sub, nsub)) {
+					flush();  // once per (bucket, sub-pass): the entries are unique in the log
+					partial_flushes = false;
+					sub++;
+					continue;
 				}
-				wave_sync();
-			} while (__any(pending));
-			if ((uint32_t)__builtin_amdgcn_readfirstlane((int)R.fill) > RT_FLUSH) expand();
+				discard();  // nothing of this sub-pass was written
+				prefetched = false;
+				if (sub == 0 && nsub < AGG_MAX_SUBPASSES) nsub *= 2;
+				else partial_flushes = true;
+			}
 		}
-		expand();
-		flush(true);
-		bucket_flushes = 0;
 		if (lane == 0) T.spilled = 0;
 		b = b2;
 		cb = nb_begin;
