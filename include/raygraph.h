@@ -186,6 +186,10 @@ int rg_read_markers(rg_handle *h, int32_t *d_forward, int32_t *d_reverse);
  * master rank only); both strands of every record, in the order of `records`. */
 int rg_write_kmers_txt(const void *records, uint64_t n_pairs, int k, int kmer_words, const char *path, int write_header,
                        const char *ray_version, int append);
+/* rg_import_vertices: the reverse of rg_export on a fresh handle without reads -- what reading the GenomeGraph
+ * checkpoint does to the GridTable (MessageProcessor.cpp:596-655, Vertex::load Vertex.cpp:422-436): n_pairs records in
+ * Vertex::dump layout become the vertex store, coverage and edges final (rg_purge_*, rg_find, rg_export, ... work). */
+int rg_import_vertices(rg_handle *h, const void *records, uint64_t n_pairs);
 int rg_write_genome_graph(const void *records, uint64_t n_pairs, int k, int kmer_words, const char *path);
 int rg_write_coverage_checkpoint(const uint32_t *coverage, const uint64_t *count, uint64_t n, const char *path);
 int rg_write_graph_partition(const uint64_t *sizes, int nranks, const char *path);

@@ -650,6 +650,48 @@ __global__ __launch_bounds__(256) void k_read_markers(const uint64_t *__restrict
 	}
 }
 
+// Vertex::load for a whole checkpoint (Vertex.cpp:422-436, MessageProcessor.cpp:596-655): records in Vertex::dump
+// layout go straight into the table with their coverage and edge byte
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_import(const uint8_t *__restrict__ rec, uint64_t n, Slot *__restrict__ tab, uint64_t mask,
+                                                  unsigned long long *__restrict__ counters) {
+	constexpr int REC = W * 8 + 5;
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	bool failed = false;
+	uint32_t claimed = 0;
+	for (; i < n; i += stride) {
+		const uint8_t *p = rec + i * REC;
+		uint64_t K0 = 0, K1 = 0;
+		for (int b = 0; b < 8; ++b) K0 |= (uint64_t)p[b] << (8 * b);
+		if (W == 2)
+			for (int b = 0; b < 8; ++b) K1 |= (uint64_t)p[8 + b] << (8 * b);
+		uint64_t cov = 0;
+		for (int b = 0; b < 4; ++b) cov |= (uint64_t)p[W * 8 + b] << (8 * b);
+		const uint64_t e = p[W * 8 + 4];
+		uint64_t i0, i1;
+		to_internal<W>(K0, K1, i0, i1);
+		// the keys of a checkpoint are distinct: claim a free slot and store the payload plainly (as k_rehash does)
+		uint64_t sl = slot_hash<W>(i0, W == 2 ? i1 : 0) & mask;
+		bool done = false;
+		for (uint32_t probe = 0; probe < MAX_PROBE && !done; ++probe) {
+			Slot *q = tab + sl;
+			const uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long *>(&q->k0), EMPTY, i0);
+			if (prev == EMPTY) {
+				q->k1 = (W == 2) ? i1 : 0;
+				q->stamp = 0;
+				q->meta = cov | (e << PUB_SHIFT);
+				claimed++;
+				done = true;
+			}
+			sl = (sl + 1) & mask;
+		}
+		if (!done) failed = true;
+	}
+	if (claimed) atomicAdd(&counters[C_FILL], (unsigned long long)claimed);
+	if (failed) atomicAdd(&counters[C_ERR], 1ull);
+}
+
 // ---- purge across ranks: the neighbour-existence queries of EdgePurgerWorker.cpp:36-44,73-81 in bulk ------
 // neighbour (in canonical internal form) named by edge bit `bit` of the stored key (K0,K1)
 template <int W>
@@ -2441,6 +2483,35 @@ int rg_read_markers(rg_handle *h, int32_t *d_forward, int32_t *d_reverse) {
 		done += b.n;
 	}
 	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	return RG_OK;
+}
+
+int rg_import_vertices(rg_handle *h, const void *records, uint64_t n_pairs) {
+	if (h) h->hist_valid = false;
+	if (!h || (n_pairs && !records)) return RG_ERR_ARG;
+	if (h->phase != PH_CREATED || h->n_reads) return fail(h, RG_ERR_STATE, "rg_import_vertices needs a fresh handle without reads");
+	HIP_TRY(h, hipSetDevice(h->cfg.device));
+	int rc = table_reserve(h, h->tab, std::max<uint64_t>(1, n_pairs), C_FILL);
+	if (rc) return rc;
+	const size_t bytes = (size_t)n_pairs * (h->W * 8 + 5);
+	uint8_t *d = nullptr;
+	if (n_pairs) {
+		HIP_TRY(h, pool_alloc(h->cfg.device, (void **)&d, bytes));
+		hipError_t e = hipMemcpyAsync(d, records, bytes, hipMemcpyHostToDevice, h->stream);
+		if (e == hipSuccess) {
+			if (h->W == 1) hipLaunchKernelGGL(k_import<1>, dim3(grid_for(n_pairs)), dim3(BLOCK), 0, h->stream, d, n_pairs, h->tab.slots, h->tab.cap - 1, h->d_counters);
+			else hipLaunchKernelGGL(k_import<2>, dim3(grid_for(n_pairs)), dim3(BLOCK), 0, h->stream, d, n_pairs, h->tab.slots, h->tab.cap - 1, h->d_counters);
+			e = hipGetLastError();
+		}
+		rc = (e == hipSuccess) ? sync_counters(h) : fail(h, RG_ERR_HIP, "rg_import_vertices: %s", hipGetErrorString(e));
+		pool_free(h->cfg.device, d);
+		if (rc) return rc;
+	}
+	h->tab.fill_known = h->h_counters[C_FILL];
+	h->tab.fill_pending = 0;
+	h->stats.candidates = h->stats.stored_pairs = h->h_counters[C_FILL];
+	h->stats.table_slots = h->tab.cap;
+	h->phase = PH_EDGES;  // a checkpoint is written after pass 2: coverage and edges are final
 	return RG_OK;
 }
 

@@ -174,6 +174,11 @@ class GraphBuilder:
                                          C.byref(n), C.byref(nb)))
         return packed[: nb.value], off[: n.value], ln[: n.value]
 
+    def import_vertices(self, records):
+        """load exported records (or a parsed GenomeGraph checkpoint) into a fresh builder: coverage and edges final"""
+        records = np.ascontiguousarray(records)
+        self._check(self._L.rg_import_vertices(self._h, records.ctypes.data, len(records)))
+
     def read_markers(self, n_reads):
         """SequencesIndexer marker positions (forward, reverse) of every read, -1 = none (IndexerWorker.cpp:67-248)"""
         import torch

@@ -170,3 +170,30 @@ def test_standalone_driver_writes_rays_files(oracle, tmp_path):
     want_cc = str(tmp_path / "want_cc")
     oracle.write_coverage_checkpoint(cov, cnt, want_cc)
     assert open(ck / "Rank0.Checkpoint.CoverageDistribution.ray", "rb").read() == open(want_cc, "rb").read()
+
+
+@pytest.mark.parametrize("k", [31, 63])
+def test_import_vertices_resumes_from_exported_records(oracle, k):
+    """what Ray does when it reads the GenomeGraph checkpoint (MessageProcessor.cpp:596-655): the exported records
+    become the vertex store again, and the later stages (purge, look-ups, degree table) give the same results"""
+    import ray_amd
+    packed, offsets, lengths = make_reads_numpy(genome=8000, read_len=150, n_reads=2500, seed=31 + k, error=0.02)
+    a = ray_amd.GraphBuilder(k, bloom_bits=200000)
+    a.add_reads(packed, offsets, lengths)
+    a.count_kmers()
+    a.add_edges()
+    rec = a.export()
+    b = ray_amd.GraphBuilder(k)
+    b.import_vertices(rec)
+    assert b.size_() == a.size_()
+    assert_records_equal(b.export(), rec, "imported")
+    a.purge_edges()
+    b.purge_edges()
+    assert_records_equal(b.export(), a.export(), "purged after import")
+    assert np.array_equal(b.degree_distribution(), a.degree_distribution())
+    g = oracle.Graph(k, bloom_bits=200000)
+    g.set_reads(packed, offsets, lengths)
+    g.count_kmers()
+    g.add_edges()
+    g.purge_edges()
+    assert_records_equal(b.export(), g.export(), "vs oracle")
