@@ -342,7 +342,7 @@ __global__ __launch_bounds__(BLOCK) void k_admit(Slot *__restrict__ tab, uint64_
 	for (; i < cap; i += stride) {
 		Slot v = tab[i];
 		if (v.k0 == EMPTY) continue;
-		const uint64_t N = v.meta & COUNT_MASK;
+		const uint64_t N = v.meta & COUNT_MASK & ~LOG_UNIQUE;  // (the slot may be a log entry: drop its mark)
 		uint64_t cov;
 		if (BLOOM) {
 			uint64_t K0, K1;
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(BLOCK) void k_admit_lost(Slot *__restrict__ tab, ui
 	for (; i < cap; i += stride) {
 		Slot v = tab[i];
 		if (v.k0 == EMPTY) continue;
-		const uint64_t N = v.meta & COUNT_MASK;
+		const uint64_t N = v.meta & COUNT_MASK & ~LOG_UNIQUE;  // (the slot may be a log entry: drop its mark)
 		const uint32_t nlost = (lost[i >> 2] >> ((i & 3u) * 8u)) & 0xFFu;
 		uint64_t cov;
 		if (nlost == 8) cov = N + 1;
@@ -692,6 +692,39 @@ __global__ __launch_bounds__(BLOCK) void k_import(const uint8_t *__restrict__ re
 	if (failed) atomicAdd(&counters[C_ERR], 1ull);
 }
 
+// admitted log entries -> vertex table.  The entries are distinct keys whose coverage and edge bits are final
+// (the admission ran on the log itself), so a slot is claimed and the payload stored plainly; entries that were
+// not admitted (coverage 0) never reach the table -- like the reference, whose Bloom filter stands before its table.
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_insert_admitted(const Slot *__restrict__ log, uint64_t n, Slot *__restrict__ tab, uint64_t mask,
+                                                           unsigned long long *__restrict__ counters) {
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	bool failed = false;
+	uint32_t claimed = 0;
+	for (; i < n; i += stride) {
+		const Slot v = log[i];
+		if (v.k0 == EMPTY || (v.meta & COUNT_MASK) == 0) continue;
+		uint64_t sl = slot_hash<W>(v.k0, W == 2 ? v.k1 : 0) & mask;
+		bool done = false;
+		for (uint32_t probe = 0; probe < MAX_PROBE && !done; ++probe) {
+			Slot *q = tab + sl;
+			const uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long *>(&q->k0), EMPTY, v.k0);
+			if (prev == EMPTY) {
+				q->k1 = v.k1;
+				*reinterpret_cast<ulonglong2 *>(&q->stamp) = make_ulonglong2(v.stamp, v.meta);
+				claimed++;
+				done = true;
+			}
+			sl = (sl + 1) & mask;
+		}
+		if (!done) failed = true;
+	}
+	for (int d = 32; d > 0; d >>= 1) claimed += __shfl_down(claimed, d);
+	if ((threadIdx.x & 63) == 0 && claimed) atomicAdd(&counters[C_FILL], (unsigned long long)claimed);
+	if (failed) atomicAdd(&counters[C_ERR], 1ull);
+}
+
 // ---- purge across ranks: the neighbour-existence queries of EdgePurgerWorker.cpp:36-44,73-81 in bulk ------
 // neighbour (in canonical internal form) named by edge bit `bit` of the stored key (K0,K1)
 template <int W>
@@ -982,6 +1015,10 @@ struct rg_handle {
 	bool profiling = false;
 	std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof;
 	// rg_histogram is called twice by every caller (size query, then fill): the table is scanned once
+	bool log_all_unique = false;         // the last sweep's log holds every key once
+	uint64_t log_keys = 0;               // entries of the last sweep's log
+	Slot *pending_log = nullptr;         // size == 1: the sweep's log of distinct k-mers, admitted before it is inserted
+	uint64_t pending_n = 0, pending_keys = 0;
 	void *rec_buf = nullptr;             // rg_records_local .. rg_export_records: super-k-mer records of the local reads
 	uint64_t rec_slots = 0;              // slots of rec_buf in use (holes included)
 	std::vector<uint64_t> rec_counts;    // valid records per destination rank
@@ -1106,6 +1143,7 @@ static int table_reserve(rg_handle *h, Table &t, uint64_t need, int fill_counter
 template <int W>
 static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bool *ok, const void *ext = nullptr, uint64_t ext_n = 0) {
 	*ok = false;
+	h->log_all_unique = false;
 	*out_log = nullptr;
 	*out_n = 0;
 	const int dev = h->cfg.device;
@@ -1342,6 +1380,8 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	*out_log = log;
 	*out_n = h->h_counters[PC_LOG_CURSOR];
 	*ok = true;
+	h->log_all_unique = flag_unique && h->h_counters[PC_NONUNIQUE] == 0 && h->h_counters[PC_LDS_SPILL] == 0;
+	h->log_keys = h->h_counters[PC_LOG_KEYS];
 	h->stats.superkmer_records = valid;
 	h->stats.partition_levels = (uint64_t)((dbits[0] > 0) + (dbits[1] > 0) + (dbits[2] > 0));
 	h->stats.log_entries = *out_n;
@@ -1475,10 +1515,10 @@ static int export_records_t(rg_handle *h, void *d_out) {
 
 // ---- Bloom admission through region partitioning (rg_bloom.h) -----------------------------------
 // *ok = false: not applicable or a region overflowed; the caller then uses the dense stamp method.
-static int bloom_partitioned(rg_handle *h, uint64_t m_bits, uint64_t keys, bool *ok) {
+// T: the slots whose keys go through the filter -- the vertex table, or the log of the sweep (same 32-byte layout)
+static int bloom_partitioned(rg_handle *h, Table &T, uint64_t m_bits, uint64_t keys, bool *ok) {
 	*ok = false;
 	const int dev = h->cfg.device;
-	Table &T = h->tab;
 	const uint64_t R = (m_bits + REGION_BITS - 1) / REGION_BITS;
 	if (R > 65536 || T.cap >= (1ull << 31) || keys == 0) return RG_OK;
 	const int nlevels = R > 256 ? 2 : 1;
@@ -1629,6 +1669,29 @@ static int bloom_partitioned(rg_handle *h, uint64_t m_bits, uint64_t keys, bool 
 	return RG_OK;
 }
 
+// size == 1 with a pending log and a caller that wants the table of all candidates before admission (the owner
+// exchange calls): the classic merge of the whole log
+static int materialize_pending_log(rg_handle *h) {
+	if (!h->pending_log) return RG_OK;
+	Table &T = h->tab;
+	int rc = table_reserve(h, T, h->pending_n, C_FILL);
+	if (rc) return rc;
+	{
+		ProfScope ps(h, "k_merge");
+		if (h->W == 1) hipLaunchKernelGGL(k_merge<1>, dim3(grid_for(h->pending_n)), dim3(BLOCK), 0, h->stream, h->pending_log, h->pending_n, T.slots, T.cap - 1, h->d_counters);
+		else hipLaunchKernelGGL(k_merge<2>, dim3(grid_for(h->pending_n)), dim3(BLOCK), 0, h->stream, h->pending_log, h->pending_n, T.slots, T.cap - 1, h->d_counters);
+	}
+	if (hipGetLastError() != hipSuccess) return fail(h, RG_ERR_HIP, "k_merge launch failed");
+	rc = sync_counters(h);
+	pool_free(h->cfg.device, h->pending_log);
+	h->pending_log = nullptr;
+	h->pending_n = 0;
+	if (rc) return rc;
+	T.fill_known = h->h_counters[C_FILL];
+	T.fill_pending = 0;
+	return RG_OK;
+}
+
 // reads the device histogram (dense bins + overflow list) back and caches it in the handle
 static int collect_histogram(rg_handle *h, const unsigned long long *dense, const uint32_t *ovf) {
 	std::vector<unsigned long long> hd(HIST_DENSE);
@@ -1725,6 +1788,7 @@ int rg_destroy(rg_handle *h) {
 	if (h->d_owner) pool_free(h->cfg.device, h->d_owner);
 	if (h->d_purge_origin) pool_free(h->cfg.device, h->d_purge_origin);
 	if (h->rec_buf) pool_free(h->cfg.device, h->rec_buf);
+	if (h->pending_log) pool_free(h->cfg.device, h->pending_log);
 	if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
 	delete h;
 	return RG_OK;
@@ -1812,7 +1876,14 @@ int rg_count_local(rg_handle *h) {
 			if (rc) return rc;
 			if (ok) {
 				h->stats.sweep_partitioned = 1;
-				if (single) {
+				if (single && h->log_all_unique && n_log && n_log < (1ull << 31)) {
+					// admission first, insertion afterwards (rg_resolve_admission): only stored vertices reach the table
+					h->pending_log = log;
+					h->pending_n = n_log;
+					h->pending_keys = h->log_keys;
+					rc = sync_counters(h);
+					if (rc) return rc;
+				} else if (single) {
 					rc = table_reserve(h, T, n_log ? n_log : 1, fill_counter);
 					if (rc == RG_OK && n_log) {
 						ProfScope ps(h, "k_merge");
@@ -1953,6 +2024,7 @@ int rg_owner_counts(rg_handle *h, uint64_t *counts) {
 	if (!h || !counts) return RG_ERR_ARG;
 	if (h->phase != PH_COUNTED_LOCAL) return fail(h, RG_ERR_STATE, "rg_owner_counts needs rg_count_local first");
 	HIP_TRY(h, hipSetDevice(h->cfg.device));
+	if (int rcm = materialize_pending_log(h)) return rcm;
 	const uint32_t size = (uint32_t)h->cfg.size;
 	Table &T = size == 1 ? h->tab : h->local;
 	HIP_TRY(h, hipMemsetAsync(h->d_owner, 0, sizeof(unsigned long long) * 2 * size, h->stream));
@@ -1970,6 +2042,7 @@ int rg_export_owner_buckets(rg_handle *h, void *d_out, uint64_t capacity_entries
 	if (!h) return RG_ERR_ARG;
 	if (h->phase != PH_COUNTED_LOCAL) return fail(h, RG_ERR_STATE, "rg_export_owner_buckets needs rg_count_local first");
 	HIP_TRY(h, hipSetDevice(h->cfg.device));
+	if (int rcm = materialize_pending_log(h)) return rcm;
 	const uint32_t size = (uint32_t)h->cfg.size;
 	Table &T = size == 1 ? h->tab : h->local;
 	std::vector<unsigned long long> cursors(size);
@@ -2022,7 +2095,13 @@ int rg_resolve_admission(rg_handle *h, uint64_t local_reads_for_bloom) {
 		if (h->phase == PH_COUNTED_LOCAL) table_free(h, h->local);
 	}
 	HIP_TRY(h, hipSetDevice(h->cfg.device));
-	Table &T = h->tab;
+	// Admission runs on the slots that hold the candidate keys: the vertex table, or -- one rank, partitioned sweep,
+	// every key once in the log -- the log itself, whose admitted entries are inserted afterwards.
+	const bool from_log = h->pending_log != nullptr;
+	Table logview;
+	logview.slots = h->pending_log;
+	logview.cap = h->pending_n;
+	Table &T = from_log ? logview : h->tab;
 	if (!T.slots) {
 		int rc = table_reserve(h, T, 1, C_FILL);
 		if (rc) return rc;
@@ -2062,13 +2141,13 @@ int rg_resolve_admission(rg_handle *h, uint64_t local_reads_for_bloom) {
 		// first, bit 5 the second (tests).
 		int rc0 = sync_counters(h);
 		if (rc0) return rc0;
-		const uint64_t keys = h->h_counters[C_FILL];
+		const uint64_t keys = from_log ? h->pending_keys : h->h_counters[C_FILL];
 		const uint32_t flags = (uint32_t)h->cfg.reserved0 & 0xFFu;
 		const double lambda = 8.0 * (double)keys / (double)m_bits;
 		// worth it while a region's contested bits (expected: 2^17 * P(two or more touchers)) fit the LDS rank table
 		const double contested = (double)REGION_BITS * (1.0 - std::exp(-lambda) * (1.0 + lambda));
 		if (!(flags & 32u) && ((flags & 16u) || (contested <= 0.9 * REGION_MULTI_CAP_BIG && keys >= (1ull << 20)))) {
-			rc0 = bloom_partitioned(h, m_bits, keys, &resolved);
+			rc0 = bloom_partitioned(h, T, m_bits, keys, &resolved);
 			if (rc0) return rc0;
 			h->stats.bloom_partitioned = resolved ? 1 : 0;
 		}
@@ -2105,13 +2184,31 @@ int rg_resolve_admission(rg_handle *h, uint64_t local_reads_for_bloom) {
 	}
 	int rc = collect_histogram(h, h->d_hist_dense, h->d_hist_ovf);
 	if (rc) return rc;
-	T.fill_known = h->h_counters[C_FILL];
-	T.fill_pending = 0;
-	h->stats.candidates = h->h_counters[C_FILL];
+	uint64_t candidates = h->h_counters[C_FILL];
+	if (from_log) {
+		candidates = h->pending_keys;
+		const uint64_t retained = h->h_counters[C_RETAINED];
+		rc = table_reserve(h, h->tab, std::max<uint64_t>(1, retained), C_FILL);
+		if (rc == RG_OK) {
+			ProfScope ps(h, "k_insert_admitted");
+			if (h->W == 1) hipLaunchKernelGGL(k_insert_admitted<1>, dim3(grid_for(h->pending_n)), dim3(BLOCK), 0, h->stream, h->pending_log, h->pending_n, h->tab.slots, h->tab.cap - 1, h->d_counters);
+			else hipLaunchKernelGGL(k_insert_admitted<2>, dim3(grid_for(h->pending_n)), dim3(BLOCK), 0, h->stream, h->pending_log, h->pending_n, h->tab.slots, h->tab.cap - 1, h->d_counters);
+			if (hipGetLastError() != hipSuccess) rc = fail(h, RG_ERR_HIP, "k_insert_admitted launch failed");
+		}
+		if (rc == RG_OK) rc = sync_counters(h);
+		pool_free(h->cfg.device, h->pending_log);
+		h->pending_log = nullptr;
+		h->pending_n = 0;
+		if (rc) return rc;
+		if (h->h_counters[C_FILL] != retained) return fail(h, RG_ERR_STATE, "inserted %llu of %llu admitted vertices", (unsigned long long)h->h_counters[C_FILL], (unsigned long long)retained);
+	}
+	h->tab.fill_known = h->h_counters[C_FILL];
+	h->tab.fill_pending = 0;
+	h->stats.candidates = candidates;
 	h->stats.stored_pairs = h->h_counters[C_RETAINED];
 	h->stats.bloom_insertions = h->h_counters[C_INSERTIONS];
 	h->stats.bloom_set_bits = h->h_counters[C_SETBITS];
-	h->stats.table_slots = T.cap;
+	h->stats.table_slots = h->tab.cap;
 	h->phase = PH_RESOLVED;
 	return RG_OK;
 }

@@ -110,7 +110,7 @@ __device__ __forceinline__ uint32_t rec_bucket(const Rec<W> &r, int m) {
 	return bucket24(canon_mmer(f, m));
 }
 
-enum PartCounter { PC_REC_CURSOR = 16, PC_REC_OVF, PC_LOG_CURSOR, PC_LOG_OVF, PC_LDS_SPILL, PC_AGG_RETRY };
+enum PartCounter { PC_REC_CURSOR = 16, PC_REC_OVF, PC_LOG_CURSOR, PC_LOG_OVF, PC_LDS_SPILL, PC_AGG_RETRY, PC_NONUNIQUE, PC_LOG_KEYS };
 
 // ------------------------------------------------------------------------------------------------
 // reads -> super-k-mer records.  A wavefront takes 64 consecutive reads at a time (their lengths and
@@ -635,6 +635,8 @@ __global__ __launch_bounds__(64 * AGG_WAVES) void k_aggregate(const Rec<W> *__re
 	const unsigned long long NO_CHUNK = ~0ull;
 	unsigned long long chunk_base = NO_CHUNK;  // wave-uniform
 	uint32_t chunk_used = 0;
+	unsigned long long keys_written = 0;
+	uint32_t nonunique_flushes = 0;
 	bool partial_flushes = false;  // last resort for a bucket that more than AGG_MAX_SUBPASSES passes cannot hold
 
 	// flush() and expand() are wave-uniform: their conditions come from fill counters read after wave_sync().
@@ -643,6 +645,10 @@ __global__ __launch_bounds__(64 * AGG_WAVES) void k_aggregate(const Rec<W> *__re
 		const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)T.fill);
 		if (n == 0) return;
 		const uint64_t mark = (flag_unique && !partial_flushes && __builtin_amdgcn_readfirstlane((int)T.spilled) == 0) ? LOG_UNIQUE : 0ull;
+		// what the host needs to know about the log: its number of entries, and whether all are unique keys (summed per
+		// wavefront, added once at the end: the counters share a cache line with the log cursor)
+		keys_written += n;
+		if (!mark) nonunique_flushes++;
 		const uint32_t room = (chunk_base == NO_CHUNK) ? 0u : LOG_CHUNK - chunk_used;
 		const unsigned long long old_dst = chunk_base + chunk_used;
 		unsigned long long new_dst = 0;
@@ -971,6 +977,10 @@ __global__ __launch_bounds__(64 * AGG_WAVES) void k_aggregate(const Rec<W> *__re
 		b = b2;
 		cb = nb_begin;
 		ce = nb_end;
+	}
+	if (lane == 0) {
+		if (keys_written) atomicAdd(&counters[PC_LOG_KEYS], keys_written);
+		if (nonunique_flushes) atomicAdd(&counters[PC_NONUNIQUE], (unsigned long long)nonunique_flushes);
 	}
 	// close the last chunk
 	if (chunk_base != NO_CHUNK)

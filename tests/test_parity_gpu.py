@@ -47,7 +47,8 @@ def test_reads_added_in_several_batches_and_table_growth(oracle):
     """rg_add_reads may be called repeatedly; read ids (hence arrival stamps) continue, the table grows"""
     packed, offsets, lengths = make_reads_numpy(genome=30000, read_len=100, n_reads=8000, seed=21, error=0.02)
     want = gpu_vs_oracle(oracle, packed, offsets, lengths, 31, bloom_bits=150000, batches=7)
-    assert want["builder"].stats()["table_slots"] >= 2 * want["builder"].stats()["candidates"] * 0.7
+    st = want["builder"].stats()
+    assert st["table_slots"] * 0.7 >= st["stored_pairs"]   # load factor <= 0.7, whichever route built the table
 
 
 def test_bloom_region_partitioning_is_used_and_exact(oracle):
