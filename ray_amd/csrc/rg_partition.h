@@ -956,20 +956,37 @@ __global__ __launch_bounds__(64 * AGG_WAVES) void k_aggregate(const Rec<W> *__re
 				prefetched = next_ready;
 			}
 		} else {
-			// Sub-pass 0 is the probe: if its k-mers do not fit the table nothing has been written yet, so the split
-			// is doubled and the bucket starts over.  A later sub-pass that overflows (its share is larger than the
-			// probe's) is redone alone with partial flushes allowed; its entries then lose the unique mark, nothing else.
+			// The bucket's k-mers are split by bits of their hash: node (nsub, sub) holds those whose low log2(nsub) bits
+			// (from bit 12 up) equal sub.  A node whose k-mers do not fit the table has written nothing yet; it is replaced
+			// by its two halves (2*nsub, sub) and (2*nsub, sub + nsub), visited depth first without a stack: after a node
+			// that is a low half comes its sibling, after a high half the parent is complete.  Only a node that cannot
+			// be halved any more is redone with partial flushes, and its entries alone lose the unique mark.
 			uint32_t nsub = 2, sub = 0;  // a listed bucket is known not to fit in one pass
-			while (sub < nsub) {
+			for (;;) {
 				if (!pass(sub, nsub)) {
-					flush();  // once per (bucket, sub-pass): the entries are unique in the log
+					flush();  // once per (bucket, node): the entries are unique in the log
 					partial_flushes = false;
-					sub++;
+					bool done = false;
+					for (;;) {
+						if (nsub == 1) {
+							done = true;
+							break;
+						}
+						const uint32_t top = nsub >> 1;
+						if (sub & top) {  // high half done: so is the parent
+							sub &= top - 1;
+							nsub = top;
+						} else {
+							sub |= top;
+							break;
+						}
+					}
+					if (done) break;
 					continue;
 				}
-				discard();  // nothing of this sub-pass was written
+				discard();  // nothing of this node was written
 				prefetched = false;
-				if (sub == 0 && nsub < AGG_MAX_SUBPASSES) nsub *= 2;
+				if (nsub < AGG_MAX_SUBPASSES) nsub *= 2;  // low half first: sub keeps its value
 				else partial_flushes = true;
 			}
 		}
