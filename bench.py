@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--cpu-sample-reads", type=int, default=60000, help="reads per CPU baseline instance")
     ap.add_argument("--cpu-cores", type=int, default=0, help="CPU baseline instances; 0 = min(16, host cores): the GPU box's share")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sweep", type=lambda x: int(x, 0), default=0, help="rg_config.reserved0 (development: forces a sweep / bucket bits)")
     ap.add_argument("--breakdown", action="store_true", help="print per-call wall times of the last step to stderr")
     return ap.parse_args()
 
@@ -142,7 +143,7 @@ def main():
     def one_step(profile=False):
         del marks[:]
         mark("start")
-        b = ray_amd.GraphBuilder(k, rank=rank, size=world * emu, device=local_rank, first_read_id=first_read_id, stream=stream)
+        b = ray_amd.GraphBuilder(k, rank=rank, size=world * emu, device=local_rank, first_read_id=first_read_id, stream=stream, sweep=args.sweep)
         if profile:
             b.set_profiling(True)
         b.add_reads_device(packed.data_ptr(), n_reads * ((cfg["read_len"] + 3) // 4), offsets.data_ptr(),

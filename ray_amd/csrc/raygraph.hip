@@ -1171,12 +1171,13 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 		*ok = true;
 		return RG_OK;
 	}
-	// number of buckets: about 4096 k-mer occurrences each, so that whenever duplicates are worth merging
-	// (coverage >= 3) a bucket's distinct k-mers fit the LDS table of k_aggregate
+	// number of buckets: at most 2048 k-mer occurrences each, so that at the coverage assemblies are run at (>= 10)
+	// a bucket's distinct k-mers fit the LDS table of k_aggregate; buckets of more diverse inputs are split further
+	// by k_aggregate<SLOW> itself
 	int bits = (h->cfg.reserved0 >> 8) & 0xFF;
 	if (bits == 0) {
 		bits = 8;
-		while (bits < MAX_BUCKET_BITS && (occ_bound >> bits) > 4096) bits++;
+		while (bits < MAX_BUCKET_BITS && (occ_bound >> bits) > 2048) bits++;
 	}
 	if (bits < 8) bits = 8;
 	if (bits > MAX_BUCKET_BITS) bits = MAX_BUCKET_BITS;
@@ -1322,61 +1323,71 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 			}
 		}
 	}
-	// 3. aggregate per bucket into the log.  The log holds one entry per distinct k-mer of a bucket
-	// flush; a quarter of the occurrences is a deterministic size (the pool reuses the block) that only
-	// low-coverage inputs exceed -- they fall back to the direct sweep
+	// 3. aggregate per bucket into the log, one entry per distinct k-mer.  A quarter of the occurrences is a
+	// deterministic size (the pool reuses the block) that only inputs of little redundancy (coverage below 4, or
+	// errors in most reads) exceed; for them the aggregation is run again with a larger log.
 	const unsigned agg_grid = (unsigned)std::min<uint64_t>((NBUCK + AGG_WAVES - 1) / AGG_WAVES, (uint64_t)n_cu * occ3);
-	uint64_t log_cap = std::min<uint64_t>(occ_bound, std::max<uint64_t>(occ_bound / 4, 1ull << 20)) + (uint64_t)agg_grid * AGG_WAVES * LOG_CHUNK;
-	if (pool_alloc(dev, (void **)&log, log_cap * sizeof(Slot)) != hipSuccess) {
-		(void)hipGetLastError();
-		cleanup();
-		return RG_OK;
-	}
+	const uint64_t log_slack = (uint64_t)agg_grid * AGG_WAVES * LOG_CHUNK;
+	uint64_t log_cap = std::min<uint64_t>(occ_bound, std::max<uint64_t>(occ_bound / 4, 1ull << 20)) + log_slack;
+	if (h->cfg.reserved0 & 64) log_cap = LOG_CHUNK;  // tests: the first attempt overflows
 	uint32_t *d_retry = nullptr;
 	if (pool_alloc(dev, (void **)&d_retry, NBUCK * sizeof(uint32_t)) != hipSuccess) {
 		(void)hipGetLastError();
 		cleanup();
-		pool_free(dev, log);
 		return RG_OK;
 	}
 	// entries may be marked unique unless other ranks aggregate the same keys (entry route, size > 1)
 	const uint32_t flag_unique = (h->cfg.size == 1 || ext) ? 1u : 0u;
-	{
-		ProfScope ps(h, "k_aggregate");
-		hipLaunchKernelGGL((k_aggregate<W, false>), dim3(agg_grid), dim3(256), 0, h->stream, level_in, d_begin, (uint32_t)NBUCK, k, log, log_cap,
-		                   h->d_counters, flag_unique, (const uint32_t *)nullptr, d_retry);
-	}
-	hipError_t e0 = hipGetLastError();
-	if (e0 == hipSuccess) {
-		rc = sync_counters(h);
-		const uint64_t n_retry = rc ? 0 : h->h_counters[PC_AGG_RETRY];
-		if (n_retry * 2 > NBUCK && !(h->cfg.reserved0 & 1)) {  // (bit 0: the tests insist on the partitioned sweep)
-			// most buckets hold more distinct k-mers than the LDS table: the data is too diverse (errors, low coverage)
-			// for aggregation to pay, the direct sweep is the better tool
+	for (int attempt = 0;; ++attempt) {
+		if (pool_alloc(dev, (void **)&log, log_cap * sizeof(Slot)) != hipSuccess) {
+			(void)hipGetLastError();
+			log = nullptr;
+			pool_free(dev, d_retry);
+			cleanup();
+			return RG_OK;
+		}
+		bool too_small = false;
+		hipError_t e0 = hipMemsetAsync(h->d_counters + PC_LOG_CURSOR, 0, 6 * sizeof(unsigned long long), h->stream);
+		if (e0 == hipSuccess) {
+			ProfScope ps(h, "k_aggregate");
+			hipLaunchKernelGGL((k_aggregate<W, false>), dim3(agg_grid), dim3(256), 0, h->stream, level_in, d_begin, (uint32_t)NBUCK, k, log, log_cap,
+			                   h->d_counters, flag_unique, (const uint32_t *)nullptr, d_retry, m, (uint32_t)(24 - bits));
+			e0 = hipGetLastError();
+		}
+		if (e0 == hipSuccess) {
+			rc = sync_counters(h);
+			const uint64_t n_retry = rc ? 0 : h->h_counters[PC_AGG_RETRY];
+			// every bucket left over holds more k-mers than the LDS table: if even that many cannot fit, skip the launch
+			if (!rc && n_retry && h->h_counters[PC_LOG_CURSOR] + n_retry * (uint64_t)AGG_LIMIT > log_cap) too_small = true;
+			if (n_retry && !too_small && !h->h_counters[PC_LOG_OVF]) {  // the buckets whose k-mers did not fit the LDS table: split further
+				ProfScope ps(h, "k_aggregate_retry");
+				const unsigned g2 = (unsigned)std::min<uint64_t>((n_retry + AGG_WAVES - 1) / AGG_WAVES, (uint64_t)n_cu * occ3);
+				hipLaunchKernelGGL((k_aggregate<W, true>), dim3(g2), dim3(256), 0, h->stream, level_in, d_begin, (uint32_t)n_retry, k, log, log_cap,
+				                   h->d_counters, flag_unique, (const uint32_t *)d_retry, (uint32_t *)nullptr, m, (uint32_t)(24 - bits));
+			}
+		}
+		hipError_t e = (e0 != hipSuccess) ? e0 : hipGetLastError();
+		if (e == hipSuccess && !rc) rc = sync_counters(h);
+		if (e != hipSuccess || rc) {
 			pool_free(dev, d_retry);
 			cleanup();
 			pool_free(dev, log);
+			return e != hipSuccess ? fail(h, RG_ERR_HIP, "k_aggregate: %s", hipGetErrorString(e)) : rc;
+		}
+		if (!h->h_counters[PC_LOG_OVF] && !too_small) break;
+		pool_free(dev, log);
+		log = nullptr;
+		if (log_cap >= occ_bound + log_slack) {  // cannot happen: one entry per occurrence always fits
+			pool_free(dev, d_retry);
+			cleanup();
 			return RG_OK;
 		}
-		if (n_retry && !h->h_counters[PC_LOG_OVF]) {  // the buckets whose k-mers did not fit the LDS table: sub-passes
-			ProfScope ps(h, "k_aggregate_retry");
-			const unsigned g2 = (unsigned)std::min<uint64_t>((n_retry + AGG_WAVES - 1) / AGG_WAVES, (uint64_t)n_cu * occ3);
-			hipLaunchKernelGGL((k_aggregate<W, true>), dim3(g2), dim3(256), 0, h->stream, level_in, d_begin, (uint32_t)n_retry, k, log, log_cap,
-			                   h->d_counters, flag_unique, (const uint32_t *)d_retry, (uint32_t *)nullptr);
-		}
+		// twice the size, then one slot per occurrence (releasing and mapping tens of GiB is what makes this slow: no more than needed)
+		const uint64_t doubled = (h->cfg.reserved0 & 64) ? 0 : 2 * (log_cap - log_slack);
+		log_cap = ((attempt == 0 && doubled) ? std::min<uint64_t>(occ_bound, doubled) : occ_bound) + log_slack;
 	}
-	hipError_t e = (e0 != hipSuccess) ? e0 : hipGetLastError();
-	if (e == hipSuccess && !rc) rc = sync_counters(h);
 	pool_free(dev, d_retry);
 	cleanup();
-	if (e != hipSuccess || rc) {
-		pool_free(dev, log);
-		return e != hipSuccess ? fail(h, RG_ERR_HIP, "k_aggregate: %s", hipGetErrorString(e)) : rc;
-	}
-	if (h->h_counters[PC_LOG_OVF]) {
-		pool_free(dev, log);
-		return RG_OK;
-	}
 	*out_log = log;
 	*out_n = h->h_counters[PC_LOG_CURSOR];
 	*ok = true;
@@ -1631,7 +1642,7 @@ static int bloom_partitioned(rg_handle *h, Table &T, uint64_t m_bits, uint64_t k
 			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 512, 0) != hipSuccess || occ < 1) occ = 1;
 			(void)hipGetLastError();
 			const unsigned grid = (unsigned)std::min<uint64_t>(NBUCK, (uint64_t)n_cu * occ);
-			hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), 0, h->stream, bufs[cur], d_begin, (uint32_t)NBUCK, T.slots, d_lost, h->d_counters, (int)C_SETBITS);
+			hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), 0, h->stream, bufs[cur], d_begin, (uint32_t)NBUCK, T.slots, d_lost, h->d_counters, (int)C_SETBITS, bufs[cur ^ 1]);
 		};
 		if (h->W == 1) {
 			if (big) launch(k_bloom_region<1, REGION_MULTI_CAP_BIG>);

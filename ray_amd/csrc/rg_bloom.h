@@ -200,10 +200,13 @@ __global__ __launch_bounds__(256) void k_scatter64(const unsigned long long *__r
 // than 512*REGION_PER items takes further rounds that read again.
 static constexpr int REGION_PER = 32;
 template <int W, uint32_t CAP>
-__global__ __launch_bounds__(512) void k_bloom_region(const unsigned long long *__restrict__ items,
+__global__ __launch_bounds__(512, (CAP <= REGION_MULTI_CAP ? 4 : 2)) void k_bloom_region(const unsigned long long *__restrict__ items,
                                                       const unsigned long long *__restrict__ region_begin, uint32_t nregions,
                                                       const Slot *__restrict__ tab, uint32_t *__restrict__ lost,
-                                                      unsigned long long *__restrict__ counters, int c_setbits) {
+                                                      unsigned long long *__restrict__ counters, int c_setbits,
+                                                      unsigned long long *__restrict__ stamp_buf) {
+	// stamp_buf: as long as items; regions of several rounds keep the stamps they gathered for the contested items
+	// there (written and read back in item order) instead of gathering them a second time
 	__shared__ uint32_t s_b1[REGION_WORDS];       // bit touched
 	__shared__ uint32_t s_b2[REGION_WORDS];       // bit touched more than once
 	__shared__ uint16_t s_pre[REGION_WORDS];      // exclusive prefix of popc(s_b2): rank of a contested bit
@@ -340,7 +343,11 @@ __global__ __launch_bounds__(512) void k_bloom_region(const unsigned long long *
 				for (uint64_t i = begin + threadIdx.x; i < end; i += 512) {
 					const unsigned long long it = items[i];
 					uint32_t rank;
-					if (contested_rank(it, rank)) atomicMin(&s_min[rank], (unsigned long long)tab[it & 0x7FFFFFFFull].stamp);
+					if (contested_rank(it, rank)) {
+						const unsigned long long st = tab[it & 0x7FFFFFFFull].stamp;
+						atomicMin(&s_min[rank], st);
+						stamp_buf[i] = st;
+					}
 				}
 				__syncthreads();
 				for (uint64_t i = begin + threadIdx.x; i < end; i += 512) {
@@ -348,7 +355,7 @@ __global__ __launch_bounds__(512) void k_bloom_region(const unsigned long long *
 					uint32_t rank;
 					if (contested_rank(it, rank)) {
 						const uint64_t slot = it & 0x7FFFFFFFull;
-						if (tab[slot].stamp > s_min[rank]) atomicAdd(&lost[slot >> 2], 1u << ((slot & 3u) * 8u));
+						if (stamp_buf[i] > s_min[rank]) atomicAdd(&lost[slot >> 2], 1u << ((slot & 3u) * 8u));
 					}
 				}
 			}

@@ -616,14 +616,17 @@ __global__ __launch_bounds__(64 * AGG_WAVES) void k_aggregate(const Rec<W> *__re
                                                               const unsigned long long *__restrict__ bucket_begin, uint32_t nbuckets,
                                                               int k, Slot *__restrict__ log, uint64_t log_cap,
                                                               unsigned long long *__restrict__ counters, uint32_t flag_unique,
-                                                              const uint32_t *__restrict__ bucket_list, uint32_t *__restrict__ retry_list) {
+                                                              const uint32_t *__restrict__ bucket_list, uint32_t *__restrict__ retry_list,
+                                                              int m, uint32_t rbits) {
 	// flag_unique: the caller guarantees that nothing outside this launch's log carries the same keys on their way
 	// to the same table; the entries are then marked LOG_UNIQUE (every k-mer lives in exactly one bucket, see
 	// k_superkmers, and a bucket is flushed once per sub-pass, each sub-pass owning a disjoint share of the k-mers).
 	// Sub-passes: when the distinct k-mers of a bucket do not fit the LDS table, nothing is flushed half-way (the
 	// occurrences of a k-mer are spread over the whole bucket, so partial flushes would multiply the log); the
-	// attempt is dropped and the bucket is redone in P = 2, 4, ... passes over its records, pass p taking the k-mers
-	// whose hash selects p.
+	// attempt is dropped and the bucket is redone in several passes over its records, each taking a share of them
+	// (see the loop at the end).  The first rbits levels of that split take whole records, by the bits of the
+	// minimizer's bucket number that the partition levels left unused (m = minimizer length): a record that is not
+	// of the pass costs its load and nothing else; further levels take k-mers by bits of their hash.
 	constexpr int NB = 2 * W;
 	__shared__ AggTable<W> s_tables[AGG_WAVES];
 	__shared__ RecTable<W> s_rtables[AGG_WAVES];
@@ -637,6 +640,7 @@ __global__ __launch_bounds__(64 * AGG_WAVES) void k_aggregate(const Rec<W> *__re
 	uint32_t chunk_used = 0;
 	unsigned long long keys_written = 0;
 	uint32_t nonunique_flushes = 0;
+	bool log_full = false;         // wave-uniform
 	bool partial_flushes = false;  // last resort for a bucket that more than AGG_MAX_SUBPASSES passes cannot hold
 
 	// flush() and expand() are wave-uniform: their conditions come from fill counters read after wave_sync().
@@ -658,6 +662,7 @@ __global__ __launch_bounds__(64 * AGG_WAVES) void k_aggregate(const Rec<W> *__re
 				if (new_dst + LOG_CHUNK > log_cap) atomicAdd(&counters[PC_LOG_OVF], 1ull);
 			}
 			new_dst = __shfl(new_dst, 0);
+			if (new_dst + LOG_CHUNK > log_cap) log_full = true;  // the launch is void: this wavefront stops after this bucket
 		}
 		for (uint32_t i = lane; i < n; i += 64) {
 			const uint32_t sl = T.list[i];
@@ -857,7 +862,7 @@ __global__ __launch_bounds__(64 * AGG_WAVES) void k_aggregate(const Rec<W> *__re
 #pragma unroll
 	for (int i = 0; i <= NB; ++i) nxt.w[i] = 0;
 	bool prefetched = false;  // nxt holds records [cb, cb+64) of the current bucket
-	while (b < nbuckets) {
+	while (b < nbuckets && !log_full) {
 		const uint32_t b2 = b + stride;  // the bucket after this one: its bounds are fetched now, used at the last round
 		uint64_t nb_begin = 0, nb_end = 0;
 		if (b2 < nbuckets) {
@@ -870,11 +875,16 @@ __global__ __launch_bounds__(64 * AGG_WAVES) void k_aggregate(const Rec<W> *__re
 		auto pass = [&](uint32_t sub, uint32_t nsub) -> bool {
 			bool overflow = false;
 			next_ready = false;
+			// record levels of the split (SLOW only), then hash levels
+			const uint32_t rl = SLOW ? min(31u - (uint32_t)__clz((int)nsub), rbits) : 0u;
+			const uint32_t rmask = (1u << rl) - 1u, rsub = sub & rmask;
+			const uint32_t hsub = sub >> rl, hn = nsub >> rl;
 			if (!prefetched && cb + lane < ce) nxt = recs[cb + lane];
 			prefetched = false;
 			for (uint64_t base = cb; base < ce && !overflow; base += 64) {
 				const Rec<W> rec = nxt;
 				bool pending = base + lane < ce;
+				if (SLOW && rl && pending && (rec_bucket<W>(rec, m) & rmask) != rsub) pending = false;  // a record of another pass
 				if (base + 64 < ce) {
 					if (base + 64 + lane < ce) nxt = recs[base + 64 + lane];
 				} else if (sub + 1 == nsub) {  // last round of the last sub-pass: the next bucket's first round
@@ -941,9 +951,9 @@ __global__ __launch_bounds__(64 * AGG_WAVES) void k_aggregate(const Rec<W> *__re
 					}
 					wave_sync();
 				} while (__any(pending));
-				if ((uint32_t)__builtin_amdgcn_readfirstlane((int)R.fill) > RT_FLUSH) overflow = !expand(sub, nsub);
+				if ((uint32_t)__builtin_amdgcn_readfirstlane((int)R.fill) > RT_FLUSH) overflow = !expand(hsub, hn);
 			}
-			if (!overflow) overflow = !expand(sub, nsub);
+			if (!overflow) overflow = !expand(hsub, hn);
 			return overflow;
 		};
 		partial_flushes = false;
@@ -956,8 +966,8 @@ __global__ __launch_bounds__(64 * AGG_WAVES) void k_aggregate(const Rec<W> *__re
 				prefetched = next_ready;
 			}
 		} else {
-			// The bucket's k-mers are split by bits of their hash: node (nsub, sub) holds those whose low log2(nsub) bits
-			// (from bit 12 up) equal sub.  A node whose k-mers do not fit the table has written nothing yet; it is replaced
+			// The bucket's k-mers are split by bits -- of their record's bucket number for the first rbits levels, of their
+			// own hash (from bit 12 up) below that: node (nsub, sub) holds those whose log2(nsub) split bits equal sub.  A node whose k-mers do not fit the table has written nothing yet; it is replaced
 			// by its two halves (2*nsub, sub) and (2*nsub, sub + nsub), visited depth first without a stack: after a node
 			// that is a low half comes its sibling, after a high half the parent is complete.  Only a node that cannot
 			// be halved any more is redone with partial flushes, and its entries alone lose the unique mark.
@@ -986,7 +996,7 @@ __global__ __launch_bounds__(64 * AGG_WAVES) void k_aggregate(const Rec<W> *__re
 				}
 				discard();  // nothing of this node was written
 				prefetched = false;
-				if (nsub < AGG_MAX_SUBPASSES) nsub *= 2;  // low half first: sub keeps its value
+				if ((nsub >> min(31u - (uint32_t)__clz((int)nsub), rbits)) < AGG_MAX_SUBPASSES) nsub *= 2;  // low half first: sub keeps its value
 				else partial_flushes = true;
 			}
 		}

@@ -56,8 +56,9 @@ def test_bloom_region_partitioning_is_used_and_exact(oracle):
     import ray_amd
     packed, offsets, lengths = make_reads_numpy(genome=40000, read_len=100, n_reads=9000, seed=71, error=0.02)
     # 2^25 bits: 256 regions, one scatter level; 50 M and 2^28: two levels; 3 M is so dense that a region's
-    # contested bits exceed the LDS rank table, so the library must notice and redo it with dense stamps
-    for bits, partitioned in ((1 << 25, 1), (50_000_000, 1), (1 << 28, 1), (3_000_000, 0)):
+    # contested bits exceed the LDS rank table, so the library must notice and redo it with dense stamps; 12 M: regions
+    # of more items than a workgroup holds in registers (several rounds, stamps kept in the spare buffer)
+    for bits, partitioned in ((1 << 25, 1), (50_000_000, 1), (1 << 28, 1), (12_000_000, 1), (3_000_000, 0)):
         want = oracle_run(oracle, packed, offsets, lengths, 31, 1, bits)
         b = ray_amd.GraphBuilder(31, bloom_bits=bits, sweep=1 | 16)
         b.add_reads(packed, offsets, lengths)
@@ -176,3 +177,11 @@ def test_long_reads_many_steps(oracle):
     p, o, l = ray_amd.pack_reads(seqs)
     gpu_vs_oracle(oracle, p, o, l, 31, bloom_bits=0, sweeps=(1 | (8 << 8), 2))
     gpu_vs_oracle(oracle, p, o, l, 31, bloom_bits=5000, sweeps=(1 | 16 | (8 << 8), 2 | 32))
+
+
+def test_log_overflow_is_redone_with_a_full_log(oracle):
+    """inputs of little redundancy overflow the log of distinct k-mers (sized for a quarter of the occurrences): the
+    aggregation then runs again with one slot per occurrence; flag 64 makes the first log one chunk long"""
+    packed, offsets, lengths = make_reads_numpy(genome=200000, read_len=100, n_reads=3000, seed=8, error=0.02)
+    want = gpu_vs_oracle(oracle, packed, offsets, lengths, 31, bloom_bits=None, sweeps=(1 | 16 | 64 | (10 << 8), 1 | 16 | (10 << 8)))
+    assert want["builder"].stats()["log_entries"] > 512
