@@ -38,6 +38,12 @@ def parse():
     ap.add_argument("--cpu-sample-reads", type=int, default=60000, help="reads per CPU baseline instance")
     ap.add_argument("--cpu-cores", type=int, default=0, help="CPU baseline instances; 0 = min(16, host cores): the GPU box's share")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--route", choices=("auto", "records", "entries"), default="auto",
+                    help="N > 1: what crosses the links first.  records: super-k-mer records to the rank that aggregates their "
+                         "bucket, then aggregated entries to their owners; entries: every rank aggregates its own reads, entries "
+                         "to their owners.  auto: entries when one rank's reads cover a k-mer 16 times or more (N = 2 here: "
+                         "a third of the bytes on the one link there is), records otherwise (less work per rank, and fewer bytes "
+                         "once a rank's own reads hold most k-mers only a few times)")
     ap.add_argument("--sweep", type=lambda x: int(x, 0), default=0, help="rg_config.reserved0 (development: forces a sweep / bucket bits)")
     ap.add_argument("--breakdown", action="store_true", help="print per-call wall times of the last step to stderr")
     return ap.parse_args()
@@ -121,7 +127,15 @@ def main():
     cfg = dict(synth.CONFIGS[args.workload])
     k = cfg["k"]
     emu = args.emulate_world if world == 1 else 1
-    genome = max(2000, int(cfg["genome"] * args.scale)) * world   # emulation: a rank receives full-coverage buckets, like N = 1
+    nranks = world * emu
+    # bytes per k-mer occurrence on the links: records ~ 24 B per 8.4 occurrences plus one entry per distinct k-mer of the
+    # whole job; entries: 32 B per distinct k-mer of ONE rank's reads, i.e. 32 / (that rank's k-mer coverage).  Per-rank
+    # work measured with --emulate-world (C2 shape): records 125 ms at any N; entries 152 / 191 / 282 ms at N = 2 / 4 / 8.
+    local_kmer_cov = cfg["coverage"] * (cfg["read_len"] - k + 1) / cfg["read_len"] / nranks
+    route = args.route if args.route != "auto" else ("entries" if local_kmer_cov >= 16 else "records")
+    # weak scaling: the genome grows with N.  Emulated records route: a rank receives full-coverage buckets, like N = 1;
+    # emulated entries route: the rank's own reads cover the N-fold genome N times thinner
+    genome = max(2000, int(cfg["genome"] * args.scale)) * world * (emu if route == "entries" else 1)
     n_reads = synth.n_reads_for(int(cfg["genome"] * args.scale), cfg["read_len"], cfg["coverage"])
     t0 = time.perf_counter()
     # same genome on every rank (same seed), different reads per rank
@@ -149,7 +163,22 @@ def main():
         b.add_reads_device(packed.data_ptr(), n_reads * ((cfg["read_len"] + 3) // 4), offsets.data_ptr(),
                            lengths.data_ptr(), n_reads, cfg["read_len"])
         mark("create+add_reads")
-        if emu > 1:
+        if emu > 1 and route == "entries":
+            from ray_amd.graph import RG_ENTRY_BYTES
+            b.count_local()
+            mark("count_local")
+            counts = b.owner_counts()
+            send = torch.empty(max(1, sum(counts)) * RG_ENTRY_BYTES, dtype=torch.uint8, device=dev)
+            b.export_owner_buckets(send.data_ptr(), max(1, sum(counts)))
+            mark("owner buckets")
+            # what arrives here: one bucket from each of N ranks holding the same keys -- this rank's own bucket, N times
+            mine = send[sum(counts[:rank]) * RG_ENTRY_BYTES:]
+            for _ in range(emu):
+                b.merge_entries(mine.data_ptr(), counts[rank])
+            mark("merge")
+            del send, mine
+            b.resolve_admission(n_reads)
+        elif emu > 1:
             from ray_amd.graph import RG_ENTRY_BYTES
             # records route: this rank's records, all of them counted here in place of the ones N ranks would send
             b.records_local()
@@ -176,7 +205,10 @@ def main():
             else:
                 b.count_kmers()                  # RAY_SLAVE_MODE_ADD_VERTICES
         else:
-            exchange_records(b, device=dev)           # super-k-mer records to the rank that aggregates their bucket
+            if route == "records":
+                exchange_records(b, device=dev)       # super-k-mer records to the rank that aggregates their bucket
+            else:
+                b.count_local()                       # every rank aggregates its own reads
             mark("records + count")
             exchange_owner_buckets(b, device=dev)     # aggregated entries to the rank vertexRank names
             b.resolve_admission(n_reads)
@@ -242,7 +274,8 @@ def main():
             "k_level_hist": max(0, st["partition_levels"] - 1) * recs0 * rec_bytes,
             "k_aggregate": recs0 * rec_bytes + st["log_entries"] * 32,       # records in, entries out
             "k_merge": st["log_entries"] * 32 + cand0 * 32,                  # entries in, slots written
-            "k_bloom_items": st["table_slots"] * 32 + cand0 * 64,            # table scan in, 8 items of 8 B per key out
+            "k_bloom_items": (st["log_entries"] if "k_insert_admitted" in kprof else st["table_slots"]) * 32 + cand0 * 64,  # scan in, 8 items of 8 B per key out
+            "k_insert_admitted": st["log_entries"] * 32 + st["stored_pairs"] * 32,   # log in, admitted slots written
             "k_scatter64": 2 * cand0 * 64,                                    # items in + out, per level (x launches below)
             "k_bloom_region": cand0 * 64,                                     # items in (contested stamps are extra)
             "k_bloom_touch": cand0 * (32 + 8 * 8),                           # slot + 8 stamp words
@@ -286,7 +319,7 @@ def main():
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": args.workload + ("" if args.scale == 1.0 else "@scale=%g" % args.scale) + ("" if args.error is None else "@error=%g" % args.error), "k": k,
                        "read_len": L, "reads_per_gpu": n_reads, "genome_bp": genome,
-                       "parallelism": "owner-partitioned x%d" % world + ("" if emu == 1 else " (rank 0 of %d emulated on one GPU, no network)" % emu), "bloom": "default 16*k*reads cap 2^33"},
+                       "parallelism": "owner-partitioned x%d" % world + ("" if nranks == 1 else ", %s route" % route) + ("" if emu == 1 else " (rank 0 of %d emulated on one GPU, no network)" % emu), "bloom": "default 16*k*reads cap 2^33"},
             "occurrences_per_s": occ / per_step,
             "kmer_occurrences": occ, "distinct_candidates": cand, "vertices_stored": stored,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
