@@ -44,6 +44,7 @@ def parse():
                          "to their owners.  auto: entries when one rank's reads cover a k-mer 16 times or more (N = 2 here: "
                          "a third of the bytes on the one link there is), records otherwise (less work per rank, and fewer bytes "
                          "once a rank's own reads hold most k-mers only a few times)")
+    ap.add_argument("--parts", type=int, default=4, help="records route: slices of the reads whose record transfers overlap the next slice's kernels")
     ap.add_argument("--sweep", type=lambda x: int(x, 0), default=0, help="rg_config.reserved0 (development: forces a sweep / bucket bits)")
     ap.add_argument("--breakdown", action="store_true", help="print per-call wall times of the last step to stderr")
     return ap.parse_args()
@@ -181,12 +182,16 @@ def main():
         elif emu > 1:
             from ray_amd.graph import RG_ENTRY_BYTES
             # records route: this rank's records, all of them counted here in place of the ones N ranks would send
-            b.records_local()
-            rcounts, unit = b.record_counts()
-            rsend = torch.empty(max(1, sum(rcounts)) * unit, dtype=torch.uint8, device=dev)
-            b.export_records(rsend.data_ptr(), max(1, sum(rcounts)))
+            rsend, n_rec = None, 0
+            for part in range(args.parts):
+                b.records_local(part, args.parts)
+                rcounts, unit = b.record_counts()
+                if rsend is None:
+                    rsend = torch.empty((int(sum(rcounts) * args.parts * 1.1) + 4096 * args.parts) * unit, dtype=torch.uint8, device=dev)
+                b.export_records(rsend.data_ptr() + n_rec * unit, rsend.numel() // unit - n_rec)
+                n_rec += sum(rcounts)
             mark("records_local + export")
-            b.count_records(rsend.data_ptr(), sum(rcounts))
+            b.count_records(rsend.data_ptr(), n_rec)
             del rsend
             mark("count_records")
             counts = b.owner_counts()
@@ -206,7 +211,7 @@ def main():
                 b.count_kmers()                  # RAY_SLAVE_MODE_ADD_VERTICES
         else:
             if route == "records":
-                exchange_records(b, device=dev)       # super-k-mer records to the rank that aggregates their bucket
+                exchange_records(b, device=dev, parts=args.parts)  # super-k-mer records to the rank that aggregates their bucket
             else:
                 b.count_local()                       # every rank aggregates its own reads
             mark("records + count")

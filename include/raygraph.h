@@ -89,8 +89,13 @@ int rg_count_kmers(rg_handle *h);
  *   -- all-to-all(v) of the records --
  *   rg_count_records    aggregates the received records (device pointer; must stay valid during the call)
  * and then, exactly as after rg_count_local: rg_owner_counts / rg_export_owner_buckets (entries to the ranks
- * vertexRank names) -- all-to-all(v) -- rg_merge_entries, rg_resolve_admission. */
+ * vertexRank names) -- all-to-all(v) -- rg_merge_entries, rg_resolve_admission.
+ * rg_records_local_part(part, nparts) does the first step for reads [n*part/nparts, n*(part+1)/nparts) of every
+ * batch only: counts + export + all-to-all per part, so that the transfer of one part overlaps the kernels of the
+ * next (the reference overlaps the same way, message by message: KmerAcademyBuilder.cpp:187-196 sends while
+ * it keeps reading); rg_count_records then takes all received records at once, in any order of parts. */
 int rg_records_local(rg_handle *h);
+int rg_records_local_part(rg_handle *h, uint32_t part, uint32_t nparts);
 int rg_record_counts(rg_handle *h, uint64_t *counts, uint32_t *record_bytes);
 int rg_export_records(rg_handle *h, void *d_out, uint64_t capacity_records);
 int rg_count_records(rg_handle *h, const void *d_records, uint64_t n_records);

@@ -29,7 +29,7 @@ class RgStats(C.Structure):
 
 # every symbol include/raygraph.h declares
 SYMBOLS = ["rg_create", "rg_destroy", "rg_last_error", "rg_add_reads", "rg_add_reads_device", "rg_count_kmers",
-           "rg_count_local", "rg_records_local", "rg_record_counts", "rg_export_records", "rg_count_records", "rg_owner_counts", "rg_export_owner_buckets", "rg_merge_entries",
+           "rg_count_local", "rg_records_local", "rg_records_local_part", "rg_record_counts", "rg_export_records", "rg_count_records", "rg_owner_counts", "rg_export_owner_buckets", "rg_merge_entries",
            "rg_resolve_admission", "rg_histogram", "rg_add_edges", "rg_purge_edges", "rg_purge_query_counts",
            "rg_purge_export_queries", "rg_purge_answer", "rg_purge_apply", "rg_size", "rg_export",
            "rg_find", "rg_add_reads_text", "rg_count_sequences", "rg_load_sequences", "rg_get_reads", "rg_read_markers",
@@ -68,6 +68,7 @@ def load():
         "rg_count_local": ([vp], C.c_int),
         "rg_owner_counts": ([vp, u64p], C.c_int),
         "rg_records_local": ([vp], C.c_int),
+        "rg_records_local_part": ([vp, C.c_uint32, C.c_uint32], C.c_int),
         "rg_record_counts": ([vp, u64p, u32p], C.c_int),
         "rg_export_records": ([vp, vp, u64], C.c_int),
         "rg_count_records": ([vp, vp, u64], C.c_int),

@@ -1411,7 +1411,7 @@ static int sweep_partitioned(rg_handle *h, Slot **out_log, uint64_t *out_n, bool
 
 // ---- record exchange between ranks: stage 1 on the sender (reads -> records, counted per destination) ----
 template <int W>
-static int records_local_t(rg_handle *h) {
+static int records_local_t(rg_handle *h, uint32_t part, uint32_t nparts) {
 	const int dev = h->cfg.device;
 	const int k = h->cfg.k;
 	const int m = k < MMER_MAX ? k : MMER_MAX;
@@ -1419,12 +1419,19 @@ static int records_local_t(rg_handle *h) {
 	const uint32_t size = (uint32_t)h->cfg.size;
 	if (w > lmax_for(W, k)) return fail(h, RG_ERR_STATE, "k-mer length %d cannot be cut into records", k);
 	if (size > 256) return fail(h, RG_ERR_STATE, "the record exchange supports at most 256 ranks (use rg_count_local + rg_export_owner_buckets)");
+	// part p of P takes reads [n*p/P, n*(p+1)/P) of every batch
+	auto slice = [&](const ReadBatch &b, uint64_t &lo, uint64_t &hi) {
+		lo = b.n / nparts * part + std::min<uint64_t>(part, b.n % nparts);
+		hi = lo + b.n / nparts + (part < b.n % nparts ? 1 : 0);
+	};
 	uint64_t rec_bound = 0, total_reads = 0, launches1 = 0;
 	for (const ReadBatch &b : h->reads) {
 		if (b.maxlen < (uint32_t)k) continue;
+		uint64_t lo, hi;
+		slice(b, lo, hi);
 		const uint64_t per = (uint64_t)b.maxlen - k + 1;
-		rec_bound += b.n * per;  // exact upper bound: a record holds at least one k-mer
-		total_reads += b.n;
+		rec_bound += (hi - lo) * per;  // exact upper bound: a record holds at least one k-mer
+		total_reads += hi - lo;
 		launches1++;
 		if (b.first_id + b.n >= (1ull << 33) - 1) return fail(h, RG_ERR_CAPACITY, "read ids above 2^33 do not fit a record");
 	}
@@ -1454,9 +1461,12 @@ static int records_local_t(rg_handle *h) {
 		if (e == hipSuccess) e = hipMemsetAsync(h->d_counters + C_OCC, 0, sizeof(unsigned long long), h->stream);
 		for (const ReadBatch &b : h->reads) {
 			if (b.maxlen < (uint32_t)k || e != hipSuccess) continue;
+			uint64_t lo, hi;
+			slice(b, lo, hi);
+			if (hi == lo) continue;
 			ProfScope ps(h, "k_superkmers");
-			hipLaunchKernelGGL(k_superkmers<W>, dim3(grid1), dim3(256), 0, h->stream, b.d_packed, b.d_off, b.d_len, b.n, b.first_id, k, m, buf, rec_cap,
-			                   h->d_counters, d_hist, size, 16u);
+			hipLaunchKernelGGL(k_superkmers<W>, dim3(grid1), dim3(256), 0, h->stream, b.d_packed, b.d_off + lo, b.d_len + lo, hi - lo, b.first_id + lo, k, m,
+			                   buf, rec_cap, h->d_counters, d_hist, size, 16u);
 			e = hipGetLastError();
 		}
 		std::vector<unsigned long long> hist(256);
@@ -1960,17 +1970,21 @@ int rg_count_local(rg_handle *h) {
 	return RG_OK;
 }
 
-int rg_records_local(rg_handle *h) {
+int rg_records_local_part(rg_handle *h, uint32_t part, uint32_t nparts) {
 	if (!h) return RG_ERR_ARG;
+	if (nparts == 0 || part >= nparts) return fail(h, RG_ERR_ARG, "part %u of %u", part, nparts);
 	if (h->phase != PH_CREATED) return fail(h, RG_ERR_STATE, "rg_records_local called after counting started");
-	if (h->rec_buf) return fail(h, RG_ERR_STATE, "rg_records_local called twice");
+	if (h->rec_buf) return fail(h, RG_ERR_STATE, "the records of the previous part have not been exported");
 	HIP_TRY(h, hipSetDevice(h->cfg.device));
-	int rc = h->W == 1 ? records_local_t<1>(h) : records_local_t<2>(h);
+	int rc = h->W == 1 ? records_local_t<1>(h, part, nparts) : records_local_t<2>(h, part, nparts);
 	if (rc) return rc;
+	if (part == 0) h->stats.occurrences = 0;
 	h->stats.reads = h->n_reads;
-	h->stats.occurrences = h->rec_slots ? h->h_counters[C_OCC] : 0;
+	h->stats.occurrences += h->rec_slots ? h->h_counters[C_OCC] : 0;
 	return RG_OK;
 }
+
+int rg_records_local(rg_handle *h) { return rg_records_local_part(h, 0, 1); }
 
 int rg_record_counts(rg_handle *h, uint64_t *counts, uint32_t *record_bytes) {
 	if (!h || !counts) return RG_ERR_ARG;

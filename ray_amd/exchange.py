@@ -76,23 +76,57 @@ def _all_to_all_bytes(send, send_counts, unit, group, device, staged):
     return recv, recv_counts
 
 
-def exchange_records(engine, group=None, device="cuda"):
-    """first exchange of the preferred multi-GPU route: the local reads cut into super-k-mer records go to the
-    rank that aggregates their bucket, which then counts them; follow with exchange_owner_buckets().
+def exchange_records(engine, group=None, device="cuda", parts=1):
+    """first exchange of the record route: the local reads cut into super-k-mer records go to the rank that
+    aggregates their bucket, which then counts them; follow with exchange_owner_buckets().
+    parts > 1: the reads are cut in `parts` slices; the all-to-all of one slice's records runs (asynchronously, on
+    the collective's own stream) while the kernels of the next slice produce theirs.
     Returns (records sent, records received)."""
-    engine.records_local()
-    counts, unit = engine.record_counts()
-    total = sum(counts)
-    send = torch.empty(max(1, total) * unit, dtype=torch.uint8, device=device)
-    engine.export_records(send.data_ptr(), max(1, total))
+    size = engine.size
     staged = _staged(group) and str(device) != "cpu"
-    recv, recv_counts = _all_to_all_bytes(send, counts, unit, group, device, staged)
-    del send
-    n_recv = sum(recv_counts)
+    xdev = "cpu" if staged else device
+    pending = []          # (work, send buffer, receive view): kept alive until the collective has finished
+    big, big_used, unit = None, 0, 0
+    sent = 0
+    for part in range(parts):
+        engine.records_local(part, parts)
+        counts, unit = engine.record_counts()
+        total = sum(counts)
+        send = torch.empty(max(1, total) * unit, dtype=torch.uint8, device=device)
+        engine.export_records(send.data_ptr(), max(1, total))   # returns once the buffer is complete
+        sent += total
+        sc = torch.tensor(counts, dtype=torch.int64, device=xdev)
+        rc = torch.empty(size, dtype=torch.int64, device=xdev)
+        dist.all_to_all_single(rc, sc, group=group)
+        recv_counts = [int(x) for x in rc.cpu().tolist()]
+        n_recv = sum(recv_counts)
+        if big is None:   # one receive buffer for all parts (sized from the first), so that nothing is copied together later
+            big = torch.empty(max(1, int(n_recv * parts * 1.1) + 4096 * parts) * unit, dtype=torch.uint8, device=xdev)
+        if big_used + n_recv * unit <= big.numel():
+            recv = big[big_used: big_used + n_recv * unit]
+            big_used += n_recv * unit
+            in_big = True
+        else:
+            recv = torch.empty(max(1, n_recv) * unit, dtype=torch.uint8, device=xdev)[: n_recv * unit]
+            in_big = False
+        src = send[: total * unit].cpu() if staged else send[: total * unit]
+        work = dist.all_to_all_single(recv, src, output_split_sizes=[c * unit for c in recv_counts],
+                                      input_split_sizes=[c * unit for c in counts], group=group, async_op=True)
+        pending.append((work, src, recv, in_big))
+    for work, _, _, _ in pending:
+        work.wait()
+    if all(p[3] for p in pending):
+        allrec = big[:big_used]
+    else:
+        allrec = torch.cat([big[:big_used]] + [p[2] for p in pending if not p[3]])
+    n_all = allrec.numel() // unit if unit else 0
+    if staged:
+        allrec = allrec.to(device)
     if str(device) != "cpu":
         torch.cuda.current_stream().synchronize()
-    engine.count_records(recv.data_ptr(), n_recv)
-    return total, n_recv
+    del pending
+    engine.count_records(allrec.data_ptr(), n_all)
+    return sent, n_all
 
 
 def purge_edges_distributed(engine, group=None, device="cuda"):

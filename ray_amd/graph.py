@@ -196,8 +196,9 @@ class GraphBuilder:
         self._check(self._L.rg_count_local(self._h))
 
     # -- record exchange (exchange.exchange_records drives these)
-    def records_local(self):
-        self._check(self._L.rg_records_local(self._h))
+    def records_local(self, part=0, nparts=1):
+        """reads -> records per destination rank; part p of P covers a P-th of every batch (see exchange_records)"""
+        self._check(self._L.rg_records_local_part(self._h, part, nparts))
 
     def record_counts(self):
         """(records per destination rank, bytes per record)"""

@@ -104,12 +104,15 @@ class ModelEngine:
     def _dest(self, key):
         return self.ro.hash2(key, self.W) % self.size
 
-    def records_local(self):
+    def records_local(self, part=0, nparts=1):
         self._rec = [[] for _ in range(self.size)]
-        for key, (stamp, count, em) in self.local.items():
+        for i, (key, (stamp, count, em)) in enumerate(sorted(self.local.items())):
+            if i % nparts != part:
+                continue
             i0, i1 = to_internal(key[0], key[1], self.W)
             self._rec[self._dest(key)].append((i0, i1, stamp, count | (em << 48)))
-        self.local = {}
+        if part == nparts - 1:
+            self.local = {}
 
     def record_counts(self):
         return [len(r) for r in self._rec], ENTRY.itemsize

@@ -12,7 +12,7 @@ from ray_amd.synth import make_reads_numpy
 pytestmark = pytest.mark.gpu
 
 
-def run_ranks(packed, offsets, lengths, k, nranks, bloom, W=0, sweep=0, route="entries"):
+def run_ranks(packed, offsets, lengths, k, nranks, bloom, W=0, sweep=0, route="entries", parts=1):
     """route "entries": every rank aggregates its own reads, then the entries go to their owners;
     route "records": the super-k-mer records go to the rank that aggregates their bucket first (the preferred
     multi-GPU route), then the entries go to their owners"""
@@ -28,13 +28,14 @@ def run_ranks(packed, offsets, lengths, k, nranks, bloom, W=0, sweep=0, route="e
         b.add_reads(packed, offsets[first:last], lengths[first:last])
         builders.append(b)
     if route == "records":
-        sent = []
+        sent = []   # parts > 1: every rank cuts its reads in slices whose records travel separately (any order on arrival)
         for b in builders:
-            b.records_local()
-            counts, unit = b.record_counts()
-            buf = torch.empty(max(1, sum(counts)) * unit, dtype=torch.uint8, device="cuda")
-            b.export_records(buf.data_ptr(), max(1, sum(counts)))
-            sent.append((counts, buf, unit))
+            for part in range(parts):
+                b.records_local(part, parts)
+                counts, unit = b.record_counts()
+                buf = torch.empty(max(1, sum(counts)) * unit, dtype=torch.uint8, device="cuda")
+                b.export_records(buf.data_ptr(), max(1, sum(counts)))
+                sent.append((counts, buf, unit))
         assert sum(sum(c) for c, _, _ in sent) > 0
         for dst, b in enumerate(builders):
             parts = []
@@ -71,8 +72,9 @@ def test_multirank_matches_oracle(oracle, k, nranks, bloom):
     packed, offsets, lengths = make_reads_numpy(genome=15000, read_len=100 if k < 63 else 150, n_reads=5001,
                                                 seed=k + nranks, error=0.015)
     want = oracle_run(oracle, packed, offsets, lengths, k, nranks, bloom)
-    for sweep, route in ((1 | 16 | (17 << 8), "entries"), (2 | 32, "entries"), (1 | 16 | (10 << 8), "records"), (2 | 32, "records")):
-        builders = run_ranks(packed, offsets, lengths, k, nranks, bloom, sweep=sweep, route=route)
+    for sweep, route, parts in ((1 | 16 | (17 << 8), "entries", 1), (2 | 32, "entries", 1), (1 | 16 | (10 << 8), "records", 1),
+                                (1 | 16 | (10 << 8), "records", 3), (2 | 32, "records", 1)):
+        builders = run_ranks(packed, offsets, lengths, k, nranks, bloom, sweep=sweep, route=route, parts=parts)
         check_ranks(builders, want, route)
     # RAY_SLAVE_MODE_PURGE_NULL_EDGES across ranks: keys to the owners, one-byte answers back
     want["graph"].purge_edges()
