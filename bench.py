@@ -275,6 +275,7 @@ def main():
         alg_bytes = {
             "k_count": occ0 * (L / (4.0 * n_per_read) + Kb + 8),            # read bits + key compare + count RMW
             "k_superkmers": occ0 * L / (4.0 * n_per_read) + recs0 * rec_bytes,  # read bits in, records out
+            "k_superkmers_lanes": occ0 * L / (4.0 * n_per_read) + recs0 * rec_bytes,  # same bytes, a lane per read
             "k_scatter": st["partition_levels"] * 2 * recs0 * rec_bytes,     # records in + out, per level
             "k_level_hist": max(0, st["partition_levels"] - 1) * recs0 * rec_bytes,
             "k_aggregate": recs0 * rec_bytes + st["log_entries"] * 32,       # records in, entries out

@@ -1140,6 +1140,43 @@ static int table_reserve(rg_handle *h, Table &t, uint64_t need, int fill_counter
 // estimate was exceeded (nothing is lost: the caller then runs the direct sweep instead).
 // ext != nullptr: the records come from outside (record exchange between ranks: ext_n valid records
 // received from all ranks) instead of from this handle's reads.
+
+// reads -> records: k_superkmers_lanes (a lane per read) for short reads and windows that fit its LDS block,
+// k_superkmers (a wavefront per read) otherwise; cfg.reserved0 bit 16 forces the latter (tests)
+static constexpr int SKL_HOST_MAX_W = 24;        // 4 wavefronts x w x 64 lanes x 8 B <= 48 KiB of dynamic LDS
+static constexpr uint32_t SKL_MAX_READ = 1024;   // longer reads: lanes of one wavefront would idle behind the longest
+template <int W>
+struct SuperkmerLaunch {
+	int grid_wave = 1, grid_lane = 0;
+	size_t lds_lane = 0;
+	int grid_max() const { return grid_wave > grid_lane ? grid_wave : grid_lane; }
+	void plan(rg_handle *h, int n_cu, int k, int m, uint64_t total_reads) {
+		const int w = k - m + 1;
+		int occ = 4;
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_superkmers<W>, 256, 0) != hipSuccess || occ < 1) occ = 4;
+		grid_wave = (int)std::min<uint64_t>((uint64_t)n_cu * occ, std::max<uint64_t>(1, (total_reads + 255) / 256));
+		grid_lane = 0;
+		if (w <= SKL_HOST_MAX_W && w <= SKL_MAX_W && !(h->cfg.reserved0 & 0x10000)) {
+			lds_lane = (size_t)4 * w * 64 * sizeof(unsigned long long);
+			int occl = 0;
+			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occl, k_superkmers_lanes<W>, 256, lds_lane) == hipSuccess && occl >= 1)
+				grid_lane = (int)std::min<uint64_t>((uint64_t)n_cu * occl, std::max<uint64_t>(1, (total_reads + 255) / 256));
+		}
+		(void)hipGetLastError();
+	}
+	bool lanes(const ReadBatch &b) const { return grid_lane > 0 && b.maxlen <= SKL_MAX_READ; }
+	const char *name(const ReadBatch &b) const { return lanes(b) ? "k_superkmers_lanes" : "k_superkmers"; }
+	void launch(rg_handle *h, const ReadBatch &b, uint64_t lo, uint64_t n, int k, int m, Rec<W> *buf, uint64_t rec_cap,
+	            unsigned long long *d_hist, uint32_t modulo, uint32_t hist_shift) const {
+		if (lanes(b))
+			hipLaunchKernelGGL(k_superkmers_lanes<W>, dim3(grid_lane), dim3(256), lds_lane, h->stream, b.d_packed, b.d_off + lo, b.d_len + lo, n,
+			                   b.first_id + lo, k, m, buf, rec_cap, h->d_counters, d_hist, modulo, hist_shift);
+		else
+			hipLaunchKernelGGL(k_superkmers<W>, dim3(grid_wave), dim3(256), 0, h->stream, b.d_packed, b.d_off + lo, b.d_len + lo, n,
+			                   b.first_id + lo, k, m, buf, rec_cap, h->d_counters, d_hist, modulo, hist_shift);
+	}
+};
+
 template <int W>
 static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bool *ok, const void *ext = nullptr, uint64_t ext_n = 0) {
 	*ok = false;
@@ -1191,12 +1228,13 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	const uint64_t NBUCK = 1ull << bits;
 	// persistent grids sized to what is resident at once, so that no second, nearly empty round of
 	// workgroups runs behind the first
-	int n_cu = 256, occ1 = 4, occ3 = 4;
+	int n_cu = 256, occ3 = 4;
 	(void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ1, k_superkmers<W>, 256, 0) != hipSuccess || occ1 < 1) occ1 = 4;
+	SuperkmerLaunch<W> sk;
+	sk.plan(h, n_cu, k, m, total_reads);
 	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ3, k_aggregate<W, false>, 256, 0) != hipSuccess || occ3 < 1) occ3 = 4;
 	(void)hipGetLastError();
-	const int grid1 = (int)std::min<uint64_t>((uint64_t)n_cu * occ1, std::max<uint64_t>(1, (total_reads + 255) / 256));
+	const int grid1 = sk.grid_max();
 	uint64_t launches1 = 0;  // every launch of k_superkmers leaves up to one open chunk per wavefront
 	for (const ReadBatch &b : h->reads)
 		if (b.maxlen >= (uint32_t)k) launches1++;
@@ -1243,9 +1281,8 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 		for (const ReadBatch &b : h->reads) {
 			if (b.maxlen < (uint32_t)k) continue;
 			{
-				ProfScope ps(h, "k_superkmers");
-				hipLaunchKernelGGL(k_superkmers<W>, dim3(grid1), dim3(256), 0, h->stream, b.d_packed, b.d_off, b.d_len, b.n, b.first_id, k, m, buf[0],
-				                   rec_cap, h->d_counters, d_hist, 0u, (uint32_t)(24 - dbits[0]));
+				ProfScope ps(h, sk.name(b));
+				sk.launch(h, b, 0, b.n, k, m, buf[0], rec_cap, d_hist, 0u, (uint32_t)(24 - dbits[0]));
 			}
 			PTRY(hipGetLastError());
 		}
@@ -1440,11 +1477,11 @@ static int records_local_t(rg_handle *h, uint32_t part, uint32_t nparts) {
 	if (rec_bound == 0) return RG_OK;
 	// the expected number of records is 2/(w+1) per k-mer; three times that has never been seen to overflow, and if it
 	// does the exact bound is used in a second attempt
-	int n_cu = 256, occ1 = 4;
+	int n_cu = 256;
 	(void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ1, k_superkmers<W>, 256, 0) != hipSuccess || occ1 < 1) occ1 = 4;
-	(void)hipGetLastError();
-	const int grid1 = (int)std::min<uint64_t>((uint64_t)n_cu * occ1, std::max<uint64_t>(1, (total_reads + 255) / 256));
+	SuperkmerLaunch<W> sk;
+	sk.plan(h, n_cu, k, m, total_reads);
+	const int grid1 = sk.grid_max();
 	unsigned long long *d_hist = nullptr;
 	HIP_TRY(h, pool_alloc(dev, (void **)&d_hist, 256 * sizeof(unsigned long long)));
 	for (int attempt = 0; attempt < 2; ++attempt) {
@@ -1464,9 +1501,8 @@ static int records_local_t(rg_handle *h, uint32_t part, uint32_t nparts) {
 			uint64_t lo, hi;
 			slice(b, lo, hi);
 			if (hi == lo) continue;
-			ProfScope ps(h, "k_superkmers");
-			hipLaunchKernelGGL(k_superkmers<W>, dim3(grid1), dim3(256), 0, h->stream, b.d_packed, b.d_off + lo, b.d_len + lo, hi - lo, b.first_id + lo, k, m,
-			                   buf, rec_cap, h->d_counters, d_hist, size, 16u);
+			ProfScope ps(h, sk.name(b));
+			sk.launch(h, b, lo, hi - lo, k, m, buf, rec_cap, d_hist, size, 16u);
 			e = hipGetLastError();
 		}
 		std::vector<unsigned long long> hist(256);

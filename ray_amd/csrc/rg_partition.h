@@ -339,6 +339,226 @@ __global__ __launch_bounds__(256) void k_superkmers(const uint64_t *__restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
+// reads -> super-k-mer records, one *lane* per read (short reads: the same records as k_superkmers cuts inside one
+// step, found with about a third of the instructions per position).  The 64 lanes of a wavefront walk their 64
+// reads in lock step, one m-mer per step and lane:
+//   1. the next base comes out of a 16-base register buffer (one dword load per 16 steps, issued 16 steps ahead),
+//      the forward and reverse-complement m-mers roll by one base, the canonical one is mixed: x = mix << 32 | j;
+//   2. the minimum of the window of w entries that ends at j is found without looking back over the window: the
+//      m-mers are cut in blocks of w; P = running minimum of the current block, S[i] = minimum of entries i.. of the
+//      previous block (one backwards pass per block), window minimum = min(S[i+1], P).  The block lives in LDS, one
+//      8-byte slot per (entry, lane); slot i holds S[i] of the previous block until step i-1 has read it and x[i]
+//      of the current block from step i on, so one array serves both;
+//   3. a lane whose minimizer occurrence changed queues a 8-byte descriptor of the record that just ended (ballot
+//      + rank into a ring in LDS); whenever 64 are queued, the wavefront assembles 64 records at once, lane per
+//      record, bases fetched from the read (cache hits), stores to consecutive slots.
+// x orders (mix, position) exactly like k_superkmers, so every k-mer still has one bucket whatever kernel cut it.
+static constexpr uint32_t SKL_RING = 128;
+static constexpr int SKL_MAX_W = 32;  // descriptor fields: 5 bits each for the record length - 1 and the minimizer offset
+
+constexpr uint32_t inv32(uint32_t a) {  // inverse of an odd number modulo 2^32 (Newton)
+	uint32_t x = a;
+	for (int i = 0; i < 5; ++i) x *= 2u - a * x;
+	return x;
+}
+static_assert(inv32(0x85ebca6bu) * 0x85ebca6bu == 1u && inv32(0x9E3779B1u) * 0x9E3779B1u == 1u, "inv32");
+__device__ __forceinline__ uint32_t order_unmix(uint32_t h) {  // order_mix is a bijection: this is its inverse
+	h *= inv32(0x85ebca6bu);
+	h ^= h >> 15;
+	h ^= h >> 30;
+	return (h * inv32(0x9E3779B1u)) ^ 0x5bd1e995u;
+}
+
+template <int W>
+__global__ __launch_bounds__(256) void k_superkmers_lanes(const uint64_t *__restrict__ P, const uint64_t *__restrict__ offsets,
+                                                          const uint32_t *__restrict__ lengths, uint64_t nreads, uint64_t read_id_base,
+                                                          int k, int m, Rec<W> *__restrict__ recs, uint64_t rec_cap,
+                                                          unsigned long long *__restrict__ counters,
+                                                          unsigned long long *__restrict__ coarse_hist, uint32_t modulo, uint32_t hist_shift) {
+	constexpr int NB = 2 * W;
+	extern __shared__ unsigned long long s_win_all[];  // [4 wavefronts][w entries][64 lanes]
+	__shared__ unsigned long long s_q[4][SKL_RING];
+	__shared__ unsigned long long s_bit0[4][64];
+	__shared__ uint32_t s_len[4][64];
+	__shared__ uint32_t s_hist[NB_COARSE];
+	const uint32_t *__restrict__ P32 = reinterpret_cast<const uint32_t *>(P);
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	const uint32_t w = (uint32_t)(k - m + 1);
+	unsigned long long *const win = s_win_all + (size_t)wave * w * 64 + lane;  // entry i of this lane: win[i * 64]
+	unsigned long long *const ring = s_q[wave];
+	s_hist[threadIdx.x] = 0;
+	__syncthreads();
+	const uint32_t maskm = (1u << (2 * m)) - 1;
+	const uint32_t top = 2u * (uint32_t)(m - 1);
+	const unsigned long long lt_mask = (1ull << lane) - 1;
+	const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+	const uint64_t ngroups = (nreads + 63) / 64;
+	uint64_t chunk_base = 0;
+	uint32_t chunk_used = REC_CHUNK;
+	bool have_chunk = false, dead = false;
+	unsigned long long occ = 0;
+	uint32_t qhead = 0, qtail = 0;  // wave-uniform
+
+	for (uint64_t g = (uint64_t)blockIdx.x * 4 + wave; g < ngroups; g += nwaves) {
+		const uint64_t rb = g * 64;
+		uint32_t L = 0;
+		uint64_t bit0 = 0;
+		if (rb + lane < nreads) {
+			L = lengths[rb + lane];
+			bit0 = offsets[rb + lane] * 8;
+		}
+		if (L < (uint32_t)k) L = 0;
+		const uint32_t n = L ? L - (uint32_t)k + 1 : 0;
+		occ += n;
+		uint32_t maxn = n;
+#pragma unroll
+		for (int d = 32; d; d >>= 1) {
+			const uint32_t o = __shfl_xor(maxn, d);
+			maxn = o > maxn ? o : maxn;
+		}
+		maxn = (uint32_t)__builtin_amdgcn_readfirstlane((int)maxn);
+		if (maxn == 0) continue;
+		s_bit0[wave][lane] = bit0;
+		s_len[wave][lane] = L;
+		const uint32_t sh = (uint32_t)bit0 & 31u;
+		const uint32_t *__restrict__ rp = P32 + (bit0 >> 5);
+		const uint32_t lastw = L ? (sh + 2u * L - 1u) >> 5 : 0u;  // last dword that holds a base of this read
+		uint32_t lo = L ? rp[0] : 0u;
+		uint32_t pend = (L && 1u <= lastw) ? rp[1] : 0u;
+		uint32_t widx = 2, buf = 0, f = 0, r = 0, t = 0;
+		auto next_base = [&]() -> uint32_t {
+			if ((t & 15u) == 0) {  // wave-uniform
+				const uint32_t hi = pend;
+				buf = __builtin_amdgcn_alignbit(hi, lo, sh);
+				lo = hi;
+				pend = (L && widx <= lastw) ? rp[widx] : 0u;
+				++widx;
+			}
+			const uint32_t c = buf & 3u;
+			buf >>= 2;
+			++t;
+			return c;
+		};
+		for (int q = 0; q < m - 1; ++q) {
+			const uint32_t c = next_base();
+			f = (f >> 2) | (c << top);
+			r = ((r << 2) | (c ^ 3u)) & maskm;
+		}
+		unsigned long long pre = ~0ull, cur = ~0ull;
+		uint32_t start = 0, i = 0;
+		const uint32_t nsteps = maxn + w;  // m-mers 0 .. max(nm): k-mer p is complete at j = p + w - 1, and p = n closes the last record
+		for (uint32_t j = 0; j < nsteps; ++j) {
+			unsigned long long sfx = ~0ull;
+			if (i + 1 < w) sfx = win[(i + 1) * 64];  // S[i+1] of the previous block (garbage in the first block: not used there)
+			const uint32_t c = next_base();
+			f = (f >> 2) | (c << top);
+			r = ((r << 2) | (c ^ 3u)) & maskm;
+			const uint32_t cm = f < r ? f : r;
+			const unsigned long long x = ((unsigned long long)order_mix(cm) << 32) | j;
+			win[i * 64] = x;
+			pre = (i == 0 || x < pre) ? x : pre;
+			if (j + 1 >= w) {  // wave-uniform
+				const unsigned long long res = sfx < pre ? sfx : pre;  // j = w-1 (first block): i+1 = w, sfx = ~0, the window is the block
+				const uint32_t p = j + 1 - w;
+				const bool changed = (uint32_t)res != (uint32_t)cur;
+				const bool push = p > 0 && p <= n && (p == n || changed);
+				const unsigned long long bal = __ballot(push);
+				if (bal) {
+					if (push) {
+						const uint32_t d = start | ((p - start - 1u) << 16) | (lane << 21) | (((uint32_t)cur - start) << 27);
+						ring[(qtail + (uint32_t)__popcll(bal & lt_mask)) & (SKL_RING - 1)] = (cur & 0xFFFFFFFF00000000ull) | d;
+					}
+					qtail += (uint32_t)__popcll(bal);
+				}
+				if (p < n && changed) {
+					start = p;
+					cur = res;
+				}
+			}
+			++i;
+			if (i == w) {  // block complete: slot t becomes the minimum of entries t .. w-1
+				unsigned long long run = x;
+				for (uint32_t q = w - 1; q-- > 1;) {
+					const unsigned long long v = win[q * 64];
+					run = v < run ? v : run;
+					win[q * 64] = run;
+				}
+				i = 0;
+			}
+			// assemble 64 queued records (all of them after the last step), lane per record
+			while (qtail - qhead >= 64u || (j + 1 == nsteps && qtail != qhead)) {
+				const uint32_t cnt = (qtail - qhead < 64u) ? qtail - qhead : 64u;
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+				if (chunk_used + cnt > REC_CHUNK) {
+					if (have_chunk && !dead)
+						for (uint32_t q = chunk_used + lane; q < REC_CHUNK; q += 64) recs[chunk_base + q].w[NB] = REC_INVALID;
+					unsigned long long nbase = 0;
+					if (lane == 0) nbase = atomicAdd(&counters[PC_REC_CURSOR], (unsigned long long)REC_CHUNK);
+					nbase = __shfl(nbase, 0);
+					if (nbase + REC_CHUNK > rec_cap) {
+						dead = true;
+						if (lane == 0) atomicAdd(&counters[PC_REC_OVF], 1ull);
+					}
+					chunk_base = nbase;
+					chunk_used = 0;
+					have_chunk = true;
+				}
+				if (!dead && lane < cnt) {
+					const unsigned long long d = ring[(qhead + lane) & (SKL_RING - 1)];
+					const uint32_t dl = (uint32_t)d;
+					const uint32_t pr = dl & 0xFFFFu, len = ((dl >> 16) & 31u) + 1u, src = (dl >> 21) & 63u, jrel = dl >> 27;
+					const uint32_t Ls = s_len[wave][src];
+					const uint64_t b0 = s_bit0[wave][src];
+					const uint32_t ns = Ls - (uint32_t)k + 1;
+					const uint32_t hasL = pr > 0, hasR = (pr + len) < ns;
+					const uint32_t first = pr - hasL;  // read position of the record's base 0
+					const uint32_t nbases = hasL + len + (uint32_t)k - 1 + hasR;
+					const uint64_t bit = b0 + 2ull * first;
+					const uint32_t *__restrict__ wp = P32 + (bit >> 5);
+					const uint32_t sf = (uint32_t)bit & 31u;
+					const uint32_t ndw = (sf + 2u * nbases + 31u) >> 5;  // dwords that hold the record's bases
+					uint32_t a[2 * NB + 1];
+#pragma unroll
+					for (int q = 0; q < 2 * NB + 1; ++q) a[q] = ((uint32_t)q < ndw) ? wp[q] : 0u;
+					Rec<W> rec;
+#pragma unroll
+					for (int q = 0; q < NB; ++q) {
+						uint64_t word = 0;
+						if (nbases > 32u * q) {
+							word = (uint64_t)__builtin_amdgcn_alignbit(a[2 * q + 1], a[2 * q], sf) |
+							       ((uint64_t)__builtin_amdgcn_alignbit(a[2 * q + 2], a[2 * q + 1], sf) << 32);
+							// bits past the last base are zeroed: equal super-k-mers are equal records (k_aggregate merges them)
+							const uint32_t rem = nbases - 32u * q;
+							if (rem < 32u) word &= (1ull << (2u * rem)) - 1;
+						}
+						rec.w[q] = word;
+					}
+					const uint32_t moff = jrel + hasL;
+					rec.w[NB] = (uint64_t)pr | ((uint64_t)(len - 1) << 16) | ((uint64_t)hasL << 22) | ((uint64_t)hasR << 23) |
+					            ((uint64_t)moff << 24) | ((read_id_base + rb + src) << 31);
+					recs[chunk_base + chunk_used + lane] = rec;
+					const uint32_t bk = bucket24(order_unmix((uint32_t)(d >> 32)));
+					atomicAdd(&s_hist[modulo ? bk % modulo : bk >> hist_shift], 1u);
+				}
+				chunk_used += cnt;
+				qhead += cnt;
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+			}
+		}
+	}
+	if (have_chunk && !dead)
+		for (uint32_t q = chunk_used + lane; q < REC_CHUNK; q += 64) recs[chunk_base + q].w[NB] = REC_INVALID;
+#pragma unroll
+	for (int d = 32; d; d >>= 1) occ += __shfl_xor(occ, d);
+	if (lane == 0 && occ) atomicAdd(&counters[2 /*C_OCC*/], occ);
+	__syncthreads();
+	if (s_hist[threadIdx.x]) atomicAdd(&coarse_hist[threadIdx.x], (unsigned long long)s_hist[threadIdx.x]);
+}
+
+// ------------------------------------------------------------------------------------------------
 // One partition level.  The input is cut into S segments (seg_begin[S+1]; level 1: the single segment
 // [0, n_in) of k_superkmers output, holes included).  A tile of SCATTER_TILE records never crosses a
 // segment (tile_first[s] = first tile of segment s).  digit = (bucket24 >> shift) & (2^dbits - 1);
