@@ -425,127 +425,131 @@ __global__ __launch_bounds__(256) void k_superkmers_lanes(const uint64_t *__rest
 		const uint32_t lastw = L ? (sh + 2u * L - 1u) >> 5 : 0u;  // last dword that holds a base of this read
 		uint32_t lo = L ? rp[0] : 0u;
 		uint32_t pend = (L && 1u <= lastw) ? rp[1] : 0u;
-		uint32_t widx = 2, buf = 0, f = 0, r = 0, t = 0;
-		auto next_base = [&]() -> uint32_t {
-			if ((t & 15u) == 0) {  // wave-uniform
-				const uint32_t hi = pend;
-				buf = __builtin_amdgcn_alignbit(hi, lo, sh);
-				lo = hi;
-				pend = (L && widx <= lastw) ? rp[widx] : 0u;
-				++widx;
-			}
-			const uint32_t c = buf & 3u;
-			buf >>= 2;
-			++t;
-			return c;
-		};
-		for (int q = 0; q < m - 1; ++q) {
-			const uint32_t c = next_base();
-			f = (f >> 2) | (c << top);
-			r = ((r << 2) | (c ^ 3u)) & maskm;
-		}
+		uint32_t widx = 2, f = 0, r = 0;
 		unsigned long long pre = ~0ull, cur = ~0ull;
 		uint32_t start = 0, i = 0;
 		const uint32_t nsteps = maxn + w;  // m-mers 0 .. max(nm): k-mer p is complete at j = p + w - 1, and p = n closes the last record
-		for (uint32_t j = 0; j < nsteps; ++j) {
-			unsigned long long sfx = ~0ull;
-			if (i + 1 < w) sfx = win[(i + 1) * 64];  // S[i+1] of the previous block (garbage in the first block: not used there)
-			const uint32_t c = next_base();
-			f = (f >> 2) | (c << top);
-			r = ((r << 2) | (c ^ 3u)) & maskm;
-			const uint32_t cm = f < r ? f : r;
-			const unsigned long long x = ((unsigned long long)order_mix(cm) << 32) | j;
-			win[i * 64] = x;
-			pre = (i == 0 || x < pre) ? x : pre;
-			if (j + 1 >= w) {  // wave-uniform
-				const unsigned long long res = sfx < pre ? sfx : pre;  // j = w-1 (first block): i+1 = w, sfx = ~0, the window is the block
-				const uint32_t p = j + 1 - w;
-				const bool changed = (uint32_t)res != (uint32_t)cur;
-				const bool push = p > 0 && p <= n && (p == n || changed);
-				const unsigned long long bal = __ballot(push);
-				if (bal) {
-					if (push) {
-						const uint32_t d = start | ((p - start - 1u) << 16) | (lane << 21) | (((uint32_t)cur - start) << 27);
-						ring[(qtail + (uint32_t)__popcll(bal & lt_mask)) & (SKL_RING - 1)] = (cur & 0xFFFFFFFF00000000ull) | d;
-					}
-					qtail += (uint32_t)__popcll(bal);
-				}
-				if (p < n && changed) {
-					start = p;
-					cur = res;
-				}
-			}
-			++i;
-			if (i == w) {  // block complete: slot t becomes the minimum of entries t .. w-1
-				unsigned long long run = x;
-				for (uint32_t q = w - 1; q-- > 1;) {
-					const unsigned long long v = win[q * 64];
-					run = v < run ? v : run;
-					win[q * 64] = run;
-				}
-				i = 0;
-			}
-			// assemble 64 queued records (all of them after the last step), lane per record
-			while (qtail - qhead >= 64u || (j + 1 == nsteps && qtail != qhead)) {
-				const uint32_t cnt = (qtail - qhead < 64u) ? qtail - qhead : 64u;
-				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-				__builtin_amdgcn_wave_barrier();
-				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-				if (chunk_used + cnt > REC_CHUNK) {
-					if (have_chunk && !dead)
-						for (uint32_t q = chunk_used + lane; q < REC_CHUNK; q += 64) recs[chunk_base + q].w[NB] = REC_INVALID;
-					unsigned long long nbase = 0;
-					if (lane == 0) nbase = atomicAdd(&counters[PC_REC_CURSOR], (unsigned long long)REC_CHUNK);
-					nbase = __shfl(nbase, 0);
-					if (nbase + REC_CHUNK > rec_cap) {
-						dead = true;
-						if (lane == 0) atomicAdd(&counters[PC_REC_OVF], 1ull);
-					}
-					chunk_base = nbase;
-					chunk_used = 0;
-					have_chunk = true;
-				}
-				if (!dead && lane < cnt) {
-					const unsigned long long d = ring[(qhead + lane) & (SKL_RING - 1)];
-					const uint32_t dl = (uint32_t)d;
-					const uint32_t pr = dl & 0xFFFFu, len = ((dl >> 16) & 31u) + 1u, src = (dl >> 21) & 63u, jrel = dl >> 27;
-					const uint32_t Ls = s_len[wave][src];
-					const uint64_t b0 = s_bit0[wave][src];
-					const uint32_t ns = Ls - (uint32_t)k + 1;
-					const uint32_t hasL = pr > 0, hasR = (pr + len) < ns;
-					const uint32_t first = pr - hasL;  // read position of the record's base 0
-					const uint32_t nbases = hasL + len + (uint32_t)k - 1 + hasR;
-					const uint64_t bit = b0 + 2ull * first;
-					const uint32_t *__restrict__ wp = P32 + (bit >> 5);
-					const uint32_t sf = (uint32_t)bit & 31u;
-					const uint32_t ndw = (sf + 2u * nbases + 31u) >> 5;  // dwords that hold the record's bases
-					uint32_t a[2 * NB + 1];
-#pragma unroll
-					for (int q = 0; q < 2 * NB + 1; ++q) a[q] = ((uint32_t)q < ndw) ? wp[q] : 0u;
-					Rec<W> rec;
-#pragma unroll
-					for (int q = 0; q < NB; ++q) {
-						uint64_t word = 0;
-						if (nbases > 32u * q) {
-							word = (uint64_t)__builtin_amdgcn_alignbit(a[2 * q + 1], a[2 * q], sf) |
-							       ((uint64_t)__builtin_amdgcn_alignbit(a[2 * q + 2], a[2 * q + 1], sf) << 32);
-							// bits past the last base are zeroed: equal super-k-mers are equal records (k_aggregate merges them)
-							const uint32_t rem = nbases - 32u * q;
-							if (rem < 32u) word &= (1ull << (2u * rem)) - 1;
+		const uint32_t nbase = nsteps + (uint32_t)m - 1;  // bases walked: m-mer j is complete with base j + m - 1
+		for (uint32_t t0 = 0; t0 < nbase; t0 += 16) {
+			// 16 bases per refill; the dword for the next refill is requested now and not touched inside the inner loop
+			const uint32_t hi = pend;
+			uint32_t buf = __builtin_amdgcn_alignbit(hi, lo, sh);
+			lo = hi;
+			asm volatile("" : "+v"(buf) : : "memory");  // the wait for the old dword must not end up behind the new request
+			pend = (L && widx <= lastw) ? rp[widx] : 0u;
+			++widx;
+			const uint32_t tend = (t0 + 16u < nbase) ? t0 + 16u : nbase;
+			for (uint32_t t = t0; t < tend; ++t) {
+				const uint32_t c = buf & 3u;
+				buf >>= 2;
+				f = (f >> 2) | (c << top);
+				r = ((r << 2) | (c ^ 3u)) & maskm;
+				if (t + 1 < (uint32_t)m) continue;  // wave-uniform
+				const uint32_t j = t + 1 - (uint32_t)m;
+				unsigned long long sfx = ~0ull;
+				if (i + 1 < w) sfx = win[(i + 1) * 64];  // S[i+1] of the previous block (garbage in the first block: not used there)
+				const uint32_t cm = f < r ? f : r;
+				const unsigned long long x = ((unsigned long long)order_mix(cm) << 32) | j;
+				win[i * 64] = x;
+				pre = (i == 0 || x < pre) ? x : pre;
+				if (j + 1 >= w) {  // wave-uniform
+					const unsigned long long res = sfx < pre ? sfx : pre;  // j = w-1 (first block): i+1 = w, sfx = ~0, the window is the block
+					const uint32_t p = j + 1 - w;
+					const bool changed = (uint32_t)res != (uint32_t)cur;
+					const bool push = p > 0 && p <= n && (p == n || changed);
+					const unsigned long long bal = __ballot(push);
+					if (bal) {
+						if (push) {
+							const uint32_t d = start | ((p - start - 1u) << 16) | (lane << 21) | (((uint32_t)cur - start) << 27);
+							ring[(qtail + (uint32_t)__popcll(bal & lt_mask)) & (SKL_RING - 1)] = (cur & 0xFFFFFFFF00000000ull) | d;
 						}
-						rec.w[q] = word;
+						qtail += (uint32_t)__popcll(bal);
 					}
-					const uint32_t moff = jrel + hasL;
-					rec.w[NB] = (uint64_t)pr | ((uint64_t)(len - 1) << 16) | ((uint64_t)hasL << 22) | ((uint64_t)hasR << 23) |
-					            ((uint64_t)moff << 24) | ((read_id_base + rb + src) << 31);
-					recs[chunk_base + chunk_used + lane] = rec;
-					const uint32_t bk = bucket24(order_unmix((uint32_t)(d >> 32)));
-					atomicAdd(&s_hist[modulo ? bk % modulo : bk >> hist_shift], 1u);
+					if (p < n && changed) {
+						start = p;
+						cur = res;
+					}
 				}
-				chunk_used += cnt;
-				qhead += cnt;
-				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-				__builtin_amdgcn_wave_barrier();
+				++i;
+				if (i == w) {  // block complete: slot t becomes the minimum of entries t .. w-1
+					// four entries per round so that their LDS latencies overlap; slot 0 is nobody's S (indices are clamped to it)
+					unsigned long long run = x;
+					for (int q = (int)w - 2; q >= 0; q -= 4) {
+						const int q1 = q > 0 ? q - 1 : 0, q2 = q > 1 ? q - 2 : 0, q3 = q > 2 ? q - 3 : 0;
+						const unsigned long long v0 = win[q * 64], v1 = win[q1 * 64], v2 = win[q2 * 64], v3 = win[q3 * 64];
+						run = v0 < run ? v0 : run;
+						win[q * 64] = run;
+						run = v1 < run ? v1 : run;
+						win[q1 * 64] = run;
+						run = v2 < run ? v2 : run;
+						win[q2 * 64] = run;
+						run = v3 < run ? v3 : run;
+						win[q3 * 64] = run;
+					}
+					i = 0;
+				}
+				// assemble 64 queued records (all of them after the last step), lane per record
+				while (qtail - qhead >= 64u || (j + 1 == nsteps && qtail != qhead)) {
+					const uint32_t cnt = (qtail - qhead < 64u) ? qtail - qhead : 64u;
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+					__builtin_amdgcn_wave_barrier();
+					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+					if (chunk_used + cnt > REC_CHUNK) {
+						if (have_chunk && !dead)
+							for (uint32_t q = chunk_used + lane; q < REC_CHUNK; q += 64) recs[chunk_base + q].w[NB] = REC_INVALID;
+						unsigned long long nbase = 0;
+						if (lane == 0) nbase = atomicAdd(&counters[PC_REC_CURSOR], (unsigned long long)REC_CHUNK);
+						nbase = __shfl(nbase, 0);
+						if (nbase + REC_CHUNK > rec_cap) {
+							dead = true;
+							if (lane == 0) atomicAdd(&counters[PC_REC_OVF], 1ull);
+						}
+						chunk_base = nbase;
+						chunk_used = 0;
+						have_chunk = true;
+					}
+					if (!dead && lane < cnt) {
+						const unsigned long long d = ring[(qhead + lane) & (SKL_RING - 1)];
+						const uint32_t dl = (uint32_t)d;
+						const uint32_t pr = dl & 0xFFFFu, len = ((dl >> 16) & 31u) + 1u, src = (dl >> 21) & 63u, jrel = dl >> 27;
+						const uint32_t Ls = s_len[wave][src];
+						const uint64_t b0 = s_bit0[wave][src];
+						const uint32_t ns = Ls - (uint32_t)k + 1;
+						const uint32_t hasL = pr > 0, hasR = (pr + len) < ns;
+						const uint32_t first = pr - hasL;  // read position of the record's base 0
+						const uint32_t nbases = hasL + len + (uint32_t)k - 1 + hasR;
+						const uint64_t bit = b0 + 2ull * first;
+						const uint32_t *__restrict__ wp = P32 + (bit >> 5);
+						const uint32_t sf = (uint32_t)bit & 31u;
+						const uint32_t ndw = (sf + 2u * nbases + 31u) >> 5;  // dwords that hold the record's bases
+						uint32_t a[2 * NB + 1];
+#pragma unroll
+						for (int q = 0; q < 2 * NB + 1; ++q) a[q] = ((uint32_t)q < ndw) ? wp[q] : 0u;
+						Rec<W> rec;
+#pragma unroll
+						for (int q = 0; q < NB; ++q) {
+							uint64_t word = 0;
+							if (nbases > 32u * q) {
+								word = (uint64_t)__builtin_amdgcn_alignbit(a[2 * q + 1], a[2 * q], sf) |
+								       ((uint64_t)__builtin_amdgcn_alignbit(a[2 * q + 2], a[2 * q + 1], sf) << 32);
+								// bits past the last base are zeroed: equal super-k-mers are equal records (k_aggregate merges them)
+								const uint32_t rem = nbases - 32u * q;
+								if (rem < 32u) word &= (1ull << (2u * rem)) - 1;
+							}
+							rec.w[q] = word;
+						}
+						const uint32_t moff = jrel + hasL;
+						rec.w[NB] = (uint64_t)pr | ((uint64_t)(len - 1) << 16) | ((uint64_t)hasL << 22) | ((uint64_t)hasR << 23) |
+						            ((uint64_t)moff << 24) | ((read_id_base + rb + src) << 31);
+						recs[chunk_base + chunk_used + lane] = rec;
+						const uint32_t bk = bucket24(order_unmix((uint32_t)(d >> 32)));
+						atomicAdd(&s_hist[modulo ? bk % modulo : bk >> hist_shift], 1u);
+					}
+					chunk_used += cnt;
+					qhead += cnt;
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+					__builtin_amdgcn_wave_barrier();
+				}
 			}
 		}
 	}
