@@ -281,6 +281,8 @@ def main():
             "k_aggregate": recs0 * rec_bytes + st["log_entries"] * 32,       # records in, entries out
             "k_merge": st["log_entries"] * 32 + cand0 * 32,                  # entries in, slots written
             "k_bloom_items": (st["log_entries"] if "k_insert_admitted" in kprof else st["table_slots"]) * 32 + cand0 * 64,  # scan in, 8 items of 8 B per key out
+            "k_bloom_hist": (st["log_entries"] if "k_insert_admitted" in kprof else st["table_slots"]) * 32,   # key scan, nothing written
+            "k_bloom_scatter_items": (st["log_entries"] if "k_insert_admitted" in kprof else st["table_slots"]) * 32 + cand0 * 64,  # key scan in, 8 items of 8 B per key out, already in level-0 order
             "k_insert_admitted": st["log_entries"] * 32 + st["stored_pairs"] * 32,   # log in, admitted slots written
             "k_scatter64": 2 * cand0 * 64,                                    # items in + out, per level (x launches below)
             "k_bloom_region": cand0 * 64,                                     # items in (contested stamps are extra)

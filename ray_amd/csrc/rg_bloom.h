@@ -5,8 +5,9 @@
 // fill the reference's sizing aims for (a few percent) almost every bit is touched by one key only, and
 // then nothing has to be ordered at all.  So instead:
 //
-//   k_bloom_items   8 items (bit index, table slot) per key, streamed out
-//   k_scatter64     1-2 partition levels by Bloom region (2^17 bits per region)
+//   k_bloom_hist + k_bloom_scatter_items   8 items (bit index, table slot) per key, produced straight into the
+//                   ranges of the first partition level (histogram first, so nothing is streamed out and read back)
+//   k_scatter64     the second partition level by Bloom region (2^17 bits per region), when there are more than 256 regions
 //   k_bloom_region  one workgroup per region, all in LDS: two bitmaps (touched / touched again);
 //                   only for bits touched more than once are the stamps fetched and the earliest
 //                   found; every later toucher of such a bit gets one "lost" mark on its key
@@ -26,75 +27,122 @@ static constexpr uint32_t REGION_WORDS = REGION_BITS / 32;  // 4096 words per bi
 static constexpr uint32_t REGION_MULTI_CAP = 4096;          // contested bits a region can rank (32 KB of stamps): 2 workgroups per CU
 static constexpr uint32_t REGION_MULTI_CAP_BIG = 10240;     // fuller filters: 80 KB of stamps, 1 workgroup per CU
 static constexpr uint64_t ITEM_INVALID = ~0ull;
-static constexpr uint32_t ITEM_CHUNK_KEYS = 512;  // keys (x8 items) a wavefront claims at a time
 static constexpr int SCATTER64_TILE = 4096;
 
 enum BloomCounter { BC_ITEM_CURSOR = 24, BC_ITEM_OVF, BC_REGION_OVF };
 
 // item = bit index (33 bits) << 31 | table slot (31 bits)
+
+// x mod d with d fixed for the launch: inv = floor(2^64 / d) (host), or 0 when d is a power of two.  The estimate
+// q = floor(x * inv / 2^64) is floor(x / d) or one less, so one conditional subtraction settles it -- a 64-bit
+// division costs ~200 instructions per Bloom bit otherwise.
+__device__ __forceinline__ uint64_t bloom_mod(uint64_t x, uint64_t d, uint64_t inv) {
+	if (inv == 0) return x & (d - 1);
+	const uint64_t r = x - __umul64hi(x, inv) * d;
+	return r >= d ? r - d : r;
+}
+
+// Level-0 digit histogram of the items of all keys, nothing written: with it the items can be produced straight
+// into their level-0 ranges (k_bloom_scatter_items) instead of being streamed out and partitioned afterwards.
 template <int W>
-__global__ __launch_bounds__(256) void k_bloom_items(const Slot *__restrict__ tab, uint64_t cap, uint64_t m_bits,
-                                                     unsigned long long *__restrict__ items, uint64_t item_cap, int shift1,
-                                                     unsigned long long *__restrict__ counters, unsigned long long *__restrict__ hist1) {
+__global__ __launch_bounds__(256) void k_bloom_hist(const Slot *__restrict__ tab, uint64_t cap, uint64_t m_bits, uint64_t m_inv, int shift1,
+                                                    unsigned long long *__restrict__ hist1) {
 	__shared__ uint32_t s_hist[256];
-	const uint32_t lane = threadIdx.x & 63u;
 	s_hist[threadIdx.x] = 0;
 	__syncthreads();
-	uint64_t chunk_base = 0;
-	uint32_t chunk_used = ITEM_CHUNK_KEYS;
-	bool have_chunk = false, dead = false;
-	const uint64_t nwaves = (uint64_t)gridDim.x * 4, wave_id = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-	for (uint64_t base = wave_id * 64; base < cap; base += nwaves * 64) {
-		const uint64_t i = base + lane;
-		Slot v;
-		bool used = false;
-		if (i < cap) {
-			v = tab[i];
-			used = v.k0 != EMPTY;
-		}
-		const unsigned long long ballot = __ballot(used);
-		const uint32_t c = (uint32_t)__popcll(ballot);
-		if (c == 0) continue;
-		// keys that do not fit the current chunk continue in a freshly claimed one (no holes in between)
-		const uint32_t room = have_chunk ? ITEM_CHUNK_KEYS - chunk_used : 0u;
-		uint64_t new_base = 0;
-		if (c > room) {
-			unsigned long long nb = 0;
-			if (lane == 0) nb = atomicAdd(&counters[BC_ITEM_CURSOR], (unsigned long long)ITEM_CHUNK_KEYS * 8);
-			nb = __shfl(nb, 0);
-			if (nb + ITEM_CHUNK_KEYS * 8 > item_cap) {
-				dead = true;
-				if (lane == 0) atomicAdd(&counters[BC_ITEM_OVF], 1ull);
-			}
-			new_base = nb;
-		}
-		if (used && !dead) {
-			const uint32_t idx = (uint32_t)__popcll(ballot & ((1ull << lane) - 1));
-			uint64_t K0, K1;
-			from_internal<W>(v.k0, v.k1, K0, K1);
-			const uint64_t origin = hash2<W>(K0, K1);
-			unsigned long long *dst = (idx < room) ? items + chunk_base + (uint64_t)(chunk_used + idx) * 8
-			                                       : items + new_base + (uint64_t)(idx - room) * 8;
+	for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * 256) {
+		const uint64_t k0 = tab[i].k0;
+		if (k0 == EMPTY) continue;
+		const uint64_t k1 = (W == 2) ? tab[i].k1 : EMPTY;
+		uint64_t K0, K1;
+		from_internal<W>(k0, k1, K0, K1);
+		const uint64_t origin = hash2<W>(K0, K1);
 #pragma unroll
-			for (int j = 0; j < 8; ++j) {
-				const uint64_t b = (origin ^ BLOOM_MAGIC[j]) % m_bits;
-				const unsigned long long item = (b << 31) | i;
-				dst[j] = item;
-				atomicAdd(&s_hist[(item >> shift1) & 255u], 1u);
-			}
-		}
-		if (c > room) {
-			chunk_base = new_base;
-			chunk_used = c - room;
-			have_chunk = true;
-		} else {
-			chunk_used += c;
+		for (int j = 0; j < 8; ++j) {
+			const unsigned long long item = (bloom_mod(origin ^ BLOOM_MAGIC[j], m_bits, m_inv) << 31) | i;
+			atomicAdd(&s_hist[(item >> shift1) & 255u], 1u);
 		}
 	}
-	if (have_chunk && !dead)
-		for (uint32_t j = chunk_used * 8 + lane; j < ITEM_CHUNK_KEYS * 8; j += 64) items[chunk_base + j] = ITEM_INVALID;
 	__syncthreads();
 	if (s_hist[threadIdx.x]) atomicAdd(&hist1[threadIdx.x], (unsigned long long)s_hist[threadIdx.x]);
+}
+
+// The items of 512 slots (up to 4096) are made in registers, sorted by their level-0 digit in LDS and written as
+// runs at the tile's cursor claims: k_scatter64's scheme with the items computed instead of loaded.
+static constexpr int ITEM_TILE_SLOTS = 512;
+template <int W>
+__global__ __launch_bounds__(256) void k_bloom_scatter_items(const Slot *__restrict__ tab, uint64_t cap, uint64_t m_bits, uint64_t m_inv,
+                                                             int shift1, unsigned long long *__restrict__ cursors,
+                                                             unsigned long long *__restrict__ out) {
+	constexpr int KEYS = ITEM_TILE_SLOTS / 256, PER = 8 * KEYS;
+	__shared__ unsigned long long s_item[8 * ITEM_TILE_SLOTS];
+	__shared__ uint8_t s_dig[8 * ITEM_TILE_SLOTS];
+	__shared__ uint32_t s_cnt[256], s_off[256], s_scan[8];
+	__shared__ unsigned long long s_gbase[256];
+	const uint64_t base = (uint64_t)blockIdx.x * ITEM_TILE_SLOTS;
+	s_cnt[threadIdx.x] = 0;
+	__syncthreads();
+	unsigned long long mine[PER];
+	uint32_t dr[PER];  // digit << 16 | rank inside the tile
+#pragma unroll
+	for (int q = 0; q < KEYS; ++q) {
+		const uint64_t i = base + threadIdx.x + (uint64_t)q * 256;
+		uint64_t k0 = EMPTY, k1 = EMPTY;
+		if (i < cap) {
+			k0 = tab[i].k0;
+			if (W == 2) k1 = tab[i].k1;
+		}
+#pragma unroll
+		for (int j = 0; j < 8; ++j) dr[q * 8 + j] = 0xFFFFFFFFu;
+		if (k0 != EMPTY) {
+			uint64_t K0, K1;
+			from_internal<W>(k0, k1, K0, K1);
+			const uint64_t origin = hash2<W>(K0, K1);
+#pragma unroll
+			for (int j = 0; j < 8; ++j) {
+				const unsigned long long item = (bloom_mod(origin ^ BLOOM_MAGIC[j], m_bits, m_inv) << 31) | i;
+				const uint32_t d = (uint32_t)(item >> shift1) & 255u;
+				mine[q * 8 + j] = item;
+				dr[q * 8 + j] = (d << 16) | atomicAdd(&s_cnt[d], 1u);
+			}
+		}
+	}
+	__syncthreads();
+	{
+		const uint32_t c = s_cnt[threadIdx.x];
+		const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+		uint32_t incl = c;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			const uint32_t o = __shfl_up(incl, d);
+			if (lane >= (uint32_t)d) incl += o;
+		}
+		if (lane == 63) s_scan[wv] = incl;
+		__syncthreads();
+		uint32_t before = 0;
+#pragma unroll
+		for (uint32_t q = 0; q < 4; ++q)
+			if (q < wv) before += s_scan[q];
+		s_off[threadIdx.x] = before + incl - c;
+		if (threadIdx.x == 255) s_scan[4] = before + incl;
+		unsigned long long g = 0;
+		if (c) g = atomicAdd(&cursors[threadIdx.x], (unsigned long long)c);
+		s_gbase[threadIdx.x] = g;
+	}
+	__syncthreads();
+	const uint32_t total = s_scan[4];
+#pragma unroll
+	for (int j = 0; j < PER; ++j)
+		if (dr[j] != 0xFFFFFFFFu) {
+			const uint32_t pos = s_off[dr[j] >> 16] + (dr[j] & 0xFFFFu);
+			s_item[pos] = mine[j];
+			s_dig[pos] = (uint8_t)(dr[j] >> 16);
+		}
+	__syncthreads();
+	for (uint32_t i = threadIdx.x; i < total; i += 256) {
+		const uint32_t d = s_dig[i];
+		out[s_gbase[d] + (i - s_off[d])] = s_item[i];
+	}
 }
 
 __device__ __forceinline__ uint32_t find_seg64(const uint32_t *__restrict__ tile_first, uint32_t S, uint32_t tile) {
