@@ -378,8 +378,6 @@ __global__ __launch_bounds__(256) void k_superkmers_lanes(const uint64_t *__rest
 	constexpr int NB = 2 * W;
 	extern __shared__ unsigned long long s_win_all[];  // [4 wavefronts][w entries][64 lanes]
 	__shared__ unsigned long long s_q[4][SKL_RING];
-	__shared__ unsigned long long s_bit0[4][64];
-	__shared__ uint32_t s_len[4][64];
 	__shared__ uint32_t s_hist[NB_COARSE];
 	const uint32_t *__restrict__ P32 = reinterpret_cast<const uint32_t *>(P);
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -390,7 +388,6 @@ __global__ __launch_bounds__(256) void k_superkmers_lanes(const uint64_t *__rest
 	__syncthreads();
 	const uint32_t maskm = (1u << (2 * m)) - 1;
 	const uint32_t top = 2u * (uint32_t)(m - 1);
-	const unsigned long long lt_mask = (1ull << lane) - 1;
 	const uint64_t nwaves = (uint64_t)gridDim.x * 4;
 	const uint64_t ngroups = (nreads + 63) / 64;
 	uint64_t chunk_base = 0;
@@ -418,16 +415,14 @@ __global__ __launch_bounds__(256) void k_superkmers_lanes(const uint64_t *__rest
 		}
 		maxn = (uint32_t)__builtin_amdgcn_readfirstlane((int)maxn);
 		if (maxn == 0) continue;
-		s_bit0[wave][lane] = bit0;
-		s_len[wave][lane] = L;
 		const uint32_t sh = (uint32_t)bit0 & 31u;
 		const uint32_t *__restrict__ rp = P32 + (bit0 >> 5);
 		const uint32_t lastw = L ? (sh + 2u * L - 1u) >> 5 : 0u;  // last dword that holds a base of this read
 		uint32_t lo = L ? rp[0] : 0u;
 		uint32_t pend = (L && 1u <= lastw) ? rp[1] : 0u;
 		uint32_t widx = 2, f = 0, r = 0;
-		unsigned long long pre = ~0ull, cur = ~0ull;
-		uint32_t start = 0, i = 0;
+		uint32_t pre_hi = ~0u, pre_lo = 0, cur_hi = 0, cur_lo = ~0u, dbase = 0, i = 0;
+		const uint32_t lane_term = lane << 21;
 		const uint32_t nsteps = maxn + w;  // m-mers 0 .. max(nm): k-mer p is complete at j = p + w - 1, and p = n closes the last record
 		const uint32_t nbase = nsteps + (uint32_t)m - 1;  // bases walked: m-mer j is complete with base j + m - 1
 		for (uint32_t t0 = 0; t0 < nbase; t0 += 16) {
@@ -449,42 +444,59 @@ __global__ __launch_bounds__(256) void k_superkmers_lanes(const uint64_t *__rest
 				unsigned long long sfx = ~0ull;
 				if (i + 1 < w) sfx = win[(i + 1) * 64];  // S[i+1] of the previous block (garbage in the first block: not used there)
 				const uint32_t cm = f < r ? f : r;
-				const unsigned long long x = ((unsigned long long)order_mix(cm) << 32) | j;
-				win[i * 64] = x;
-				pre = (i == 0 || x < pre) ? x : pre;
+				const uint32_t mix = order_mix(cm);
+				win[i * 64] = ((unsigned long long)mix << 32) | j;
+				// (mix, position) pairs are ordered by mix, the earlier position winning ties: positions only grow, so
+				// 32-bit compares of the mixes do, < where the newcomer is the later one, <= where it is the earlier one
+				const bool newpre = i == 0 || mix < pre_hi;
+				pre_hi = newpre ? mix : pre_hi;
+				pre_lo = newpre ? j : pre_lo;
 				if (j + 1 >= w) {  // wave-uniform
-					const unsigned long long res = sfx < pre ? sfx : pre;  // j = w-1 (first block): i+1 = w, sfx = ~0, the window is the block
+					// j = w-1 (first block): i+1 = w, the window is the block
+					const bool use_sfx = (i + 1 < w) && (uint32_t)(sfx >> 32) <= pre_hi;
+					const uint32_t res_hi = use_sfx ? (uint32_t)(sfx >> 32) : pre_hi, res_lo = use_sfx ? (uint32_t)sfx : pre_lo;
 					const uint32_t p = j + 1 - w;
-					const bool changed = (uint32_t)res != (uint32_t)cur;
+					const bool changed = res_lo != cur_lo;
 					const bool push = p > 0 && p <= n && (p == n || changed);
 					const unsigned long long bal = __ballot(push);
 					if (bal) {
 						if (push) {
-							const uint32_t d = start | ((p - start - 1u) << 16) | (lane << 21) | (((uint32_t)cur - start) << 27);
-							ring[(qtail + (uint32_t)__popcll(bal & lt_mask)) & (SKL_RING - 1)] = (cur & 0xFFFFFFFF00000000ull) | d;
+							// dbase + ((p - 1) << 16) = start | (p - start - 1) << 16 | lane << 21 | (minimizer position - start) << 27
+							const uint32_t d = dbase + ((p - 1u) << 16);
+							const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+							ring[(qtail + rk) & (SKL_RING - 1)] = ((unsigned long long)cur_hi << 32) | d;
 						}
 						qtail += (uint32_t)__popcll(bal);
 					}
-					if (p < n && changed) {
-						start = p;
-						cur = res;
+					if (p < n && changed) {  // a record starts at p
+						dbase = (res_lo << 27) + (lane_term + p * (1u - (1u << 16) - (1u << 27)));
+						cur_lo = res_lo;
+						cur_hi = res_hi;
 					}
 				}
 				++i;
 				if (i == w) {  // block complete: slot t becomes the minimum of entries t .. w-1
 					// four entries per round so that their LDS latencies overlap; slot 0 is nobody's S (indices are clamped to it)
-					unsigned long long run = x;
+					uint32_t run_hi = mix, run_lo = j;
 					for (int q = (int)w - 2; q >= 0; q -= 4) {
 						const int q1 = q > 0 ? q - 1 : 0, q2 = q > 1 ? q - 2 : 0, q3 = q > 2 ? q - 3 : 0;
 						const unsigned long long v0 = win[q * 64], v1 = win[q1 * 64], v2 = win[q2 * 64], v3 = win[q3 * 64];
-						run = v0 < run ? v0 : run;
-						win[q * 64] = run;
-						run = v1 < run ? v1 : run;
-						win[q1 * 64] = run;
-						run = v2 < run ? v2 : run;
-						win[q2 * 64] = run;
-						run = v3 < run ? v3 : run;
-						win[q3 * 64] = run;
+						const bool t0 = (uint32_t)(v0 >> 32) <= run_hi;
+						run_hi = t0 ? (uint32_t)(v0 >> 32) : run_hi;
+						run_lo = t0 ? (uint32_t)v0 : run_lo;
+						win[q * 64] = ((unsigned long long)run_hi << 32) | run_lo;
+						const bool t1 = (uint32_t)(v1 >> 32) <= run_hi;
+						run_hi = t1 ? (uint32_t)(v1 >> 32) : run_hi;
+						run_lo = t1 ? (uint32_t)v1 : run_lo;
+						win[q1 * 64] = ((unsigned long long)run_hi << 32) | run_lo;
+						const bool t2 = (uint32_t)(v2 >> 32) <= run_hi;
+						run_hi = t2 ? (uint32_t)(v2 >> 32) : run_hi;
+						run_lo = t2 ? (uint32_t)v2 : run_lo;
+						win[q2 * 64] = ((unsigned long long)run_hi << 32) | run_lo;
+						const bool t3 = (uint32_t)(v3 >> 32) <= run_hi;
+						run_hi = t3 ? (uint32_t)(v3 >> 32) : run_hi;
+						run_lo = t3 ? (uint32_t)v3 : run_lo;
+						win[q3 * 64] = ((unsigned long long)run_hi << 32) | run_lo;
 					}
 					i = 0;
 				}
@@ -508,12 +520,15 @@ __global__ __launch_bounds__(256) void k_superkmers_lanes(const uint64_t *__rest
 						chunk_used = 0;
 						have_chunk = true;
 					}
+					// all lanes take part in the shuffles (a lane that is switched off cannot be read from): the read of lane
+					// src gives its length and bit offset over the lane crossbar, not through LDS arrays, whose 3 KB would
+					// cost the kernel its fourth workgroup per CU
+					const unsigned long long d = ring[(qhead + lane) & (SKL_RING - 1)];
+					const uint32_t dl = (uint32_t)d;
+					const uint32_t pr = dl & 0xFFFFu, len = ((dl >> 16) & 31u) + 1u, src = (dl >> 21) & 63u, jrel = dl >> 27;
+					const uint32_t Ls = (uint32_t)__shfl((int)L, (int)src);
+					const uint64_t b0 = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(bit0 >> 32), (int)src) << 32) | (uint32_t)__shfl((int)(uint32_t)bit0, (int)src);
 					if (!dead && lane < cnt) {
-						const unsigned long long d = ring[(qhead + lane) & (SKL_RING - 1)];
-						const uint32_t dl = (uint32_t)d;
-						const uint32_t pr = dl & 0xFFFFu, len = ((dl >> 16) & 31u) + 1u, src = (dl >> 21) & 63u, jrel = dl >> 27;
-						const uint32_t Ls = s_len[wave][src];
-						const uint64_t b0 = s_bit0[wave][src];
 						const uint32_t ns = Ls - (uint32_t)k + 1;
 						const uint32_t hasL = pr > 0, hasR = (pr + len) < ns;
 						const uint32_t first = pr - hasL;  // read position of the record's base 0
