@@ -1232,7 +1232,7 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	(void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
 	SuperkmerLaunch<W> sk;
 	sk.plan(h, n_cu, k, m, total_reads);
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ3, k_aggregate<W, false>, 256, 0) != hipSuccess || occ3 < 1) occ3 = 4;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ3, k_aggregate<W, false>, 64 * AGG_WAVES, 0) != hipSuccess || occ3 < 1) occ3 = 4;
 	(void)hipGetLastError();
 	const int grid1 = sk.grid_max();
 	uint64_t launches1 = 0;  // every launch of k_superkmers leaves up to one open chunk per wavefront
@@ -1387,7 +1387,7 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 		hipError_t e0 = hipMemsetAsync(h->d_counters + PC_LOG_CURSOR, 0, 6 * sizeof(unsigned long long), h->stream);
 		if (e0 == hipSuccess) {
 			ProfScope ps(h, "k_aggregate");
-			hipLaunchKernelGGL((k_aggregate<W, false>), dim3(agg_grid), dim3(256), 0, h->stream, level_in, d_begin, (uint32_t)NBUCK, k, log, log_cap,
+			hipLaunchKernelGGL((k_aggregate<W, false>), dim3(agg_grid), dim3(64 * AGG_WAVES), 0, h->stream, level_in, d_begin, (uint32_t)NBUCK, k, log, log_cap,
 			                   h->d_counters, flag_unique, (const uint32_t *)nullptr, d_retry, m, (uint32_t)(24 - bits));
 			e0 = hipGetLastError();
 		}
@@ -1399,7 +1399,7 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 			if (n_retry && !too_small && !h->h_counters[PC_LOG_OVF]) {  // the buckets whose k-mers did not fit the LDS table: split further
 				ProfScope ps(h, "k_aggregate_retry");
 				const unsigned g2 = (unsigned)std::min<uint64_t>((n_retry + AGG_WAVES - 1) / AGG_WAVES, (uint64_t)n_cu * occ3);
-				hipLaunchKernelGGL((k_aggregate<W, true>), dim3(g2), dim3(256), 0, h->stream, level_in, d_begin, (uint32_t)n_retry, k, log, log_cap,
+				hipLaunchKernelGGL((k_aggregate<W, true>), dim3(g2), dim3(64 * AGG_WAVES), 0, h->stream, level_in, d_begin, (uint32_t)n_retry, k, log, log_cap,
 				                   h->d_counters, flag_unique, (const uint32_t *)d_retry, (uint32_t *)nullptr, m, (uint32_t)(24 - bits));
 			}
 		}
