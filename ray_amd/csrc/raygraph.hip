@@ -1585,6 +1585,10 @@ static int bloom_partitioned(rg_handle *h, Table &T, uint64_t m_bits, uint64_t k
 	(void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
 	const int grid_items = (int)std::min<uint64_t>((uint64_t)n_cu * 8, (T.cap + 255) / 256);
 	const uint64_t m_inv = (m_bits & (m_bits - 1)) ? (uint64_t)((((unsigned __int128)1) << 64) / m_bits) : 0;  // bloom_mod
+	// dense key array (the sweep's log: every chunk full) -> items made straight into their first-level ranges; sparse
+	// (a vertex table at load <= 0.7) -> items streamed out densely first, then one more partition level
+	const bool fused = (h->cfg.reserved0 & 0x20000) || keys * 5 >= T.cap * 4;  // bit 17 forces it (tests)
+	const uint64_t item_cap = fused ? 8 * keys : 8 * (keys + (uint64_t)grid_items * 4 * ITEM_CHUNK_KEYS);
 	unsigned long long *A = nullptr, *B = nullptr, *d_seg = nullptr, *d_hist = nullptr, *d_begin = nullptr, *d_sums = nullptr;
 	uint32_t *d_tile = nullptr, *d_lost = nullptr;
 	auto cleanup = [&]() {
@@ -1605,7 +1609,7 @@ static int bloom_partitioned(rg_handle *h, Table &T, uint64_t m_bits, uint64_t k
 			return fail(h, e_ == hipErrorOutOfMemory ? RG_ERR_NOMEM : RG_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
 		}                                                                                                   \
 	} while (0)
-	if (pool_alloc(dev, (void **)&A, 8 * keys * 8) != hipSuccess || pool_alloc(dev, (void **)&B, 8 * keys * 8) != hipSuccess) {
+	if (pool_alloc(dev, (void **)&A, item_cap * 8) != hipSuccess || pool_alloc(dev, (void **)&B, 8 * keys * 8) != hipSuccess) {
 		(void)hipGetLastError();
 		cleanup();
 		return RG_OK;
@@ -1620,37 +1624,59 @@ static int bloom_partitioned(rg_handle *h, Table &T, uint64_t m_bits, uint64_t k
 	BTRY(hipMemsetAsync(d_lost, 0, lost_words * sizeof(uint32_t), h->stream));
 	BTRY(hipMemsetAsync(d_hist, 0, 256 * sizeof(unsigned long long), h->stream));
 	BTRY(hipMemsetAsync(h->d_counters + BC_ITEM_CURSOR, 0, 4 * sizeof(unsigned long long), h->stream));
-	// level 0: the digit histogram of all items first, then the items are produced straight into their ranges
-	{
-		ProfScope ps(h, "k_bloom_hist");
-		if (h->W == 1) hipLaunchKernelGGL(k_bloom_hist<1>, dim3(grid_items), dim3(256), 0, h->stream, T.slots, T.cap, m_bits, m_inv, shift1, d_hist);
-		else hipLaunchKernelGGL(k_bloom_hist<2>, dim3(grid_items), dim3(256), 0, h->stream, T.slots, T.cap, m_bits, m_inv, shift1, d_hist);
-		BTRY(hipGetLastError());
-	}
 	unsigned long long *bufs[2] = {A, B};
-	int cur = 0;
-	{
+	int cur = 0, first_level = 0;
+	std::vector<unsigned long long> seg_begin = {0, 0};
+	std::vector<uint32_t> tile_first;
+	if (fused) {
+		// level 0: the digit histogram of all items first, then the items are produced straight into their ranges
+		{
+			ProfScope ps(h, "k_bloom_hist");
+			if (h->W == 1) hipLaunchKernelGGL(k_bloom_hist<1>, dim3(grid_items), dim3(256), 0, h->stream, T.slots, T.cap, m_bits, m_inv, shift1, d_hist);
+			else hipLaunchKernelGGL(k_bloom_hist<2>, dim3(grid_items), dim3(256), 0, h->stream, T.slots, T.cap, m_bits, m_inv, shift1, d_hist);
+			BTRY(hipGetLastError());
+		}
 		hipLaunchKernelGGL(k_scan_local, dim3(1), dim3(256), 0, h->stream, d_hist, d_begin, (uint64_t)256, d_sums);
 		hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(64), 0, h->stream, d_sums, 1u, d_sums + 1);
 		hipLaunchKernelGGL(k_scan_add, dim3(1), dim3(256), 0, h->stream, d_begin, (uint64_t)256, d_sums, d_sums + 1, d_hist);
-		ProfScope ps(h, "k_bloom_scatter_items");
-		const unsigned grid = (unsigned)((T.cap + ITEM_TILE_SLOTS - 1) / ITEM_TILE_SLOTS);
-		if (h->W == 1) hipLaunchKernelGGL(k_bloom_scatter_items<1>, dim3(grid), dim3(256), 0, h->stream, T.slots, T.cap, m_bits, m_inv, shift1, d_hist, bufs[1]);
-		else hipLaunchKernelGGL(k_bloom_scatter_items<2>, dim3(grid), dim3(256), 0, h->stream, T.slots, T.cap, m_bits, m_inv, shift1, d_hist, bufs[1]);
-		BTRY(hipGetLastError());
-		cur = 1;
-	}
-	std::vector<unsigned long long> seg_begin(257);
-	std::vector<uint32_t> tile_first;
-	if (nlevels > 1) {
-		BTRY(hipMemcpyAsync(seg_begin.data(), d_begin, 257 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-		BTRY(hipStreamSynchronize(h->stream));
-		if (seg_begin[256] != 8 * keys) {
-			cleanup();
-			return fail(h, RG_ERR_STATE, "Bloom partition lost items: %llu of %llu", seg_begin[256], (unsigned long long)(8 * keys));
+		{
+			ProfScope ps(h, "k_bloom_scatter_items");
+			const unsigned grid = (unsigned)((T.cap + ITEM_TILE_SLOTS - 1) / ITEM_TILE_SLOTS);
+			if (h->W == 1) hipLaunchKernelGGL(k_bloom_scatter_items<1>, dim3(grid), dim3(256), 0, h->stream, T.slots, T.cap, m_bits, m_inv, shift1, d_hist, bufs[1]);
+			else hipLaunchKernelGGL(k_bloom_scatter_items<2>, dim3(grid), dim3(256), 0, h->stream, T.slots, T.cap, m_bits, m_inv, shift1, d_hist, bufs[1]);
+			BTRY(hipGetLastError());
 		}
+		cur = 1;
+		first_level = 1;
+		if (nlevels > 1) {
+			seg_begin.resize(257);
+			BTRY(hipMemcpyAsync(seg_begin.data(), d_begin, 257 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+			BTRY(hipStreamSynchronize(h->stream));
+			if (seg_begin[256] != 8 * keys) {
+				cleanup();
+				return fail(h, RG_ERR_STATE, "Bloom partition lost items: %llu of %llu", seg_begin[256], (unsigned long long)(8 * keys));
+			}
+		}
+	} else {
+		{
+			ProfScope ps(h, "k_bloom_items");
+			if (h->W == 1) hipLaunchKernelGGL(k_bloom_items<1>, dim3(grid_items), dim3(256), 0, h->stream, T.slots, T.cap, m_bits, A, item_cap, shift1, h->d_counters, d_hist);
+			else hipLaunchKernelGGL(k_bloom_items<2>, dim3(grid_items), dim3(256), 0, h->stream, T.slots, T.cap, m_bits, A, item_cap, shift1, h->d_counters, d_hist);
+			BTRY(hipGetLastError());
+		}
+		const int rc0 = sync_counters(h);
+		if (rc0) {
+			cleanup();
+			return rc0;
+		}
+		if (h->h_counters[BC_ITEM_OVF]) {
+			if (getenv("RG_DEBUG")) fprintf(stderr, "[raygraph] Bloom partition: item buffer overflow, using dense stamps\n");
+			cleanup();
+			return RG_OK;
+		}
+		seg_begin[1] = std::min<uint64_t>(h->h_counters[BC_ITEM_CURSOR], item_cap);
 	}
-	for (int level = 1; level < nlevels; ++level) {
+	for (int level = first_level; level < nlevels; ++level) {
 		const uint32_t S = (uint32_t)seg_begin.size() - 1;
 		const int shift = level == 0 ? shift1 : 48;
 		tile_first.assign(S + 1, 0);

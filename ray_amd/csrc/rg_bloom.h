@@ -7,6 +7,8 @@
 //
 //   k_bloom_hist + k_bloom_scatter_items   8 items (bit index, table slot) per key, produced straight into the
 //                   ranges of the first partition level (histogram first, so nothing is streamed out and read back)
+//                   (dense key arrays: the log of the sweep; sparse ones -- a vertex table -- go through k_bloom_items,
+//                   which streams the items out, and one more k_scatter64 level)
 //   k_scatter64     the second partition level by Bloom region (2^17 bits per region), when there are more than 256 regions
 //   k_bloom_region  one workgroup per region, all in LDS: two bitmaps (touched / touched again);
 //                   only for bits touched more than once are the stamps fetched and the earliest
@@ -27,11 +29,79 @@ static constexpr uint32_t REGION_WORDS = REGION_BITS / 32;  // 4096 words per bi
 static constexpr uint32_t REGION_MULTI_CAP = 4096;          // contested bits a region can rank (32 KB of stamps): 2 workgroups per CU
 static constexpr uint32_t REGION_MULTI_CAP_BIG = 10240;     // fuller filters: 80 KB of stamps, 1 workgroup per CU
 static constexpr uint64_t ITEM_INVALID = ~0ull;
+static constexpr uint32_t ITEM_CHUNK_KEYS = 512;  // keys (x8 items) a wavefront claims at a time (k_bloom_items)
 static constexpr int SCATTER64_TILE = 4096;
 
 enum BloomCounter { BC_ITEM_CURSOR = 24, BC_ITEM_OVF, BC_REGION_OVF };
 
 // item = bit index (33 bits) << 31 | table slot (31 bits)
+// Sparse key arrays (the vertex table of a rank that received its keys from others): the items are streamed out
+// densely, chunk by chunk, and partitioned by k_scatter64 afterwards -- a tile of slots would hold too few keys for
+// k_bloom_scatter_items to write runs.
+template <int W>
+__global__ __launch_bounds__(256) void k_bloom_items(const Slot *__restrict__ tab, uint64_t cap, uint64_t m_bits,
+                                                     unsigned long long *__restrict__ items, uint64_t item_cap, int shift1,
+                                                     unsigned long long *__restrict__ counters, unsigned long long *__restrict__ hist1) {
+	__shared__ uint32_t s_hist[256];
+	const uint32_t lane = threadIdx.x & 63u;
+	s_hist[threadIdx.x] = 0;
+	__syncthreads();
+	uint64_t chunk_base = 0;
+	uint32_t chunk_used = ITEM_CHUNK_KEYS;
+	bool have_chunk = false, dead = false;
+	const uint64_t nwaves = (uint64_t)gridDim.x * 4, wave_id = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+	for (uint64_t base = wave_id * 64; base < cap; base += nwaves * 64) {
+		const uint64_t i = base + lane;
+		Slot v;
+		bool used = false;
+		if (i < cap) {
+			v = tab[i];
+			used = v.k0 != EMPTY;
+		}
+		const unsigned long long ballot = __ballot(used);
+		const uint32_t c = (uint32_t)__popcll(ballot);
+		if (c == 0) continue;
+		// keys that do not fit the current chunk continue in a freshly claimed one (no holes in between)
+		const uint32_t room = have_chunk ? ITEM_CHUNK_KEYS - chunk_used : 0u;
+		uint64_t new_base = 0;
+		if (c > room) {
+			unsigned long long nb = 0;
+			if (lane == 0) nb = atomicAdd(&counters[BC_ITEM_CURSOR], (unsigned long long)ITEM_CHUNK_KEYS * 8);
+			nb = __shfl(nb, 0);
+			if (nb + ITEM_CHUNK_KEYS * 8 > item_cap) {
+				dead = true;
+				if (lane == 0) atomicAdd(&counters[BC_ITEM_OVF], 1ull);
+			}
+			new_base = nb;
+		}
+		if (used && !dead) {
+			const uint32_t idx = (uint32_t)__popcll(ballot & ((1ull << lane) - 1));
+			uint64_t K0, K1;
+			from_internal<W>(v.k0, v.k1, K0, K1);
+			const uint64_t origin = hash2<W>(K0, K1);
+			unsigned long long *dst = (idx < room) ? items + chunk_base + (uint64_t)(chunk_used + idx) * 8
+			                                       : items + new_base + (uint64_t)(idx - room) * 8;
+#pragma unroll
+			for (int j = 0; j < 8; ++j) {
+				const uint64_t b = (origin ^ BLOOM_MAGIC[j]) % m_bits;
+				const unsigned long long item = (b << 31) | i;
+				dst[j] = item;
+				atomicAdd(&s_hist[(item >> shift1) & 255u], 1u);
+			}
+		}
+		if (c > room) {
+			chunk_base = new_base;
+			chunk_used = c - room;
+			have_chunk = true;
+		} else {
+			chunk_used += c;
+		}
+	}
+	if (have_chunk && !dead)
+		for (uint32_t j = chunk_used * 8 + lane; j < ITEM_CHUNK_KEYS * 8; j += 64) items[chunk_base + j] = ITEM_INVALID;
+	__syncthreads();
+	if (s_hist[threadIdx.x]) atomicAdd(&hist1[threadIdx.x], (unsigned long long)s_hist[threadIdx.x]);
+}
 
 // x mod d with d fixed for the launch: inv = floor(2^64 / d) (host), or 0 when d is a power of two.  The estimate
 // q = floor(x * inv / 2^64) is floor(x / d) or one less, so one conditional subtraction settles it -- a 64-bit

@@ -29,13 +29,15 @@ def assert_records_equal(a, b, what=""):
 
 
 def gpu_vs_oracle(ro, packed, offsets, lengths, k, bloom_bits=None, W=None, purge=True, batches=1, tmpdir=None,
-                  sweeps=(1 | 16 | (8 << 8), 1 | 32 | (12 << 8), 1 | 16 | (19 << 8), 1 | 16 | (12 << 8) | 0x10000, 2 | 32, 2 | 16)):
+                  sweeps=(1 | 16 | (8 << 8) | 0x20000, 1 | 32 | (12 << 8), 1 | 16 | (19 << 8), 1 | 16 | (12 << 8) | 0x10000, 2 | 32, 2 | 16 | 0x20000)):
     """single-rank parity through the C ABI, once per sweep implementation: the partitioned sweep
     (super-k-mer records + LDS aggregation) with 2^8, 2^12 and 2^19 buckets = one, two and three partition
     levels (records cut by k_superkmers_lanes where it applies; flag 0x10000 forces k_superkmers), and the direct sweep
     (one table upsert per occurrence); flag 16 asks for the Bloom-region
     partitioning (it falls back by itself when the filter is too full), flag 32 for the dense first-touch
-    stamps; returns the oracle outputs"""
+    stamps; flag 0x20000 makes the Bloom items straight into their first partition level even
+    when the key array is sparse (k_bloom_scatter_items instead of k_bloom_items + one more k_scatter64 level);
+    returns the oracle outputs"""
     want = oracle_run(ro, packed, offsets, lengths, k, 1, bloom_bits, W, purge)
     for sweep in sweeps:
         want["builder"] = _gpu_check(ro, want, packed, offsets, lengths, k, bloom_bits, W, purge, batches, tmpdir, sweep)
