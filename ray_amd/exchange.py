@@ -29,6 +29,17 @@ def _staged(group):
     return dist.get_backend(group) == "gloo"
 
 
+def _a2a(recv, src, out_counts, in_counts, unit, group, async_op=False):
+    """all-to-all(v) of `unit`-byte items held in uint8 tensors.  Items of a multiple of 8 bytes travel as int64
+    elements, so that no per-peer element count comes near 2^31 (3.2 GB of entries to one peer at N = 2)."""
+    if unit % 8 == 0 and recv.numel() % 8 == 0 and src.numel() % 8 == 0 and recv.storage_offset() % 8 == 0 and src.storage_offset() % 8 == 0:
+        q = unit // 8
+        return dist.all_to_all_single(recv.view(torch.int64), src.view(torch.int64), output_split_sizes=[c * q for c in out_counts],
+                                      input_split_sizes=[c * q for c in in_counts], group=group, async_op=async_op)
+    return dist.all_to_all_single(recv, src, output_split_sizes=[c * unit for c in out_counts],
+                                  input_split_sizes=[c * unit for c in in_counts], group=group, async_op=async_op)
+
+
 def exchange_owner_buckets(engine, group=None, device="cuda"):
     """all-to-all(v) of the per-owner buckets; returns (entries sent, entries received)."""
     size = engine.size
@@ -47,9 +58,7 @@ def exchange_owner_buckets(engine, group=None, device="cuda"):
     n_recv = sum(recv_list)
     recv = torch.empty(max(1, n_recv) * RG_ENTRY_BYTES, dtype=torch.uint8, device=xdev)
     src = send[: total * RG_ENTRY_BYTES].cpu() if staged else send[: total * RG_ENTRY_BYTES]
-    dist.all_to_all_single(recv[: n_recv * RG_ENTRY_BYTES], src,
-                           output_split_sizes=[c * RG_ENTRY_BYTES for c in recv_list],
-                           input_split_sizes=[c * RG_ENTRY_BYTES for c in counts], group=group)
+    _a2a(recv[: n_recv * RG_ENTRY_BYTES], src, recv_list, counts, RG_ENTRY_BYTES, group)
     if staged:
         recv = recv.to(device)
     if str(device) != "cpu":
@@ -69,8 +78,7 @@ def _all_to_all_bytes(send, send_counts, unit, group, device, staged):
     n_send, n_recv = sum(send_counts), sum(recv_counts)
     recv = torch.empty(max(1, n_recv) * unit, dtype=torch.uint8, device=xdev)
     src = send[: n_send * unit].cpu() if staged else send[: n_send * unit]
-    dist.all_to_all_single(recv[: n_recv * unit], src, output_split_sizes=[c * unit for c in recv_counts],
-                           input_split_sizes=[c * unit for c in send_counts], group=group)
+    _a2a(recv[: n_recv * unit], src, recv_counts, send_counts, unit, group)
     if staged:
         recv = recv.to(device)
     return recv, recv_counts
@@ -110,8 +118,7 @@ def exchange_records(engine, group=None, device="cuda", parts=1):
             recv = torch.empty(max(1, n_recv) * unit, dtype=torch.uint8, device=xdev)[: n_recv * unit]
             in_big = False
         src = send[: total * unit].cpu() if staged else send[: total * unit]
-        work = dist.all_to_all_single(recv, src, output_split_sizes=[c * unit for c in recv_counts],
-                                      input_split_sizes=[c * unit for c in counts], group=group, async_op=True)
+        work = _a2a(recv, src, recv_counts, counts, unit, group, async_op=True)
         pending.append((work, src, recv, in_big))
     for work, _, _, _ in pending:
         work.wait()
