@@ -748,19 +748,22 @@ __global__ __launch_bounds__(256) void k_scan_add(unsigned long long *__restrict
 //     bases + length + neighbour flags, value = multiplicity and smallest (read id, position).  Equal
 //     records produce equal k-mers with equal edge bits, and the smallest stamp of k-mer i over them is
 //     (smallest record stamp) + i, so expanding one representative with a weight is exact.
-//  2. a table of distinct k-mers, fed by expanding every distinct record once (lane per record,
-//     rolling k-mer / reverse complement), then appended to the log.
+//  2. a table of distinct k-mers, fed by expanding every distinct record once (its k-mers laid out
+//     flat, a lane per k-mer), then appended to the log.
 // Slots claimed since the last flush are remembered in lists, so a flush costs O(distinct keys).  Log
 // space is reserved LOG_CHUNK entries at a time per wavefront; unused entries of a chunk are EMPTY.
 // Neither table can overfill: their fill is checked at points between which at most 64 keys arrive
 // (the spill path of the k-mer table is for safety only).  The records of the next round (or of the
 // next bucket's first round) are loaded before the current round is processed.
 static constexpr uint32_t AGG_SLOTS = 256;
-// the table is declared too small for a (sub-pass of a) bucket when more than AGG_FLUSH of its 256 slots are
-// claimed at a check point; up to 64 keys can arrive between two checks, the few that might not find a slot any
-// more take the spill path
-static constexpr uint32_t AGG_LIMIT = 215;
-static constexpr uint32_t AGG_FLUSH = 200;
+// The k-mer table takes up to 64 new keys per round of the expansion (one lane per k-mer), so a round may only start
+// with AGG_SLOTS - 64 slots claimed at most: a batch of records whose k-mers fit below AGG_LIMIT all together runs
+// unchecked, otherwise the fill is looked at after every round and the table is declared too small for the (sub-pass
+// of the) bucket above AGG_FLUSH.  With that no k-mer can fail to find a slot; should one all the same, the attempt
+// is dropped like an overfull one (only the last-resort mode of partial flushes writes such a k-mer to the log on
+// its own: a k-mer written before the attempt is dropped would be counted again by the retry).
+static constexpr uint32_t AGG_LIMIT = 190;
+static constexpr uint32_t AGG_FLUSH = 190;
 static constexpr uint32_t RT_SLOTS = 128;
 static constexpr uint32_t RT_FLUSH = RT_SLOTS * 3 / 4 - 64;
 static constexpr uint32_t LOG_CHUNK = 512;
@@ -786,7 +789,7 @@ struct RecTable {
 	uint32_t tag[RT_SLOTS];  // header bits 16..30: length, neighbour flags, minimizer offset
 	uint32_t cnt[RT_SLOTS];
 	uint16_t list[RT_SLOTS];
-	uint32_t fill, rmax, rsum;
+	uint32_t fill;
 };
 
 __device__ __forceinline__ void wave_sync() {  // orders this wavefront's LDS traffic; no s_barrier
@@ -955,110 +958,107 @@ __global__ __launch_bounds__(64 * AGG_WAVES) void k_aggregate(const Rec<W> *__re
 	// expand: every distinct record of the record table goes through the k-mer table once, weighted; of its k-mers
 	// only those of sub-pass `sub` (of `nsub`, a power of two) are taken.  Returns false when the k-mer table would
 	// overfill: the caller then drops the attempt.
+	// The k-mers of a batch of 64 distinct records are laid out flat, one *lane per k-mer*: records hold 1 to w k-mers
+	// (the ones cut short by a read end are the many), so a lane per record walking its own k-mers would leave most
+	// lanes idle for most of the w iterations.  Lane t of a round finds its record by a binary search over the prefix
+	// sums of the lengths (held in registers, read through the lane crossbar) and takes its k-mer and the two
+	// neighbour bases straight out of the record's words.
 	auto expand = [&](uint32_t sub, uint32_t nsub) -> bool {
 		const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)R.fill);
 		if (n == 0) return true;
 		for (uint32_t e0 = 0; e0 < n; e0 += 64) {
-			if (lane == 0) {
-				R.rmax = 0;
-				R.rsum = 0;
-			}
-			wave_sync();
 			const uint32_t e = e0 + lane;
-			uint32_t len = 0, hasL = 0, hasR = 0, prev = 0, prev_valid = 0, weight = 0;
-			uint64_t bw[NB], f0 = 0, f1 = 0, r0 = 0, r1 = 0, stamp0 = 0, upcoming = 0;
-#pragma unroll
-			for (int i = 0; i < NB; ++i) bw[i] = 0;
+			uint32_t rlen = 0, rsl = 0, rweight = 0;
+			uint64_t rstamp = 0;
 			if (e < n) {
-				const uint32_t sl = R.list[e];
-#pragma unroll
-				for (int i = 0; i < NB; ++i) bw[i] = R.w[i][sl];
-				const uint32_t tag = R.tag[sl];
-				weight = R.cnt[sl];
-				stamp0 = R.stamp[sl];
-				R.fp[sl] = 0;
-				R.cnt[sl] = 0;
-				R.stamp[sl] = INF_STAMP;
-				len = (tag & 63u) + 1;
-				hasL = (tag >> 6) & 1u;
-				hasR = (tag >> 7) & 1u;
-				f0 = rec_ext<W>(bw, hasL) & mask0;
-				if (W == 2 && k > 32) f1 = rec_ext<W>(bw, hasL + 32) & mask1;
-				revcomp<W>(f0, f1, k, r0, r1);
-				prev = hasL ? (uint32_t)bw[0] & 3u : 0;
-				prev_valid = hasL;
-				if (W == 1) upcoming = rec_ext<W>(bw, hasL + (uint32_t)k);  // the bases after the first k-mer (<= 18 are used)
-				atomicMax(&R.rmax, len);
-				atomicAdd(&R.rsum, len);
+				rsl = R.list[e];
+				rlen = (R.tag[rsl] & 63u) + 1;
+				rweight = R.cnt[rsl];
+				rstamp = R.stamp[rsl];
+				R.fp[rsl] = 0;  // the slot is free again (its words and tag stay readable until it is claimed anew)
+				R.cnt[rsl] = 0;
+				R.stamp[rsl] = INF_STAMP;
 			}
-			wave_sync();
-			const uint32_t rmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)R.rmax);
-			const bool checked = (uint32_t)__builtin_amdgcn_readfirstlane((int)(T.fill + R.rsum)) > AGG_LIMIT;  // else no overfill possible
-			auto step = [&](uint32_t i) {
-				const bool has_next = (i + 1 < len) || hasR;
-				uint32_t nb;
-				if (W == 1) {
-					nb = (uint32_t)upcoming & 3u;
-					upcoming >>= 2;
-				} else {
-					nb = rec_base<W>(bw, hasL + i + (uint32_t)k);
+			uint32_t incl = rlen;  // inclusive prefix sums of the lengths
+#pragma unroll
+			for (int d = 1; d < 64; d <<= 1) {
+				const uint32_t o = __shfl_up(incl, d);
+				if (lane >= (uint32_t)d) incl += o;
+			}
+			const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+			const uint32_t rpre = incl - rlen;
+			const bool checked = (uint32_t)__builtin_amdgcn_readfirstlane((int)T.fill) + total > AGG_LIMIT;  // else no overfill possible
+			for (uint32_t t0 = 0; t0 < total; t0 += 64) {
+				const uint32_t t = t0 + lane;
+				// owner = number of records whose prefix sum is <= t (all lanes take part in the shuffles)
+				uint32_t own = 0;
+#pragma unroll
+				for (uint32_t st = 32; st; st >>= 1) {
+					const uint32_t v = (uint32_t)__shfl((int)incl, (int)(own + st - 1));
+					if (v <= t) own += st;
 				}
-				const bool use_rc = kmer_less<W>(r0, r1, f0, f1);
-				uint32_t em = 0;
-				if (prev_valid) em = 1u << (use_rc ? 7u - prev : prev);
-				if (has_next) em |= 1u << (use_rc ? 3u - nb : 4u + nb);
-				uint64_t i0, i1;
-				to_internal<W>(use_rc ? r0 : f0, use_rc ? r1 : f1, i0, i1);
-				const uint32_t hx = agg_hash<W>(i0, i1);
-				if (SLOW && ((hx >> 12) & (nsub - 1)) != sub) {
-					// another sub-pass owns this k-mer
-				} else if (!lds_upsert<W>(T, hx, i0, i1, stamp0 + i, em, weight)) {
-					// LDS table full: this k-mer goes to the log on its own
-					unsigned long long g = atomicAdd(&counters[PC_LOG_CURSOR], 1ull);
-					if (g < log_cap) {
-						Slot en;
-						en.k0 = i0;
-						en.k1 = (W == 2) ? i1 : EMPTY;
-						en.stamp = stamp0 + i;
-						en.meta = (uint64_t)weight | ((uint64_t)em << PEND_SHIFT);
-						log[g] = en;
-					} else {
-						atomicAdd(&counters[PC_LOG_OVF], 1ull);
+				own = own < 63u ? own : 63u;  // lanes past the last k-mer: any record will do, they do nothing
+				const uint32_t sl = (uint32_t)__shfl((int)rsl, (int)own);
+				const uint32_t i = t - (uint32_t)__shfl((int)rpre, (int)own);
+				const uint32_t weight = (uint32_t)__shfl((int)rweight, (int)own);
+				const uint64_t stamp0 = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(rstamp >> 32), (int)own) << 32) | (uint32_t)__shfl((int)(uint32_t)rstamp, (int)own);
+				if (t < total) {
+					uint64_t bw[NB];
+#pragma unroll
+					for (int q = 0; q < NB; ++q) bw[q] = R.w[q][sl];
+					const uint32_t tag = R.tag[sl];
+					const uint32_t len = (tag & 63u) + 1, hasL = (tag >> 6) & 1u, hasR = (tag >> 7) & 1u;
+					const uint32_t pos = hasL + i;  // the k-mer's first base in the record
+					uint64_t f0, f1 = 0, r0, r1;
+					f0 = rec_ext<W>(bw, pos) & mask0;
+					if (W == 2 && k > 32) f1 = rec_ext<W>(bw, pos + 32) & mask1;
+					revcomp<W>(f0, f1, k, r0, r1);
+					const bool use_rc = kmer_less<W>(r0, r1, f0, f1);
+					uint32_t em = 0;
+					if (pos > 0) {  // a k-mer precedes this one in its read
+						const uint32_t prev = rec_base<W>(bw, pos - 1);
+						em = 1u << (use_rc ? 7u - prev : prev);
 					}
-					atomicAdd(&counters[PC_LDS_SPILL], 1ull);
-					T.spilled = 1;
-				}
-				// roll to the next k-mer
-				prev = (uint32_t)f0 & 3u;
-				prev_valid = 1;
-				if (W == 1) {
-					f0 = (f0 >> 2) | ((uint64_t)nb << (2 * (k - 1)));
-					r0 = ((r0 << 2) | (uint64_t)(3u - nb)) & mask0;
-				} else {
-					f0 = (f0 >> 2) | (f1 << 62);
-					if (k > 32) {
-						f1 = (f1 >> 2) | ((uint64_t)nb << (2 * (k - 1) - 64));
-						r1 = ((r1 << 2) | (r0 >> 62)) & mask1;
-						r0 = (r0 << 2) | (uint64_t)(3u - nb);
-					} else {
-						f0 |= (uint64_t)nb << (2 * (k - 1));
-						r0 = ((r0 << 2) | (uint64_t)(3u - nb)) & mask0;
+					if (i + 1 < len || hasR) {
+						const uint32_t nb = rec_base<W>(bw, pos + (uint32_t)k);
+						em |= 1u << (use_rc ? 3u - nb : 4u + nb);
+					}
+					uint64_t i0, i1;
+					to_internal<W>(use_rc ? r0 : f0, use_rc ? r1 : f1, i0, i1);
+					const uint32_t hx = agg_hash<W>(i0, i1);
+					if (SLOW && ((hx >> 12) & (nsub - 1)) != sub) {
+						// another sub-pass owns this k-mer
+					} else if (!lds_upsert<W>(T, hx, i0, i1, stamp0 + i, em, weight)) {
+						if (!partial_flushes) {
+							T.spilled = 2;  // no slot left: the attempt is void
+						} else {
+						// LDS table full: this k-mer goes to the log on its own
+						unsigned long long g = atomicAdd(&counters[PC_LOG_CURSOR], 1ull);
+						if (g < log_cap) {
+							Slot en;
+							en.k0 = i0;
+							en.k1 = (W == 2) ? i1 : EMPTY;
+							en.stamp = stamp0 + i;
+							en.meta = (uint64_t)weight | ((uint64_t)em << PEND_SHIFT);
+							log[g] = en;
+						} else {
+							atomicAdd(&counters[PC_LOG_OVF], 1ull);
+						}
+						atomicAdd(&counters[PC_LDS_SPILL], 1ull);
+						T.spilled = 1;
+						}
 					}
 				}
-			};
-			if (!checked) {
-				for (uint32_t i = 0; i < len; ++i) step(i);
-				wave_sync();
-			} else {
-				for (uint32_t i = 0; i < rmax; ++i) {
-					if (i < len) step(i);
+				if (checked) {
 					wave_sync();
+					if (!partial_flushes && (uint32_t)__builtin_amdgcn_readfirstlane((int)T.spilled) == 2) return false;
 					if ((uint32_t)__builtin_amdgcn_readfirstlane((int)T.fill) > AGG_FLUSH) {
 						if (!partial_flushes) return false;
 						flush();
 					}
 				}
 			}
+			wave_sync();
 		}
 		if (lane == 0) R.fill = 0;
 		wave_sync();
