@@ -29,6 +29,15 @@ def test_graph_matches_oracle(oracle, tmp_path, k, read_len, bloom, error):
     gpu_vs_oracle(oracle, packed, offsets, lengths, k, bloom_bits=bloom, tmpdir=str(tmp_path))
 
 
+def test_long_records_fill_the_bucket_tables(oracle):
+    """k = 63: records of up to 49 k-mers, expanded 64 k-mers per round, fill the 256-slot LDS table of a bucket within a
+    few rounds; buckets that do not fit are dropped unwritten and redone in sub-passes -- nothing of a dropped attempt
+    may stay in the log (a k-mer written on its own before the drop was once counted twice)"""
+    packed, offsets, lengths = make_reads_numpy(genome=15000, read_len=150, n_reads=2500, seed=65, error=0.015)
+    gpu_vs_oracle(oracle, packed, offsets, lengths, 63, bloom_bits=0, sweeps=(1 | 16 | (16 << 8), 1 | 16 | (8 << 8)))
+    gpu_vs_oracle(oracle, packed, offsets, lengths, 63, bloom_bits=90000, sweeps=(1 | 16 | (16 << 8),))
+
+
 def test_two_word_layout_with_short_k(oracle):
     """a MAXKMERLENGTH=64 build running -k 31 hashes with the two-word formula (Kmer.cpp:287-293)"""
     packed, offsets, lengths = make_reads_numpy(genome=8000, read_len=80, n_reads=2500, seed=5, error=0.01)
