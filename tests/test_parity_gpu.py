@@ -188,6 +188,17 @@ def test_long_reads_many_steps(oracle):
     gpu_vs_oracle(oracle, p, o, l, 31, bloom_bits=5000, sweeps=(1 | 16 | (8 << 8), 2 | 32))
 
 
+def test_reads_up_to_the_lane_kernel_limit(oracle):
+    """ragged reads of up to 1024 bases, the longest k_superkmers_lanes takes: 64 reads of very different lengths walk
+    in lock step (lanes idle behind the longest), dozens of 16-base refills per read, record positions near 1000;
+    the wavefront-per-read kernel cuts the same input for comparison (flag 0x10000)"""
+    packed, offsets, lengths = make_reads_numpy(genome=30000, read_len=1024, n_reads=700, seed=12, error=0.01, ragged=True)
+    assert lengths.max() > 1000 and (lengths < 31).any()
+    gpu_vs_oracle(oracle, packed, offsets, lengths, 31, bloom_bits=300000, sweeps=(1 | 16 | (10 << 8), 1 | 16 | (10 << 8) | 0x10000))
+    gpu_vs_oracle(oracle, packed, offsets, lengths, 21, bloom_bits=0, sweeps=(1 | (9 << 8),))
+    gpu_vs_oracle(oracle, packed, offsets, lengths, 37, bloom_bits=None, sweeps=(1 | 16 | (9 << 8),))   # two-word keys, w = 23
+
+
 def test_log_overflow_is_redone_with_a_full_log(oracle):
     """inputs of little redundancy overflow the log of distinct k-mers (sized for a quarter of the occurrences): the
     aggregation then runs again with one slot per occurrence; flag 64 makes the first log one chunk long"""
