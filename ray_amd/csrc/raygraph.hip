@@ -1343,7 +1343,7 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 		PTRY(hipGetLastError());
 		{
 			ProfScope ps(h, "k_scatter");
-			hipLaunchKernelGGL(k_scatter<W>, dim3((unsigned)ntiles), dim3(256), 0, h->stream, level_in, m, S, d_seg, d_tile, shift, db, d_hist,
+			hipLaunchKernelGGL(k_scatter<W>, dim3((unsigned)ntiles), dim3(SCATTER_THREADS), 0, h->stream, level_in, m, S, d_seg, d_tile, shift, db, d_hist,
 			                   buf[cur ^ 1], 0u);
 		}
 		PTRY(hipGetLastError());
@@ -1555,7 +1555,7 @@ static int export_records_t(rg_handle *h, void *d_out) {
 	if (e == hipSuccess) e = hipMemcpyAsync(d_cur, cursors.data(), 256 * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream);
 	if (e == hipSuccess) {
 		ProfScope ps(h, "k_scatter");
-		hipLaunchKernelGGL(k_scatter<W>, dim3((unsigned)ntiles), dim3(256), 0, h->stream, (const Rec<W> *)h->rec_buf, m, 1u, d_seg, d_tile, 0, 8, d_cur,
+		hipLaunchKernelGGL(k_scatter<W>, dim3((unsigned)ntiles), dim3(SCATTER_THREADS), 0, h->stream, (const Rec<W> *)h->rec_buf, m, 1u, d_seg, d_tile, 0, 8, d_cur,
 		                   (Rec<W> *)d_out, size);
 		e = hipGetLastError();
 	}
@@ -1642,8 +1642,8 @@ static int bloom_partitioned(rg_handle *h, Table &T, uint64_t m_bits, uint64_t k
 		{
 			ProfScope ps(h, "k_bloom_scatter_items");
 			const unsigned grid = (unsigned)((T.cap + ITEM_TILE_SLOTS - 1) / ITEM_TILE_SLOTS);
-			if (h->W == 1) hipLaunchKernelGGL(k_bloom_scatter_items<1>, dim3(grid), dim3(256), 0, h->stream, T.slots, T.cap, m_bits, m_inv, shift1, d_hist, bufs[1]);
-			else hipLaunchKernelGGL(k_bloom_scatter_items<2>, dim3(grid), dim3(256), 0, h->stream, T.slots, T.cap, m_bits, m_inv, shift1, d_hist, bufs[1]);
+			if (h->W == 1) hipLaunchKernelGGL(k_bloom_scatter_items<1>, dim3(grid), dim3(SCATTER_THREADS), 0, h->stream, T.slots, T.cap, m_bits, m_inv, shift1, d_hist, bufs[1]);
+			else hipLaunchKernelGGL(k_bloom_scatter_items<2>, dim3(grid), dim3(SCATTER_THREADS), 0, h->stream, T.slots, T.cap, m_bits, m_inv, shift1, d_hist, bufs[1]);
 			BTRY(hipGetLastError());
 		}
 		cur = 1;
@@ -1698,7 +1698,7 @@ static int bloom_partitioned(rg_handle *h, Table &T, uint64_t m_bits, uint64_t k
 		hipLaunchKernelGGL(k_scan_local, dim3(nblk), dim3(256), 0, h->stream, d_hist, d_begin, nout, d_sums);
 		hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(64), 0, h->stream, d_sums, nblk, d_sums + nblk);
 		hipLaunchKernelGGL(k_scan_add, dim3(nblk), dim3(256), 0, h->stream, d_begin, nout, d_sums, d_sums + nblk, d_hist);
-		hipLaunchKernelGGL(k_scatter64, dim3((unsigned)ntiles), dim3(256), 0, h->stream, bufs[cur], S, d_seg, d_tile, shift, d_hist, bufs[cur ^ 1]);
+		hipLaunchKernelGGL(k_scatter64, dim3((unsigned)ntiles), dim3(SCATTER_THREADS), 0, h->stream, bufs[cur], S, d_seg, d_tile, shift, d_hist, bufs[cur ^ 1]);
 		BTRY(hipGetLastError());
 		cur ^= 1;
 		if (level + 1 < nlevels) {

@@ -141,22 +141,22 @@ __global__ __launch_bounds__(256) void k_bloom_hist(const Slot *__restrict__ tab
 // runs at the tile's cursor claims: k_scatter64's scheme with the items computed instead of loaded.
 static constexpr int ITEM_TILE_SLOTS = 512;
 template <int W>
-__global__ __launch_bounds__(256) void k_bloom_scatter_items(const Slot *__restrict__ tab, uint64_t cap, uint64_t m_bits, uint64_t m_inv,
+__global__ __launch_bounds__(SCATTER_THREADS) void k_bloom_scatter_items(const Slot *__restrict__ tab, uint64_t cap, uint64_t m_bits, uint64_t m_inv,
                                                              int shift1, unsigned long long *__restrict__ cursors,
                                                              unsigned long long *__restrict__ out) {
-	constexpr int KEYS = ITEM_TILE_SLOTS / 256, PER = 8 * KEYS;
+	constexpr int KEYS = ITEM_TILE_SLOTS / SCATTER_THREADS, PER = 8 * KEYS;
 	__shared__ unsigned long long s_item[8 * ITEM_TILE_SLOTS];
 	__shared__ uint8_t s_dig[8 * ITEM_TILE_SLOTS];
 	__shared__ uint32_t s_cnt[256], s_off[256], s_scan[8];
 	__shared__ unsigned long long s_gbase[256];
 	const uint64_t base = (uint64_t)blockIdx.x * ITEM_TILE_SLOTS;
-	s_cnt[threadIdx.x] = 0;
+	if (threadIdx.x < 256) s_cnt[threadIdx.x] = 0;
 	__syncthreads();
 	unsigned long long mine[PER];
 	uint32_t dr[PER];  // digit << 16 | rank inside the tile
 #pragma unroll
 	for (int q = 0; q < KEYS; ++q) {
-		const uint64_t i = base + threadIdx.x + (uint64_t)q * 256;
+		const uint64_t i = base + threadIdx.x + (uint64_t)q * SCATTER_THREADS;
 		uint64_t k0 = EMPTY, k1 = EMPTY;
 		if (i < cap) {
 			k0 = tab[i].k0;
@@ -179,7 +179,8 @@ __global__ __launch_bounds__(256) void k_bloom_scatter_items(const Slot *__restr
 	}
 	__syncthreads();
 	{
-		const uint32_t c = s_cnt[threadIdx.x];
+		const bool low = threadIdx.x < 256;  // one thread per digit
+		const uint32_t c = low ? s_cnt[threadIdx.x] : 0u;
 		const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
 		uint32_t incl = c;
 #pragma unroll
@@ -187,17 +188,19 @@ __global__ __launch_bounds__(256) void k_bloom_scatter_items(const Slot *__restr
 			const uint32_t o = __shfl_up(incl, d);
 			if (lane >= (uint32_t)d) incl += o;
 		}
-		if (lane == 63) s_scan[wv] = incl;
+		if (lane == 63 && low) s_scan[wv] = incl;
 		__syncthreads();
 		uint32_t before = 0;
 #pragma unroll
 		for (uint32_t q = 0; q < 4; ++q)
 			if (q < wv) before += s_scan[q];
-		s_off[threadIdx.x] = before + incl - c;
-		if (threadIdx.x == 255) s_scan[4] = before + incl;
-		unsigned long long g = 0;
-		if (c) g = atomicAdd(&cursors[threadIdx.x], (unsigned long long)c);
-		s_gbase[threadIdx.x] = g;
+		if (low) {
+			s_off[threadIdx.x] = before + incl - c;
+			if (threadIdx.x == 255) s_scan[4] = before + incl;
+			unsigned long long g = 0;
+			if (c) g = atomicAdd(&cursors[threadIdx.x], (unsigned long long)c);
+			s_gbase[threadIdx.x] = g;
+		}
 	}
 	__syncthreads();
 	const uint32_t total = s_scan[4];
@@ -209,7 +212,7 @@ __global__ __launch_bounds__(256) void k_bloom_scatter_items(const Slot *__restr
 			s_dig[pos] = (uint8_t)(dr[j] >> 16);
 		}
 	__syncthreads();
-	for (uint32_t i = threadIdx.x; i < total; i += 256) {
+	for (uint32_t i = threadIdx.x; i < total; i += SCATTER_THREADS) {
 		const uint32_t d = s_dig[i];
 		out[s_gbase[d] + (i - s_off[d])] = s_item[i];
 	}
@@ -244,11 +247,11 @@ __global__ __launch_bounds__(256) void k_hist64(const unsigned long long *__rest
 }
 
 // one partition level of 8-byte items: same scheme as k_scatter (tile-local counting sort in LDS)
-__global__ __launch_bounds__(256) void k_scatter64(const unsigned long long *__restrict__ in, uint32_t S,
+__global__ __launch_bounds__(SCATTER_THREADS) void k_scatter64(const unsigned long long *__restrict__ in, uint32_t S,
                                                    const unsigned long long *__restrict__ seg_begin,
                                                    const uint32_t *__restrict__ tile_first, int shift,
                                                    unsigned long long *__restrict__ cursors, unsigned long long *__restrict__ out) {
-	constexpr int PER = SCATTER64_TILE / 256;
+	constexpr int PER = SCATTER64_TILE / SCATTER_THREADS;
 	__shared__ unsigned long long s_item[SCATTER64_TILE];
 	__shared__ uint8_t s_dig[SCATTER64_TILE];
 	__shared__ uint32_t s_cnt[256], s_off[256], s_scan[256];
@@ -256,13 +259,13 @@ __global__ __launch_bounds__(256) void k_scatter64(const unsigned long long *__r
 	const uint32_t seg = find_seg64(tile_first, S, blockIdx.x);
 	const uint64_t begin = seg_begin[seg] + (uint64_t)(blockIdx.x - tile_first[seg]) * SCATTER64_TILE;
 	const uint64_t end = begin + SCATTER64_TILE < seg_begin[seg + 1] ? begin + SCATTER64_TILE : seg_begin[seg + 1];
-	s_cnt[threadIdx.x] = 0;
+	if (threadIdx.x < 256) s_cnt[threadIdx.x] = 0;
 	__syncthreads();
 	unsigned long long mine[PER];
 	uint32_t dig[PER], rank[PER];
 #pragma unroll
 	for (int j = 0; j < PER; ++j) {
-		const uint64_t i = begin + threadIdx.x + (uint64_t)j * 256;
+		const uint64_t i = begin + threadIdx.x + (uint64_t)j * SCATTER_THREADS;
 		dig[j] = 0xFFFFFFFFu;
 		rank[j] = 0;
 		mine[j] = ITEM_INVALID;
@@ -276,7 +279,8 @@ __global__ __launch_bounds__(256) void k_scatter64(const unsigned long long *__r
 	}
 	__syncthreads();
 	{
-		const uint32_t c = s_cnt[threadIdx.x];
+		const bool low = threadIdx.x < 256;  // one thread per digit
+		const uint32_t c = low ? s_cnt[threadIdx.x] : 0u;
 		const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
 		uint32_t incl = c;
 #pragma unroll
@@ -284,17 +288,19 @@ __global__ __launch_bounds__(256) void k_scatter64(const unsigned long long *__r
 			const uint32_t o = __shfl_up(incl, d);
 			if (lane >= (uint32_t)d) incl += o;
 		}
-		if (lane == 63) s_scan[wv] = incl;
+		if (lane == 63 && low) s_scan[wv] = incl;
 		__syncthreads();
 		uint32_t before = 0;
 #pragma unroll
 		for (uint32_t q = 0; q < 4; ++q)
 			if (q < wv) before += s_scan[q];
-		s_off[threadIdx.x] = before + incl - c;
-		if (threadIdx.x == 255) s_scan[4] = before + incl;
-		unsigned long long g = 0;
-		if (c) g = atomicAdd(&cursors[((uint64_t)seg << 8) + threadIdx.x], (unsigned long long)c);
-		s_gbase[threadIdx.x] = g;
+		if (low) {
+			s_off[threadIdx.x] = before + incl - c;
+			if (threadIdx.x == 255) s_scan[4] = before + incl;
+			unsigned long long g = 0;
+			if (c) g = atomicAdd(&cursors[((uint64_t)seg << 8) + threadIdx.x], (unsigned long long)c);
+			s_gbase[threadIdx.x] = g;
+		}
 	}
 	__syncthreads();
 	const uint32_t total = s_scan[4];
@@ -306,7 +312,7 @@ __global__ __launch_bounds__(256) void k_scatter64(const unsigned long long *__r
 			s_dig[pos] = (uint8_t)dig[j];
 		}
 	__syncthreads();
-	for (uint32_t i = threadIdx.x; i < total; i += 256) {
+	for (uint32_t i = threadIdx.x; i < total; i += SCATTER_THREADS) {
 		const uint32_t d = s_dig[i];
 		out[s_gbase[d] + (i - s_off[d])] = s_item[i];
 	}

@@ -579,6 +579,7 @@ __global__ __launch_bounds__(256) void k_superkmers_lanes(const uint64_t *__rest
 // segment (tile_first[s] = first tile of segment s).  digit = (bucket24 >> shift) & (2^dbits - 1);
 // the records of segment s with digit d go to the range that starts at cursors[(s << dbits) + d].
 static constexpr int SCATTER_TILE = 2048;
+static constexpr int SCATTER_THREADS = 512;  // threads of a scatter workgroup: 4 records each (256 threads x 8: 23-25 ms for the three levels on C2, 512 x 4: 20.5-22)
 
 __device__ __forceinline__ uint32_t find_segment(const uint32_t *__restrict__ tile_first, uint32_t S, uint32_t tile) {
 	uint32_t lo = 0, hi = S;  // largest s with tile_first[s] <= tile
@@ -591,12 +592,12 @@ __device__ __forceinline__ uint32_t find_segment(const uint32_t *__restrict__ ti
 }
 
 template <int W>
-__global__ __launch_bounds__(256) void k_scatter(const Rec<W> *__restrict__ in, int m, uint32_t S,
+__global__ __launch_bounds__(SCATTER_THREADS) void k_scatter(const Rec<W> *__restrict__ in, int m, uint32_t S,
                                                  const unsigned long long *__restrict__ seg_begin,
                                                  const uint32_t *__restrict__ tile_first, int shift, int dbits,
                                                  unsigned long long *__restrict__ cursors, Rec<W> *__restrict__ out, uint32_t modulo) {
 	// modulo != 0: the digit is bucket % modulo (destination rank of the record exchange) instead of bits of the bucket
-	constexpr int NB = 2 * W, PER = SCATTER_TILE / 256;
+	constexpr int NB = 2 * W, PER = SCATTER_TILE / SCATTER_THREADS;
 	__shared__ Rec<W> s_rec[SCATTER_TILE];
 	__shared__ uint8_t s_dig[SCATTER_TILE];
 	__shared__ uint32_t s_cnt[256], s_off[256];
@@ -606,13 +607,13 @@ __global__ __launch_bounds__(256) void k_scatter(const Rec<W> *__restrict__ in, 
 	const uint64_t begin = seg_begin[seg] + (uint64_t)(blockIdx.x - tile_first[seg]) * SCATTER_TILE;
 	const uint64_t end = begin + SCATTER_TILE < seg_begin[seg + 1] ? begin + SCATTER_TILE : seg_begin[seg + 1];
 	const uint32_t dmask = (1u << dbits) - 1;
-	s_cnt[threadIdx.x] = 0;
+	if (threadIdx.x < 256) s_cnt[threadIdx.x] = 0;
 	__syncthreads();
 	Rec<W> mine[PER];
 	uint32_t dig[PER], rank[PER];
 #pragma unroll
 	for (int j = 0; j < PER; ++j) {
-		uint64_t i = begin + threadIdx.x + (uint64_t)j * 256;
+		uint64_t i = begin + threadIdx.x + (uint64_t)j * SCATTER_THREADS;
 		dig[j] = 0xFFFFFFFFu;
 		rank[j] = 0;
 		if (i < end) {
@@ -628,7 +629,8 @@ __global__ __launch_bounds__(256) void k_scatter(const Rec<W> *__restrict__ in, 
 	// exclusive scan of the 256 digit counts (shuffles inside each wavefront, one barrier across the four) and one
 	// cursor claim per non-empty digit
 	{
-		const uint32_t c = s_cnt[threadIdx.x];
+		const bool low = threadIdx.x < 256;  // one thread per digit
+		const uint32_t c = low ? s_cnt[threadIdx.x] : 0u;
 		const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
 		uint32_t incl = c;
 #pragma unroll
@@ -636,17 +638,19 @@ __global__ __launch_bounds__(256) void k_scatter(const Rec<W> *__restrict__ in, 
 			const uint32_t o = __shfl_up(incl, d);
 			if (lane >= (uint32_t)d) incl += o;
 		}
-		if (lane == 63) s_scan[wv] = incl;
+		if (lane == 63 && low) s_scan[wv] = incl;
 		__syncthreads();
 		uint32_t before = 0;
 #pragma unroll
 		for (uint32_t q = 0; q < 4; ++q)
 			if (q < wv) before += s_scan[q];
-		s_off[threadIdx.x] = before + incl - c;
-		if (threadIdx.x == 255) s_scan[4] = before + incl;
-		unsigned long long g = 0;
-		if (c) g = atomicAdd(&cursors[((uint64_t)seg << dbits) + threadIdx.x], (unsigned long long)c);
-		s_gbase[threadIdx.x] = g;
+		if (low) {
+			s_off[threadIdx.x] = before + incl - c;
+			if (threadIdx.x == 255) s_scan[4] = before + incl;
+			unsigned long long g = 0;
+			if (c) g = atomicAdd(&cursors[((uint64_t)seg << dbits) + threadIdx.x], (unsigned long long)c);
+			s_gbase[threadIdx.x] = g;
+		}
 	}
 	__syncthreads();
 	const uint32_t total = s_scan[4];
@@ -658,7 +662,7 @@ __global__ __launch_bounds__(256) void k_scatter(const Rec<W> *__restrict__ in, 
 			s_dig[pos] = (uint8_t)dig[j];
 		}
 	__syncthreads();
-	for (uint32_t i = threadIdx.x; i < total; i += 256) {
+	for (uint32_t i = threadIdx.x; i < total; i += SCATTER_THREADS) {
 		uint32_t d = s_dig[i];
 		out[s_gbase[d] + (i - s_off[d])] = s_rec[i];
 	}
