@@ -1383,6 +1383,52 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 			cleanup();
 			return RG_OK;
 		}
+		// Before the first attempt a sample of the buckets (the bucket number is a hash: any range is a fair sample) is
+		// aggregated alone, overflowing buckets included, and the log sized from what it produced: an input of little
+		// redundancy (errors in most reads) then gets its larger log at once instead of losing a whole aggregation to
+		// find out.  Costs 1/256 of the aggregation; bit 18 of reserved0 runs it on small inputs too and always resizes (tests).
+		const bool force_probe = (h->cfg.reserved0 & 0x40000) != 0;
+		if (attempt == 0 && !(h->cfg.reserved0 & 64) && (NBUCK >= (1u << 16) || force_probe)) {
+			const uint32_t P = force_probe ? std::max<uint32_t>((uint32_t)NBUCK / 4, 1u) : (uint32_t)NBUCK / 256;
+			bool fine = hipMemsetAsync(h->d_counters + PC_LOG_CURSOR, 0, 6 * sizeof(unsigned long long), h->stream) == hipSuccess;
+			if (fine) {
+				ProfScope ps(h, "k_aggregate_probe");
+				const unsigned g1 = (unsigned)std::min<uint64_t>((P + AGG_WAVES - 1) / AGG_WAVES, (uint64_t)agg_grid);
+				hipLaunchKernelGGL((k_aggregate<W, false>), dim3(g1), dim3(64 * AGG_WAVES), 0, h->stream, level_in, d_begin, P, k, log, log_cap,
+				                   h->d_counters, flag_unique, (const uint32_t *)nullptr, d_retry, m, (uint32_t)(24 - bits));
+				fine = hipGetLastError() == hipSuccess && sync_counters(h) == RG_OK;
+				const uint64_t n_retry = fine ? h->h_counters[PC_AGG_RETRY] : 0;
+				if (fine && n_retry && !h->h_counters[PC_LOG_OVF] && h->h_counters[PC_LOG_CURSOR] + n_retry * (uint64_t)AGG_LIMIT <= log_cap) {
+					const unsigned g2 = (unsigned)std::min<uint64_t>((n_retry + AGG_WAVES - 1) / AGG_WAVES, (uint64_t)agg_grid);
+					hipLaunchKernelGGL((k_aggregate<W, true>), dim3(g2), dim3(64 * AGG_WAVES), 0, h->stream, level_in, d_begin, (uint32_t)n_retry, k, log, log_cap,
+					                   h->d_counters, flag_unique, (const uint32_t *)d_retry, (uint32_t *)nullptr, m, (uint32_t)(24 - bits));
+					fine = hipGetLastError() == hipSuccess && sync_counters(h) == RG_OK;
+				} else if (n_retry) {
+					fine = false;  // the sample alone does not fit: the attempt below finds out and the log doubles
+				}
+			}
+			if (fine && !h->h_counters[PC_LOG_OVF]) {
+				const double per_bucket = (double)h->h_counters[PC_LOG_KEYS] / (double)P;
+				const uint64_t proj = std::min<uint64_t>(occ_bound, (uint64_t)(per_bucket * (double)NBUCK * 1.10) + (1ull << 16));
+				if (getenv("RG_DEBUG"))
+					fprintf(stderr, "[raygraph] log probe: %llu keys in %u of %llu buckets -> %llu entries expected, log holds %llu\n",
+					        (unsigned long long)h->h_counters[PC_LOG_KEYS], P, (unsigned long long)NBUCK, (unsigned long long)proj,
+					        (unsigned long long)(log_cap - log_slack));
+				if (proj + log_slack > log_cap || force_probe) {
+					pool_free(dev, log);
+					log_cap = proj + log_slack;
+					if (pool_alloc(dev, (void **)&log, log_cap * sizeof(Slot)) != hipSuccess) {
+						(void)hipGetLastError();
+						log = nullptr;
+						pool_free(dev, d_retry);
+						cleanup();
+						return RG_OK;
+					}
+				}
+			} else {
+				(void)hipGetLastError();
+			}
+		}
 		bool too_small = false;
 		hipError_t e0 = hipMemsetAsync(h->d_counters + PC_LOG_CURSOR, 0, 6 * sizeof(unsigned long long), h->stream);
 		if (e0 == hipSuccess) {

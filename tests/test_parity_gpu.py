@@ -205,3 +205,16 @@ def test_log_overflow_is_redone_with_a_full_log(oracle):
     packed, offsets, lengths = make_reads_numpy(genome=200000, read_len=100, n_reads=3000, seed=8, error=0.02)
     want = gpu_vs_oracle(oracle, packed, offsets, lengths, 31, bloom_bits=None, sweeps=(1 | 16 | 64 | (10 << 8), 1 | 16 | (10 << 8)))
     assert want["builder"].stats()["log_entries"] > 512
+
+
+def test_log_sized_from_a_sample_of_the_buckets(oracle):
+    """before the first aggregation a sample of the buckets is aggregated alone and the log sized from it (flag
+    0x40000 runs that on small inputs and always resizes): same result with an input of little redundancy, where the
+    projection is what the log holds, with a redundant one, and with buckets that overflow the LDS table (few
+    buckets, k = 63), whose second launch is part of the sample"""
+    packed, offsets, lengths = make_reads_numpy(genome=200000, read_len=100, n_reads=3000, seed=8, error=0.02)
+    gpu_vs_oracle(oracle, packed, offsets, lengths, 31, bloom_bits=None, sweeps=(1 | 16 | 0x40000 | (10 << 8), 1 | 32 | 0x40000 | (12 << 8)))
+    packed, offsets, lengths = make_reads_numpy(genome=4000, read_len=100, n_reads=4000, seed=9, error=0.0)
+    gpu_vs_oracle(oracle, packed, offsets, lengths, 31, bloom_bits=None, sweeps=(1 | 16 | 0x40000 | (8 << 8),))
+    packed, offsets, lengths = make_reads_numpy(genome=60000, read_len=150, n_reads=4000, seed=10, error=0.01)
+    gpu_vs_oracle(oracle, packed, offsets, lengths, 63, bloom_bits=None, sweeps=(1 | 16 | 0x40000 | (4 << 8),))
