@@ -41,6 +41,7 @@ enum Counter {
 	C_OVF,          // histogram overflow entries
 	C_FILL_LOCAL,   // claimed slots (local aggregation table)
 	C_EXPORT,       // export cursor
+	C_ADOPT_BAD,    // received entries that are not marked unique (rg_merge_entries)
 	C_NUM = 32
 };
 
@@ -1019,6 +1020,7 @@ struct rg_handle {
 	uint64_t log_keys = 0;               // entries of the last sweep's log
 	Slot *pending_log = nullptr;         // size == 1: the sweep's log of distinct k-mers, admitted before it is inserted
 	uint64_t pending_n = 0, pending_keys = 0;
+	bool merge_started = false;          // rg_merge_entries has been called with entries
 	void *rec_buf = nullptr;             // rg_records_local .. rg_export_records: super-k-mer records of the local reads
 	uint64_t rec_slots = 0;              // slots of rec_buf in use (holes included)
 	std::vector<uint64_t> rec_counts;    // valid records per destination rank
@@ -1807,6 +1809,22 @@ static int bloom_partitioned(rg_handle *h, Table &T, uint64_t m_bits, uint64_t k
 	return RG_OK;
 }
 
+// rg_merge_entries, first call into an empty partition: the received entries are copied into a log of the library's own
+// and those that do not carry the unique mark (or hold no key) are counted; none = the copy can be admitted as a log
+__global__ __launch_bounds__(256) void k_adopt_entries(const Slot *__restrict__ in, uint64_t n, Slot *__restrict__ out,
+                                                       unsigned long long *__restrict__ counters) {
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	uint32_t bad = 0;
+	for (; i < n; i += stride) {
+		const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(&in[i].k0), b = *reinterpret_cast<const ulonglong2 *>(&in[i].stamp);
+		if (a.x == EMPTY || !(b.y & LOG_UNIQUE)) bad++;
+		*reinterpret_cast<ulonglong2 *>(&out[i].k0) = a;
+		*reinterpret_cast<ulonglong2 *>(&out[i].stamp) = b;
+	}
+	if (bad) atomicAdd(&counters[C_ADOPT_BAD], (unsigned long long)bad);
+}
+
 // size == 1 with a pending log and a caller that wants the table of all candidates before admission (the owner
 // exchange calls): the classic merge of the whole log
 static int materialize_pending_log(rg_handle *h) {
@@ -2216,6 +2234,41 @@ int rg_merge_entries(rg_handle *h, const void *d_entries, uint64_t n_entries) {
 	}
 	if (n_entries == 0) return RG_OK;
 	if (!d_entries) return fail(h, RG_ERR_ARG, "null entries");
+	// Record route: every key was aggregated by exactly one rank, so what the owner receives is a log of distinct
+	// k-mers like the one a single rank makes for itself (the entries carry the unique mark).  If the whole partition
+	// arrives in one call, it is kept as that log: admission runs on it and only admitted vertices reach the table
+	// (rg_resolve_admission).  A further call, or entries without the mark, take the classic merge.
+	if (!h->tab.slots && !h->pending_log && !h->merge_started && n_entries < (1ull << 31) && !(h->cfg.reserved0 & 0x80000)) {
+		h->merge_started = true;
+		Slot *copy = nullptr;
+		Slot first;  // entries of the entry route carry no mark: one look spares them the copy
+		HIP_TRY(h, hipMemcpyAsync(&first, d_entries, sizeof(Slot), hipMemcpyDeviceToHost, h->stream));
+		HIP_TRY(h, hipStreamSynchronize(h->stream));
+		if ((first.meta & LOG_UNIQUE) && pool_alloc(h->cfg.device, (void **)&copy, n_entries * sizeof(Slot)) == hipSuccess) {
+			hipError_t e = hipMemsetAsync(h->d_counters + C_ADOPT_BAD, 0, sizeof(unsigned long long), h->stream);
+			if (e == hipSuccess) {
+				ProfScope ps(h, "k_adopt_entries");
+				hipLaunchKernelGGL(k_adopt_entries, dim3(grid_for(n_entries)), dim3(BLOCK), 0, h->stream, (const Slot *)d_entries, n_entries, copy, h->d_counters);
+				e = hipGetLastError();
+			}
+			int rc0 = e == hipSuccess ? sync_counters(h) : fail(h, RG_ERR_HIP, "k_adopt_entries: %s", hipGetErrorString(e));
+			if (rc0) {
+				pool_free(h->cfg.device, copy);
+				return rc0;
+			}
+			if (h->h_counters[C_ADOPT_BAD] == 0) {
+				h->pending_log = copy;
+				h->pending_n = h->pending_keys = n_entries;
+				if (getenv("RG_DEBUG")) fprintf(stderr, "[raygraph] rank %d: %llu received entries kept as a log of distinct k-mers\n", h->cfg.rank, (unsigned long long)n_entries);
+				return RG_OK;  // synchronised: the caller may reuse d_entries
+			}
+			pool_free(h->cfg.device, copy);
+		} else {
+			(void)hipGetLastError();
+		}
+	}
+	h->merge_started = true;
+	if (int rcm = materialize_pending_log(h)) return rcm;  // a second call: what was kept as a log goes to the table first
 	int rc = table_reserve(h, h->tab, n_entries, C_FILL);
 	if (rc) return rc;
 	ProfScope ps(h, "k_merge");

@@ -12,10 +12,13 @@ from ray_amd.synth import make_reads_numpy
 pytestmark = pytest.mark.gpu
 
 
-def run_ranks(packed, offsets, lengths, k, nranks, bloom, W=0, sweep=0, route="entries", parts=1):
+def run_ranks(packed, offsets, lengths, k, nranks, bloom, W=0, sweep=0, route="entries", parts=1, one_merge=False):
     """route "entries": every rank aggregates its own reads, then the entries go to their owners;
     route "records": the super-k-mer records go to the rank that aggregates their bucket first (the preferred
-    multi-GPU route), then the entries go to their owners"""
+    multi-GPU route), then the entries go to their owners.
+    one_merge: an owner gets everything it receives in ONE rg_merge_entries call, as exchange_owner_buckets delivers it
+    (record route: the entries are unique and are kept as a log that is admitted before anything is inserted);
+    otherwise one call per source rank (the first is kept as a log, the second sends it to the table: classic merge)"""
     import torch
     import ray_amd
     from ray_amd.graph import RG_BLOOM_DEFAULT, RG_ENTRY_BYTES
@@ -56,10 +59,18 @@ def run_ranks(packed, offsets, lengths, k, nranks, bloom, W=0, sweep=0, route="e
         torch.cuda.synchronize()
         sends.append((counts, buf))
     for dst, b in enumerate(builders):
+        got = []
         for counts, buf in sends:
             start = sum(counts[:dst])
             part = buf[start * RG_ENTRY_BYTES:(start + counts[dst]) * RG_ENTRY_BYTES]
-            b.merge_entries(part.data_ptr(), counts[dst])
+            if one_merge:
+                got.append(part)
+            else:
+                b.merge_entries(part.data_ptr(), counts[dst])
+        if one_merge:
+            allgot = torch.cat(got)
+            torch.cuda.synchronize()
+            b.merge_entries(allgot.data_ptr() if allgot.numel() else 0, allgot.numel() // RG_ENTRY_BYTES)
     for r, b in enumerate(builders):
         first, last = partition_reads(n, r, nranks)
         b.resolve_admission(last - first)
@@ -72,9 +83,10 @@ def test_multirank_matches_oracle(oracle, k, nranks, bloom):
     packed, offsets, lengths = make_reads_numpy(genome=15000, read_len=100 if k < 63 else 150, n_reads=5001,
                                                 seed=k + nranks, error=0.015)
     want = oracle_run(oracle, packed, offsets, lengths, k, nranks, bloom)
-    for sweep, route, parts in ((1 | 16 | (17 << 8), "entries", 1), (2 | 32, "entries", 1), (1 | 16 | (10 << 8), "records", 1),
-                                (1 | 16 | (10 << 8), "records", 3), (2 | 32, "records", 1)):
-        builders = run_ranks(packed, offsets, lengths, k, nranks, bloom, sweep=sweep, route=route, parts=parts)
+    for sweep, route, parts, one in ((1 | 16 | (17 << 8), "entries", 1, False), (2 | 32, "entries", 1, True), (1 | 16 | (10 << 8), "records", 1, True),
+                                     (1 | 32 | (10 << 8), "records", 1, True), (1 | 16 | (10 << 8) | 0x80000, "records", 1, True),
+                                     (1 | 16 | (10 << 8), "records", 3, False), (2 | 32, "records", 1, False)):
+        builders = run_ranks(packed, offsets, lengths, k, nranks, bloom, sweep=sweep, route=route, parts=parts, one_merge=one)
         check_ranks(builders, want, route)
     # RAY_SLAVE_MODE_PURGE_NULL_EDGES across ranks: keys to the owners, one-byte answers back
     want["graph"].purge_edges()
