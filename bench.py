@@ -276,8 +276,9 @@ def main():
             "k_count": occ0 * (L / (4.0 * n_per_read) + Kb + 8),            # read bits + key compare + count RMW
             "k_superkmers": occ0 * L / (4.0 * n_per_read) + recs0 * rec_bytes,  # read bits in, records out
             "k_superkmers_lanes": occ0 * L / (4.0 * n_per_read) + recs0 * rec_bytes,  # same bytes, a lane per read
-            "k_scatter": st["partition_levels"] * 2 * recs0 * rec_bytes,     # records in + out, per level
+            "k_scatter": st["partition_levels"] * 2 * recs0 * rec_bytes + max(0, st["partition_levels"] - 1) * recs0,  # records in + out per level, + the next level's digit byte
             "k_level_hist": max(0, st["partition_levels"] - 1) * recs0 * rec_bytes,
+            "k_level_hist_side": max(0, st["partition_levels"] - 1) * recs0,     # one digit byte per record and level
             "k_aggregate": recs0 * rec_bytes + st["log_entries"] * 32,       # records in, entries out
             "k_merge": st["log_entries"] * 32 + cand0 * 32,                  # entries in, slots written
             "k_bloom_items": (st["log_entries"] if "k_insert_admitted" in kprof else st["table_slots"]) * 32 + cand0 * 64,  # scan in, 8 items of 8 B per key out

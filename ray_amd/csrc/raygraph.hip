@@ -1245,8 +1245,11 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	Rec<W> *buf[2] = {nullptr, nullptr};
 	unsigned long long *d_seg = nullptr, *d_hist = nullptr, *d_begin = nullptr, *d_sums = nullptr;
 	uint32_t *d_tile = nullptr;
+	uint8_t *d_side = nullptr;  // next-level digit of every record of the current level's output
+	bool side_valid = false;
 	Slot *log = nullptr;
 	auto cleanup = [&]() {
+		pool_free(dev, d_side);
 		pool_free(dev, buf[0]);
 		pool_free(dev, buf[1]);
 		pool_free(dev, d_seg);
@@ -1330,7 +1333,17 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 		PTRY(hipMemcpyAsync(d_seg, seg_begin.data(), (S + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
 		PTRY(hipMemcpyAsync(d_tile, tile_first.data(), (S + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
 		const uint64_t nout = (uint64_t)S << db;  // buckets after this level
-		if (level > 0 || ext) {  // level 0's histogram came out of k_superkmers
+		const bool have_next = level < 2 && dbits[level + 1] > 0;
+		if (have_next && !d_side && pool_alloc(dev, (void **)&d_side, valid) != hipSuccess) {
+			(void)hipGetLastError();  // no room for the side bytes: the next histogram reads the records
+			d_side = nullptr;
+		}
+		if (level > 0 && side_valid) {  // the previous level's scatter left this level's digits, one byte per record
+			PTRY(hipMemsetAsync(d_hist, 0, nout * sizeof(unsigned long long), h->stream));
+			ProfScope ps(h, "k_level_hist_side");
+			hipLaunchKernelGGL(k_level_hist_side, dim3((unsigned)ntiles), dim3(256), 0, h->stream, d_side, S, d_seg, d_tile, db, d_hist);
+			PTRY(hipGetLastError());
+		} else if (level > 0 || ext) {  // level 0's histogram came out of k_superkmers
 			PTRY(hipMemsetAsync(d_hist, 0, nout * sizeof(unsigned long long), h->stream));
 			ProfScope ps(h, "k_level_hist");
 			hipLaunchKernelGGL(k_level_hist<W>, dim3((unsigned)ntiles), dim3(256), 0, h->stream, level_in, m, S, d_seg, d_tile, shift, db, d_hist);
@@ -1345,8 +1358,11 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 		PTRY(hipGetLastError());
 		{
 			ProfScope ps(h, "k_scatter");
+			uint8_t *side_out = (have_next && !(h->cfg.reserved0 & 0x100000)) ? d_side : nullptr;  // bit 20: histograms read the records (tests)
+			const int ndb = have_next ? dbits[level + 1] : 0;
 			hipLaunchKernelGGL(k_scatter<W>, dim3((unsigned)ntiles), dim3(SCATTER_THREADS), 0, h->stream, level_in, m, S, d_seg, d_tile, shift, db, d_hist,
-			                   buf[cur ^ 1], 0u);
+			                   buf[cur ^ 1], 0u, side_out, shift - ndb, (1u << ndb) - 1u);
+			side_valid = side_out != nullptr;
 		}
 		PTRY(hipGetLastError());
 		used_bits += db;
@@ -1604,7 +1620,7 @@ static int export_records_t(rg_handle *h, void *d_out) {
 	if (e == hipSuccess) {
 		ProfScope ps(h, "k_scatter");
 		hipLaunchKernelGGL(k_scatter<W>, dim3((unsigned)ntiles), dim3(SCATTER_THREADS), 0, h->stream, (const Rec<W> *)h->rec_buf, m, 1u, d_seg, d_tile, 0, 8, d_cur,
-		                   (Rec<W> *)d_out, size);
+		                   (Rec<W> *)d_out, size, (uint8_t *)nullptr, 0, 0u);
 		e = hipGetLastError();
 	}
 	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);

@@ -595,11 +595,14 @@ template <int W>
 __global__ __launch_bounds__(SCATTER_THREADS) void k_scatter(const Rec<W> *__restrict__ in, int m, uint32_t S,
                                                  const unsigned long long *__restrict__ seg_begin,
                                                  const uint32_t *__restrict__ tile_first, int shift, int dbits,
-                                                 unsigned long long *__restrict__ cursors, Rec<W> *__restrict__ out, uint32_t modulo) {
+                                                 unsigned long long *__restrict__ cursors, Rec<W> *__restrict__ out, uint32_t modulo,
+                                                 uint8_t *__restrict__ side, int next_shift, uint32_t next_mask) {
 	// modulo != 0: the digit is bucket % modulo (destination rank of the record exchange) instead of bits of the bucket
+	// side != null: side[i] = the NEXT level's digit of out[i], so that the next level's histogram reads one byte per
+	// record instead of the record (k_level_hist_side)
 	constexpr int NB = 2 * W, PER = SCATTER_TILE / SCATTER_THREADS;
 	__shared__ Rec<W> s_rec[SCATTER_TILE];
-	__shared__ uint8_t s_dig[SCATTER_TILE];
+	__shared__ uint8_t s_dig[SCATTER_TILE], s_next[SCATTER_TILE];
 	__shared__ uint32_t s_cnt[256], s_off[256];
 	__shared__ unsigned long long s_gbase[256];
 	__shared__ uint32_t s_scan[256];
@@ -610,16 +613,18 @@ __global__ __launch_bounds__(SCATTER_THREADS) void k_scatter(const Rec<W> *__res
 	if (threadIdx.x < 256) s_cnt[threadIdx.x] = 0;
 	__syncthreads();
 	Rec<W> mine[PER];
-	uint32_t dig[PER], rank[PER];
+	uint32_t dig[PER], rank[PER], nxt[PER];
 #pragma unroll
 	for (int j = 0; j < PER; ++j) {
 		uint64_t i = begin + threadIdx.x + (uint64_t)j * SCATTER_THREADS;
 		dig[j] = 0xFFFFFFFFu;
 		rank[j] = 0;
+		nxt[j] = 0;
 		if (i < end) {
 			mine[j] = in[i];
 			if (mine[j].w[NB] != REC_INVALID) {
 				const uint32_t bk = rec_bucket<W>(mine[j], m);
+				nxt[j] = (bk >> next_shift) & next_mask;
 				dig[j] = modulo ? bk % modulo : (bk >> shift) & dmask;
 				rank[j] = atomicAdd(&s_cnt[dig[j]], 1u);
 			}
@@ -660,12 +665,42 @@ __global__ __launch_bounds__(SCATTER_THREADS) void k_scatter(const Rec<W> *__res
 			uint32_t pos = s_off[dig[j]] + rank[j];
 			s_rec[pos] = mine[j];
 			s_dig[pos] = (uint8_t)dig[j];
+			s_next[pos] = (uint8_t)nxt[j];
 		}
 	__syncthreads();
 	for (uint32_t i = threadIdx.x; i < total; i += SCATTER_THREADS) {
 		uint32_t d = s_dig[i];
-		out[s_gbase[d] + (i - s_off[d])] = s_rec[i];
+		const unsigned long long dst = s_gbase[d] + (i - s_off[d]);
+		out[dst] = s_rec[i];
+		if (side) side[dst] = s_next[i];
 	}
+}
+
+// digit histogram of one level from the side bytes the previous level's scatter wrote: hist[(seg << dbits) + digit]
+__global__ __launch_bounds__(256) void k_level_hist_side(const uint8_t *__restrict__ side, uint32_t S,
+                                                         const unsigned long long *__restrict__ seg_begin,
+                                                         const uint32_t *__restrict__ tile_first, int dbits,
+                                                         unsigned long long *__restrict__ hist) {
+	__shared__ uint32_t s_cnt[256];
+	const uint32_t seg = find_segment(tile_first, S, blockIdx.x);
+	const uint64_t begin = seg_begin[seg] + (uint64_t)(blockIdx.x - tile_first[seg]) * SCATTER_TILE;
+	const uint64_t end = begin + SCATTER_TILE < seg_begin[seg + 1] ? begin + SCATTER_TILE : seg_begin[seg + 1];
+	s_cnt[threadIdx.x] = 0;
+	__syncthreads();
+	{  // a tile is 2048 bytes: eight per thread in one load (any alignment), the last ones of a segment one by one
+		const uint64_t i = begin + (uint64_t)threadIdx.x * 8;
+		if (i + 8 <= end) {
+			uint64_t v;
+			__builtin_memcpy(&v, side + i, 8);
+#pragma unroll
+			for (int b = 0; b < 8; ++b) atomicAdd(&s_cnt[(uint32_t)(v >> (8 * b)) & 255u], 1u);
+		} else {
+			for (uint64_t j = i; j < end; ++j) atomicAdd(&s_cnt[side[j]], 1u);
+		}
+	}
+	__syncthreads();
+	if (threadIdx.x < (1u << dbits) && s_cnt[threadIdx.x])
+		atomicAdd(&hist[((uint64_t)seg << dbits) + threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
 }
 
 // digit histogram of one level: hist[(seg << dbits) + digit]

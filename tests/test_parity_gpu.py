@@ -218,3 +218,13 @@ def test_log_sized_from_a_sample_of_the_buckets(oracle):
     gpu_vs_oracle(oracle, packed, offsets, lengths, 31, bloom_bits=None, sweeps=(1 | 16 | 0x40000 | (8 << 8),))
     packed, offsets, lengths = make_reads_numpy(genome=60000, read_len=150, n_reads=4000, seed=10, error=0.01)
     gpu_vs_oracle(oracle, packed, offsets, lengths, 63, bloom_bits=None, sweeps=(1 | 16 | 0x40000 | (4 << 8),))
+
+
+def test_level_histograms_from_digit_bytes_and_from_records(oracle):
+    """a partition level's scatter leaves the next level's digit of every record in a byte array, which that level's
+    histogram reads instead of the records; flag 0x100000 keeps the histograms on the records: same buckets, same
+    result, with two and three levels, one- and two-word keys, ragged reads (segments that end inside a tile)"""
+    packed, offsets, lengths = make_reads_numpy(genome=30000, read_len=120, n_reads=6000, seed=14, error=0.01, ragged=True)
+    gpu_vs_oracle(oracle, packed, offsets, lengths, 31, bloom_bits=None,
+                  sweeps=(1 | 16 | (19 << 8), 1 | 16 | (19 << 8) | 0x100000, 1 | 16 | (13 << 8), 1 | 16 | (13 << 8) | 0x100000))
+    gpu_vs_oracle(oracle, packed, offsets, lengths, 63, bloom_bits=200000, sweeps=(1 | 16 | (18 << 8), 1 | 16 | (18 << 8) | 0x100000))
