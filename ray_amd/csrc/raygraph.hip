@@ -1341,7 +1341,7 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 		if (level > 0 && side_valid) {  // the previous level's scatter left this level's digits, one byte per record
 			PTRY(hipMemsetAsync(d_hist, 0, nout * sizeof(unsigned long long), h->stream));
 			ProfScope ps(h, "k_level_hist_side");
-			hipLaunchKernelGGL(k_level_hist_side, dim3((unsigned)ntiles), dim3(256), 0, h->stream, d_side, S, d_seg, d_tile, db, d_hist);
+			hipLaunchKernelGGL(k_level_hist_side<SCATTER_TILE>, dim3((unsigned)ntiles), dim3(256), 0, h->stream, d_side, S, d_seg, d_tile, db, d_hist);
 			PTRY(hipGetLastError());
 		} else if (level > 0 || ext) {  // level 0's histogram came out of k_superkmers
 			PTRY(hipMemsetAsync(d_hist, 0, nout * sizeof(unsigned long long), h->stream));
@@ -1655,9 +1655,11 @@ static int bloom_partitioned(rg_handle *h, Table &T, uint64_t m_bits, uint64_t k
 	const uint64_t item_cap = fused ? 8 * keys : 8 * (keys + (uint64_t)grid_items * 4 * ITEM_CHUNK_KEYS);
 	unsigned long long *A = nullptr, *B = nullptr, *d_seg = nullptr, *d_hist = nullptr, *d_begin = nullptr, *d_sums = nullptr;
 	uint32_t *d_tile = nullptr, *d_lost = nullptr;
+	uint8_t *d_side = nullptr;
 	auto cleanup = [&]() {
 		pool_free(dev, A);
 		pool_free(dev, B);
+		pool_free(dev, d_side);
 		pool_free(dev, d_seg);
 		pool_free(dev, d_hist);
 		pool_free(dev, d_begin);
@@ -1706,8 +1708,13 @@ static int bloom_partitioned(rg_handle *h, Table &T, uint64_t m_bits, uint64_t k
 		{
 			ProfScope ps(h, "k_bloom_scatter_items");
 			const unsigned grid = (unsigned)((T.cap + ITEM_TILE_SLOTS - 1) / ITEM_TILE_SLOTS);
-			if (h->W == 1) hipLaunchKernelGGL(k_bloom_scatter_items<1>, dim3(grid), dim3(SCATTER_THREADS), 0, h->stream, T.slots, T.cap, m_bits, m_inv, shift1, d_hist, bufs[1]);
-			else hipLaunchKernelGGL(k_bloom_scatter_items<2>, dim3(grid), dim3(SCATTER_THREADS), 0, h->stream, T.slots, T.cap, m_bits, m_inv, shift1, d_hist, bufs[1]);
+			// the second level's digits, one byte per item, for its histogram (reserved0 bit 20: it reads the items)
+			if (nlevels > 1 && !(h->cfg.reserved0 & 0x100000) && pool_alloc(dev, (void **)&d_side, 8 * keys) != hipSuccess) {
+				(void)hipGetLastError();
+				d_side = nullptr;
+			}
+			if (h->W == 1) hipLaunchKernelGGL(k_bloom_scatter_items<1>, dim3(grid), dim3(SCATTER_THREADS), 0, h->stream, T.slots, T.cap, m_bits, m_inv, shift1, d_hist, bufs[1], d_side, 48);
+			else hipLaunchKernelGGL(k_bloom_scatter_items<2>, dim3(grid), dim3(SCATTER_THREADS), 0, h->stream, T.slots, T.cap, m_bits, m_inv, shift1, d_hist, bufs[1], d_side, 48);
 			BTRY(hipGetLastError());
 		}
 		cur = 1;
@@ -1756,7 +1763,8 @@ static int bloom_partitioned(rg_handle *h, Table &T, uint64_t m_bits, uint64_t k
 		ProfScope ps(h, "k_scatter64");
 		if (level > 0) {
 			BTRY(hipMemsetAsync(d_hist, 0, nout * sizeof(unsigned long long), h->stream));
-			hipLaunchKernelGGL(k_hist64, dim3((unsigned)ntiles), dim3(256), 0, h->stream, bufs[cur], S, d_seg, d_tile, shift, d_hist);
+			if (level == 1 && d_side) hipLaunchKernelGGL(k_level_hist_side<SCATTER64_TILE>, dim3((unsigned)ntiles), dim3(256), 0, h->stream, d_side, S, d_seg, d_tile, 8, d_hist);
+			else hipLaunchKernelGGL(k_hist64, dim3((unsigned)ntiles), dim3(256), 0, h->stream, bufs[cur], S, d_seg, d_tile, shift, d_hist);
 		}
 		const uint32_t nblk = (uint32_t)((nout + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK);
 		hipLaunchKernelGGL(k_scan_local, dim3(nblk), dim3(256), 0, h->stream, d_hist, d_begin, nout, d_sums);

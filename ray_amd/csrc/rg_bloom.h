@@ -143,7 +143,8 @@ static constexpr int ITEM_TILE_SLOTS = 512;
 template <int W>
 __global__ __launch_bounds__(SCATTER_THREADS) void k_bloom_scatter_items(const Slot *__restrict__ tab, uint64_t cap, uint64_t m_bits, uint64_t m_inv,
                                                              int shift1, unsigned long long *__restrict__ cursors,
-                                                             unsigned long long *__restrict__ out) {
+                                                             unsigned long long *__restrict__ out, uint8_t *__restrict__ side, int shift2) {
+	// side != null: side[i] = the second level's digit of out[i] (k_level_hist_side reads it instead of the items)
 	constexpr int KEYS = ITEM_TILE_SLOTS / SCATTER_THREADS, PER = 8 * KEYS;
 	__shared__ unsigned long long s_item[8 * ITEM_TILE_SLOTS];
 	__shared__ uint8_t s_dig[8 * ITEM_TILE_SLOTS];
@@ -214,7 +215,9 @@ __global__ __launch_bounds__(SCATTER_THREADS) void k_bloom_scatter_items(const S
 	__syncthreads();
 	for (uint32_t i = threadIdx.x; i < total; i += SCATTER_THREADS) {
 		const uint32_t d = s_dig[i];
-		out[s_gbase[d] + (i - s_off[d])] = s_item[i];
+		const unsigned long long item = s_item[i], dst = s_gbase[d] + (i - s_off[d]);
+		out[dst] = item;
+		if (side) side[dst] = (uint8_t)((item >> shift2) & 255u);
 	}
 }
 

@@ -677,18 +677,21 @@ __global__ __launch_bounds__(SCATTER_THREADS) void k_scatter(const Rec<W> *__res
 }
 
 // digit histogram of one level from the side bytes the previous level's scatter wrote: hist[(seg << dbits) + digit]
+// (TILE = the tile of the scatter kernel that follows: SCATTER_TILE records, or SCATTER64_TILE Bloom items)
+template <int TILE>
 __global__ __launch_bounds__(256) void k_level_hist_side(const uint8_t *__restrict__ side, uint32_t S,
                                                          const unsigned long long *__restrict__ seg_begin,
                                                          const uint32_t *__restrict__ tile_first, int dbits,
                                                          unsigned long long *__restrict__ hist) {
 	__shared__ uint32_t s_cnt[256];
 	const uint32_t seg = find_segment(tile_first, S, blockIdx.x);
-	const uint64_t begin = seg_begin[seg] + (uint64_t)(blockIdx.x - tile_first[seg]) * SCATTER_TILE;
-	const uint64_t end = begin + SCATTER_TILE < seg_begin[seg + 1] ? begin + SCATTER_TILE : seg_begin[seg + 1];
+	const uint64_t begin = seg_begin[seg] + (uint64_t)(blockIdx.x - tile_first[seg]) * TILE;
+	const uint64_t end = begin + TILE < seg_begin[seg + 1] ? begin + TILE : seg_begin[seg + 1];
 	s_cnt[threadIdx.x] = 0;
 	__syncthreads();
-	{  // a tile is 2048 bytes: eight per thread in one load (any alignment), the last ones of a segment one by one
-		const uint64_t i = begin + (uint64_t)threadIdx.x * 8;
+#pragma unroll
+	for (int r = 0; r < TILE / 2048; ++r) {  // eight bytes per thread in one load (any alignment), the last ones of a segment one by one
+		const uint64_t i = begin + (uint64_t)r * 2048 + (uint64_t)threadIdx.x * 8;
 		if (i + 8 <= end) {
 			uint64_t v;
 			__builtin_memcpy(&v, side + i, 8);
