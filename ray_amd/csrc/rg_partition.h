@@ -578,7 +578,9 @@ __global__ __launch_bounds__(256) void k_superkmers_lanes(const uint64_t *__rest
 // [0, n_in) of k_superkmers output, holes included).  A tile of SCATTER_TILE records never crosses a
 // segment (tile_first[s] = first tile of segment s).  digit = (bucket24 >> shift) & (2^dbits - 1);
 // the records of segment s with digit d go to the range that starts at cursors[(s << dbits) + d].
-static constexpr int SCATTER_TILE = 2048;
+// 2560 records of 24 bytes + digits = 72 KB: still two workgroups per CU, runs a quarter longer than with 2048 (k_scatter x3
+// 21.9-23.1 -> 21.0-22.3 ms on C2, same box; 3072 would leave one workgroup per CU)
+static constexpr int SCATTER_TILE = 2560;
 static constexpr int SCATTER_THREADS = 512;  // threads of a scatter workgroup: 4 records each (256 threads x 8: 23-25 ms for the three levels on C2, 512 x 4: 20.5-22)
 
 __device__ __forceinline__ uint32_t find_segment(const uint32_t *__restrict__ tile_first, uint32_t S, uint32_t tile) {
@@ -690,7 +692,7 @@ __global__ __launch_bounds__(256) void k_level_hist_side(const uint8_t *__restri
 	s_cnt[threadIdx.x] = 0;
 	__syncthreads();
 #pragma unroll
-	for (int r = 0; r < TILE / 2048; ++r) {  // eight bytes per thread in one load (any alignment), the last ones of a segment one by one
+	for (int r = 0; r < (TILE + 2047) / 2048; ++r) {  // eight bytes per thread in one load (any alignment), the last ones of a segment one by one
 		const uint64_t i = begin + (uint64_t)r * 2048 + (uint64_t)threadIdx.x * 8;
 		if (i + 8 <= end) {
 			uint64_t v;
