@@ -137,9 +137,11 @@ __global__ __launch_bounds__(256) void k_bloom_hist(const Slot *__restrict__ tab
 	if (s_hist[threadIdx.x]) atomicAdd(&hist1[threadIdx.x], (unsigned long long)s_hist[threadIdx.x]);
 }
 
-// The items of 512 slots (up to 4096) are made in registers, sorted by their level-0 digit in LDS and written as
+// The items of a tile of slots are made in registers, sorted by their level-0 digit in LDS and written as
 // runs at the tile's cursor claims: k_scatter64's scheme with the items computed instead of loaded.
-static constexpr int ITEM_TILE_SLOTS = 512;
+// 1024 keys = 8192 items per workgroup (64 KB of items + digits in LDS, two workgroups per CU): runs of 32 items per
+// (tile, digit); with 512 keys k_bloom_scatter_items took 4.9-5.0 ms on C2, with 1024 2.8-3.7 (same box)
+static constexpr int ITEM_TILE_SLOTS = 1024;
 template <int W>
 __global__ __launch_bounds__(SCATTER_THREADS) void k_bloom_scatter_items(const Slot *__restrict__ tab, uint64_t cap, uint64_t m_bits, uint64_t m_inv,
                                                              int shift1, unsigned long long *__restrict__ cursors,
