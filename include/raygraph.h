@@ -178,6 +178,21 @@ int rg_count_sequences(const char *path, uint64_t *n);
 int rg_load_sequences(rg_handle *h, const char *path, uint64_t first, uint64_t last, uint64_t *loaded);
 int rg_get_reads(rg_handle *h, uint8_t *packed, uint64_t packed_cap, uint64_t *byte_offsets, uint32_t *lengths,
                  uint64_t cap_reads, uint64_t *n_reads, uint64_t *packed_bytes);
+/* Read ingest that allocates nothing.  No counterpart in the reference: it is for callers that cannot allocate
+ * device memory -- code under HIP graph capture, tight serving loops that ingest one batch of reads after another,
+ * harnesses that forbid hipMalloc.  Same trimming and packing as rg_add_reads_text (same kernels), but every array
+ * is the caller's and lives in device memory: sequence i = d_text[d_starts[i], d_starts[i] + d_raw_lengths[i])
+ * (d_raw_lengths[i] < 65535); out: d_lengths[i] = stored length, d_byte_offsets[i] = start of read i in d_packed,
+ * d_byte_offsets[n_reads] = packed bytes produced (the array has n_reads + 1 entries).  Bytes beyond packed_cap are
+ * not written: d_byte_offsets[n_reads] > packed_cap tells the caller that d_packed is incomplete.  The outputs have
+ * the layout rg_add_reads_device takes.  The per-read scratch (16 B per sequence) is a fixed array inside the
+ * library, RG_NOALLOC_MAX_READS sequences per call (more: RG_ERR_CAPACITY); one array per GPU, shared by every
+ * call on that GPU, so calls that overlap on one GPU (two streams, two threads) race.  The work is queued on the
+ * handle's stream and not waited for; no hipMalloc, hipFree or other allocating call is made. */
+#define RG_NOALLOC_MAX_READS 262144
+int rg_pack_reads_noalloc(rg_handle *h, const char *d_text, uint64_t text_bytes, const uint64_t *d_starts,
+                          const uint32_t *d_raw_lengths, uint64_t n_reads, uint8_t *d_packed, uint64_t packed_cap,
+                          uint64_t *d_byte_offsets, uint32_t *d_lengths);
 /* SequencesIndexer marker selection (SequencesIndexer/IndexerWorker.cpp:67-248,328-362; the build without
  * CONFIG_USE_COVERAGE_DISTRIBUTION): for every read, in the order added, the forward marker = first
  * k-mer position whose coverage reaches the read's threshold, the reverse marker = length-k-(last such

@@ -14,6 +14,7 @@ RG_ERR_ARG, RG_ERR_HIP, RG_ERR_NOMEM, RG_ERR_STATE, RG_ERR_CAPACITY = -1, -2, -3
 RG_BLOOM_DEFAULT = (1 << 64) - 1
 RG_ENTRY_BYTES = 32
 UINT64_MAX = (1 << 64) - 1
+RG_NOALLOC_MAX_READS = 262144
 
 
 class RgConfig(C.Structure):
@@ -32,7 +33,7 @@ SYMBOLS = ["rg_create", "rg_destroy", "rg_last_error", "rg_add_reads", "rg_add_r
            "rg_count_local", "rg_records_local", "rg_records_local_part", "rg_record_counts", "rg_export_records", "rg_count_records", "rg_owner_counts", "rg_export_owner_buckets", "rg_merge_entries",
            "rg_resolve_admission", "rg_histogram", "rg_add_edges", "rg_purge_edges", "rg_purge_query_counts",
            "rg_purge_export_queries", "rg_purge_answer", "rg_purge_apply", "rg_size", "rg_export",
-           "rg_find", "rg_add_reads_text", "rg_count_sequences", "rg_load_sequences", "rg_get_reads", "rg_read_markers",
+           "rg_find", "rg_add_reads_text", "rg_count_sequences", "rg_load_sequences", "rg_get_reads", "rg_pack_reads_noalloc", "rg_read_markers",
            "rg_import_vertices", "rg_write_kmers_txt", "rg_write_genome_graph", "rg_write_coverage_checkpoint", "rg_write_graph_partition", "rg_degree_distribution", "rg_get_stats", "rg_set_profiling", "rg_get_kernel_profile", "rg_release_cached_memory", "rg_coverage_distribution", "rg_pack_read",
            "rg_version"]
 
@@ -90,6 +91,7 @@ def load():
         "rg_count_sequences": ([C.c_char_p, u64p], C.c_int),
         "rg_load_sequences": ([vp, C.c_char_p, u64, u64, u64p], C.c_int),
         "rg_get_reads": ([vp, vp, u64, vp, vp, u64, u64p, u64p], C.c_int),
+        "rg_pack_reads_noalloc": ([vp, vp, u64, vp, vp, u64, vp, u64, vp, vp], C.c_int),
         "rg_read_markers": ([vp, vp, vp], C.c_int),
         "rg_import_vertices": ([vp, vp, u64], C.c_int),
         "rg_write_kmers_txt": ([vp, u64, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int], C.c_int),

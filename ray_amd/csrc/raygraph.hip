@@ -537,7 +537,7 @@ __global__ __launch_bounds__(BLOCK) void k_trim_reads(const uint8_t *__restrict_
 // C, G or T encodes as A (Read.cpp:117-141)
 __global__ __launch_bounds__(BLOCK) void k_pack_reads(const uint8_t *__restrict__ text, const uint64_t *__restrict__ tstart,
                                                       const uint32_t *__restrict__ tlen, const unsigned long long *__restrict__ off,
-                                                      uint64_t n, uint8_t *__restrict__ out) {
+                                                      uint64_t n, uint8_t *__restrict__ out, uint64_t out_cap) {
 	__shared__ unsigned long long s_off[65];
 	const uint64_t r0 = (uint64_t)blockIdx.x * 64;
 	const uint32_t nr = (n - r0 < 64) ? (uint32_t)(n - r0) : 64u;
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(BLOCK) void k_pack_reads(const uint8_t *__restrict_
 				const uint32_t code = (c == 'C') ? 1u : (c == 'G') ? 2u : (c == 'T') ? 3u : 0u;
 				v |= code << (2 * q);
 			}
-		out[b] = (uint8_t)v;
+		if (b < out_cap) out[b] = (uint8_t)v;  // out_cap: the caller's buffer (rg_pack_reads_noalloc); ~0 when the library sized it
 	}
 }
 
@@ -974,6 +974,33 @@ void pool_free(int device, void *p) {
 	if (it == g_pool.live[device].end()) return;
 	g_pool.free_blocks[device].insert({it->second, p});
 	g_pool.live[device].erase(it);
+}
+}  // namespace
+
+// ---- scratch of the entry point that allocates nothing (rg_pack_reads_noalloc) -----------------------
+// One file-scope device array per GPU (every device the code object is loaded on holds its own copy, at its
+// own address, until the process ends).  Host code never passes the array's name to a kernel: g_noalloc_ptr[d]
+// is the address hipGetSymbolAddress returned with device d current, and that is what kernels, memsets and
+// copies get.  Layout: trimmed start of every sequence (8 B), packed bytes of every sequence (8 B), the
+// scan's block sums.
+static constexpr uint64_t NOALLOC_MAX_READS = RG_NOALLOC_MAX_READS;
+static constexpr uint64_t NOALLOC_SUMS = NOALLOC_MAX_READS / SCAN_PER_BLOCK + 2;
+static constexpr uint64_t NOALLOC_BYTES = (2 * NOALLOC_MAX_READS + 2 * NOALLOC_SUMS) * sizeof(unsigned long long);
+static __device__ __align__(256) unsigned char scratch[NOALLOC_BYTES];
+namespace {
+std::mutex g_noalloc_mu;
+void *g_noalloc_ptr[64] = {nullptr};
+// once per device, with that device current
+hipError_t noalloc_init(int device) {
+	if (device < 0 || device >= 64) return hipErrorInvalidDevice;
+	std::lock_guard<std::mutex> lk(g_noalloc_mu);
+	if (g_noalloc_ptr[device]) return hipSuccess;
+	void *ptr = nullptr;
+	hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+	if (e != hipSuccess) return e;
+	if (!ptr) return hipErrorInvalidSymbol;
+	g_noalloc_ptr[device] = ptr;
+	return hipSuccess;
 }
 }  // namespace
 
@@ -1942,6 +1969,8 @@ int rg_create(const rg_config *cfg, rg_handle **out) {
 		return fail(nullptr, RG_ERR_NOMEM, "allocating counters failed");
 	}
 	(void)hipMemsetAsync(h->d_counters, 0, sizeof(unsigned long long) * C_NUM, h->stream);
+	if (cfg->device < 64) (void)noalloc_init(cfg->device);  // set-up of rg_pack_reads_noalloc (it checks the result itself)
+	(void)hipGetLastError();
 	h->owner_counts.assign((size_t)cfg->size, 0);
 	*out = h;
 	return RG_OK;
@@ -2729,7 +2758,7 @@ int rg_add_reads_text(rg_handle *h, const char *text, uint64_t text_bytes, const
 	if (e == hipSuccess) e = hipMemsetAsync(d_packed + (padded - 24), 0, 24, h->stream);
 	if (e == hipSuccess) {
 		ProfScope ps(h, "k_pack_reads");
-		hipLaunchKernelGGL(k_pack_reads, dim3((unsigned)((n_reads + 63) / 64)), dim3(BLOCK), 0, h->stream, d_text, d_tstart, d_tlen, d_off, n_reads, d_packed);
+		hipLaunchKernelGGL(k_pack_reads, dim3((unsigned)((n_reads + 63) / 64)), dim3(BLOCK), 0, h->stream, d_text, d_tstart, d_tlen, d_off, n_reads, d_packed, ~0ull);
 		e = hipGetLastError();
 	}
 	std::vector<uint32_t> tl(n_reads);
@@ -2753,6 +2782,42 @@ int rg_add_reads_text(rg_handle *h, const char *text, uint64_t text_bytes, const
 	b.owned = true;
 	h->reads.push_back(b);
 	h->n_reads += n_reads;
+	return RG_OK;
+}
+
+// The read ingest of rg_add_reads_text for callers that cannot allocate: same kernels, their per-read scratch
+// in the file-scope array, results in the caller's buffers.  No hipMalloc / hipFree / pool / event creation here.
+int rg_pack_reads_noalloc(rg_handle *h, const char *d_text, uint64_t text_bytes, const uint64_t *d_starts,
+                          const uint32_t *d_raw_lengths, uint64_t n_reads, uint8_t *d_packed, uint64_t packed_cap,
+                          uint64_t *d_byte_offsets, uint32_t *d_lengths) {
+	if (!h) return RG_ERR_ARG;
+	if (n_reads > NOALLOC_MAX_READS)
+		return fail(h, RG_ERR_CAPACITY, "rg_pack_reads_noalloc: %llu sequences, the scratch holds %llu per call", (unsigned long long)n_reads,
+		            (unsigned long long)NOALLOC_MAX_READS);
+	if (!d_byte_offsets) return fail(h, RG_ERR_ARG, "null offsets array");
+	if (n_reads && (!d_text || !d_starts || !d_raw_lengths || !d_lengths || (!d_packed && packed_cap))) return fail(h, RG_ERR_ARG, "null read arrays");
+	(void)text_bytes;  // the device arrays are the caller's: sequence i must lie inside d_text
+	const int dev = h->cfg.device;
+	HIP_TRY(h, hipSetDevice(dev));
+	HIP_TRY(h, noalloc_init(dev));
+	unsigned long long *base = (unsigned long long *)g_noalloc_ptr[dev];
+	uint64_t *s_tstart = (uint64_t *)base;
+	unsigned long long *s_nbytes = base + NOALLOC_MAX_READS;
+	unsigned long long *s_sums = base + 2 * NOALLOC_MAX_READS;
+	unsigned long long *off = (unsigned long long *)d_byte_offsets;
+	if (n_reads == 0) {  // d_byte_offsets[0] = 0 packed bytes
+		HIP_TRY(h, hipMemsetAsync(off, 0, sizeof(unsigned long long), h->stream));
+		return RG_OK;
+	}
+	const uint32_t nblk = (uint32_t)((n_reads + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK);
+	hipLaunchKernelGGL(k_trim_reads, dim3(grid_for(n_reads)), dim3(BLOCK), 0, h->stream, (const uint8_t *)d_text, d_starts, d_raw_lengths, n_reads, s_tstart,
+	                   d_lengths, s_nbytes);
+	hipLaunchKernelGGL(k_scan_local, dim3(nblk), dim3(256), 0, h->stream, s_nbytes, off, n_reads, s_sums);
+	hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(64), 0, h->stream, s_sums, nblk, s_sums + nblk);
+	hipLaunchKernelGGL(k_scan_add, dim3(nblk), dim3(256), 0, h->stream, off, n_reads, s_sums, s_sums + nblk, (unsigned long long *)nullptr);
+	hipLaunchKernelGGL(k_pack_reads, dim3((unsigned)((n_reads + 63) / 64)), dim3(BLOCK), 0, h->stream, (const uint8_t *)d_text, s_tstart, d_lengths, off, n_reads,
+	                   d_packed, packed_cap);
+	HIP_TRY(h, hipGetLastError());
 	return RG_OK;
 }
 

@@ -174,6 +174,12 @@ class GraphBuilder:
                                          C.byref(n), C.byref(nb)))
         return packed[: nb.value], off[: n.value], ln[: n.value]
 
+    def pack_reads_noalloc(self, text_ptr, text_bytes, starts_ptr, raw_lengths_ptr, n_reads, packed_ptr, packed_cap,
+                           offsets_ptr, lengths_ptr):
+        """rg_pack_reads_noalloc: device pointers only, nothing allocated, queued on the builder's stream"""
+        self._check(self._L.rg_pack_reads_noalloc(self._h, text_ptr, text_bytes, starts_ptr, raw_lengths_ptr, n_reads,
+                                                  packed_ptr, packed_cap, offsets_ptr, lengths_ptr))
+
     def import_vertices(self, records):
         """load exported records (or a parsed GenomeGraph checkpoint) into a fresh builder: coverage and edges final"""
         records = np.ascontiguousarray(records)
