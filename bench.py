@@ -102,6 +102,18 @@ def cpu_baseline(packed, offsets, lengths, k, n_sample, cores):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks here, before anything in this process has
+        # touched the GPU (a process that has must never be replaced or forked), and hand on their exit code.  Rank 0's
+        # JSON line goes to the same stdout.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     import torch
     import torch.distributed as dist
     import ray_amd
@@ -112,8 +124,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        raise SystemExit("--gpus %d but the launcher started %d ranks" % (args.gpus, world))
     backend = os.environ.get("RAYGRAPH_BENCH_BACKEND", "nccl")  # "gloo": rehearse N ranks on one GPU (host-staged)
     if backend == "gloo":
         local_rank = 0

@@ -1036,6 +1036,7 @@ struct rg_handle {
 	unsigned long long *h_counters = nullptr;  // pinned
 	unsigned long long *d_owner = nullptr;     // [size] counts, [size] cursors
 	std::vector<uint64_t> owner_counts;
+	bool owner_counts_valid = false;           // set by rg_owner_counts, cleared by whatever changes the entries it counted
 	Phase phase = PH_CREATED;
 	rg_stats stats{};
 	std::string err;
@@ -2063,7 +2064,7 @@ int rg_add_reads_device(rg_handle *h, const void *d_packed, uint64_t packed_byte
 }
 
 int rg_count_local(rg_handle *h) {
-	if (h) h->hist_valid = false;
+	if (h) h->hist_valid = h->owner_counts_valid = false;
 	if (!h) return RG_ERR_ARG;
 	if (h->phase != PH_CREATED) return fail(h, RG_ERR_STATE, "rg_count_local called twice");
 	HIP_TRY(h, hipSetDevice(h->cfg.device));
@@ -2195,10 +2196,9 @@ int rg_export_records(rg_handle *h, void *d_out, uint64_t capacity_records) {
 }
 
 int rg_count_records(rg_handle *h, const void *d_records, uint64_t n_records) {
-	if (h) h->hist_valid = false;
+	if (h) h->hist_valid = h->owner_counts_valid = false;
 	if (!h || (n_records && !d_records)) return RG_ERR_ARG;
 	if (h->phase != PH_CREATED) return fail(h, RG_ERR_STATE, "rg_count_records called after counting started");
-	if (h->cfg.size == 1) return fail(h, RG_ERR_STATE, "rg_count_records is for size > 1 (use rg_count_kmers)");
 	HIP_TRY(h, hipSetDevice(h->cfg.device));
 	Slot *log = nullptr;
 	uint64_t n_log = 0;
@@ -2240,7 +2240,7 @@ int rg_owner_counts(rg_handle *h, uint64_t *counts) {
 	HIP_TRY(h, hipSetDevice(h->cfg.device));
 	if (int rcm = materialize_pending_log(h)) return rcm;
 	const uint32_t size = (uint32_t)h->cfg.size;
-	Table &T = size == 1 ? h->tab : h->local;
+	Table &T = h->local.slots ? h->local : h->tab;  // size == 1 after rg_count_local: the table itself
 	HIP_TRY(h, hipMemsetAsync(h->d_owner, 0, sizeof(unsigned long long) * 2 * size, h->stream));
 	if (h->W == 1) hipLaunchKernelGGL(k_owner_counts<1>, dim3(grid_for(T.cap)), dim3(BLOCK), size * sizeof(uint32_t), h->stream, T.slots, T.cap, size, h->d_owner);
 	else hipLaunchKernelGGL(k_owner_counts<2>, dim3(grid_for(T.cap)), dim3(BLOCK), size * sizeof(uint32_t), h->stream, T.slots, T.cap, size, h->d_owner);
@@ -2249,6 +2249,7 @@ int rg_owner_counts(rg_handle *h, uint64_t *counts) {
 	HIP_TRY(h, hipMemcpyAsync(tmp.data(), h->d_owner, sizeof(unsigned long long) * size, hipMemcpyDeviceToHost, h->stream));
 	HIP_TRY(h, hipStreamSynchronize(h->stream));
 	for (uint32_t r = 0; r < size; ++r) h->owner_counts[r] = counts[r] = tmp[r];
+	h->owner_counts_valid = true;
 	return RG_OK;
 }
 
@@ -2258,7 +2259,8 @@ int rg_export_owner_buckets(rg_handle *h, void *d_out, uint64_t capacity_entries
 	HIP_TRY(h, hipSetDevice(h->cfg.device));
 	if (int rcm = materialize_pending_log(h)) return rcm;
 	const uint32_t size = (uint32_t)h->cfg.size;
-	Table &T = size == 1 ? h->tab : h->local;
+	Table &T = h->local.slots ? h->local : h->tab;
+	if (!h->owner_counts_valid) return fail(h, RG_ERR_STATE, "rg_export_owner_buckets needs rg_owner_counts first");
 	std::vector<unsigned long long> cursors(size);
 	uint64_t total = 0;
 	for (uint32_t r = 0; r < size; ++r) {
@@ -2280,8 +2282,11 @@ int rg_merge_entries(rg_handle *h, const void *d_entries, uint64_t n_entries) {
 	if (h) h->hist_valid = false;
 	if (!h) return RG_ERR_ARG;
 	if (h->phase != PH_COUNTED_LOCAL && h->phase != PH_MERGING) return fail(h, RG_ERR_STATE, "rg_merge_entries needs rg_count_local first");
-	if (h->cfg.size == 1) return fail(h, RG_ERR_STATE, "rg_merge_entries is for size > 1 (the local table is already the partition)");
+	// one rank: only after rg_count_records (a rank that sent its records to itself); after rg_count_local the table already is the partition
+	if (h->cfg.size == 1 && h->phase == PH_COUNTED_LOCAL && !h->local.slots)
+		return fail(h, RG_ERR_STATE, "rg_merge_entries is for size > 1 (the local table is already the partition)");
 	HIP_TRY(h, hipSetDevice(h->cfg.device));
+	h->owner_counts_valid = false;
 	if (h->phase == PH_COUNTED_LOCAL) {
 		table_free(h, h->local);  // the buckets hold everything the local table knew
 		h->phase = PH_MERGING;
@@ -2337,7 +2342,7 @@ int rg_merge_entries(rg_handle *h, const void *d_entries, uint64_t n_entries) {
 int rg_resolve_admission(rg_handle *h, uint64_t local_reads_for_bloom) {
 	if (h) h->hist_valid = false;
 	if (!h) return RG_ERR_ARG;
-	if (h->cfg.size == 1) {
+	if (h->cfg.size == 1 && h->phase != PH_MERGING && !(h->phase == PH_COUNTED_LOCAL && h->local.slots)) {
 		if (h->phase != PH_COUNTED_LOCAL) return fail(h, RG_ERR_STATE, "rg_resolve_admission needs rg_count_local first");
 	} else {
 		if (h->phase != PH_MERGING && h->phase != PH_COUNTED_LOCAL) return fail(h, RG_ERR_STATE, "rg_resolve_admission needs rg_merge_entries first");

@@ -40,10 +40,11 @@ def _a2a(recv, src, out_counts, in_counts, unit, group, async_op=False):
                                   input_split_sizes=[c * unit for c in in_counts], group=group, async_op=async_op)
 
 
-def exchange_owner_buckets(engine, group=None, device="cuda"):
-    """all-to-all(v) of the per-owner buckets; returns (entries sent, entries received)."""
+def exchange_owner_buckets(engine, group=None, device="cuda", always=False):
+    """all-to-all(v) of the per-owner buckets; returns (entries sent, entries received).
+    always: run the exchange on one rank too (after exchange_records: the rank's entries travel to itself)."""
     size = engine.size
-    if size == 1:
+    if size == 1 and not always:
         return 0, 0  # the local table already is the partition; nothing moves
     counts = engine.owner_counts()
     total = sum(counts)
@@ -136,11 +137,11 @@ def exchange_records(engine, group=None, device="cuda", parts=1):
     return sent, n_all
 
 
-def purge_edges_distributed(engine, group=None, device="cuda"):
+def purge_edges_distributed(engine, group=None, device="cuda", always=False):
     """RAY_SLAVE_MODE_PURGE_NULL_EDGES across ranks: one all-to-all of neighbour keys, one of one-byte
     answers back (EdgePurgerWorker.cpp:28-102 asks one key per message, MessageProcessor.cpp:1224-1256
     answers with the coverage).  Returns the number of queries this rank asked."""
-    if engine.size == 1:
+    if engine.size == 1 and not always:
         engine.purge_edges()
         return 0
     unit = 8 * engine.kmer_words
@@ -166,12 +167,12 @@ def purge_edges_distributed(engine, group=None, device="cuda"):
 HIST_DENSE = 65536
 
 
-def reduce_histogram(cov, cnt, group=None, device="cuda", size=1):
+def reduce_histogram(cov, cnt, group=None, device="cuda", size=1, always=False):
     """merge the ranks' (coverage, count) pairs like rank 0 does on RAY_MPI_TAG_COVERAGE_DATA
     (MessageProcessor.cpp:1048-1061): a dense all-reduce for coverage < 65536, the rare tail by object
     gather.  Every rank gets the merged, ascending arrays."""
     import numpy as np
-    if size == 1:
+    if size == 1 and not always:
         return cov, cnt
     dense = torch.zeros(HIST_DENSE, dtype=torch.int64)
     low = cov < HIST_DENSE
