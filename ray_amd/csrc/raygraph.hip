@@ -1207,6 +1207,48 @@ struct SuperkmerLaunch {
 	}
 };
 
+// the aggregation kernel of the sweep: a wavefront per bucket of a three-level partition (k_aggregate), or -- cfg.reserved0
+// bit 21 -- a workgroup per bucket of a two-level one (k_aggregate_wg)
+template <int W>
+struct AggLaunch {
+	static constexpr int THREADS = 1024, KS = 4096, RS = (W == 1 ? 1024 : 512);  // 132 / 152 KB of LDS: one workgroup of 16 wavefronts per CU
+	static constexpr uint32_t KLIMIT = KS * 5 / 8;
+	bool wg = true;
+	int occ = 1;
+	void plan(bool use_wg) {
+		wg = use_wg;
+		occ = wg ? 1 : 4;
+		if (wg) {
+			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_aggregate_wg<W, THREADS, KS, RS, false>, THREADS, 0) != hipSuccess || occ < 1) occ = 1;
+		} else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_aggregate<W, false>, 64 * AGG_WAVES, 0) != hipSuccess || occ < 1) occ = 4;
+		(void)hipGetLastError();
+	}
+	uint32_t per_group() const { return wg ? 1u : AGG_WAVES; }           // buckets a workgroup works on at a time
+	uint64_t key_limit() const { return wg ? KLIMIT : AGG_LIMIT; }       // keys a bucket attempt can hold
+	uint64_t slack(unsigned grid) const { return wg ? 0 : (uint64_t)grid * AGG_WAVES * LOG_CHUNK; }  // log entries lost to open chunks
+	// occurrences a bucket should hold at most: its distinct k-mers must fit the LDS table at the coverage assemblies are run at
+	uint64_t occ_per_bucket() const { return wg ? (uint64_t)KS * 24 : 2048; }
+	unsigned grid_for_buckets(uint64_t n, int n_cu) const { return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n + per_group() - 1) / per_group(), (uint64_t)n_cu * occ)); }
+	void fast(rg_handle *h, unsigned grid, const Rec<W> *recs, const unsigned long long *begin, uint32_t nb, int k, Slot *log, uint64_t log_cap,
+	          uint32_t flag_unique, uint32_t *retry, int m, uint32_t rbits) const {
+		if (wg)
+			hipLaunchKernelGGL((k_aggregate_wg<W, THREADS, KS, RS, false>), dim3(grid), dim3(THREADS), 0, h->stream, recs, begin, nb, k, log, log_cap, h->d_counters,
+			                   flag_unique, (const uint32_t *)nullptr, retry, m, rbits);
+		else
+			hipLaunchKernelGGL((k_aggregate<W, false>), dim3(grid), dim3(64 * AGG_WAVES), 0, h->stream, recs, begin, nb, k, log, log_cap, h->d_counters, flag_unique,
+			                   (const uint32_t *)nullptr, retry, m, rbits);
+	}
+	void slow(rg_handle *h, unsigned grid, const Rec<W> *recs, const unsigned long long *begin, uint32_t nlist, int k, Slot *log, uint64_t log_cap,
+	          uint32_t flag_unique, const uint32_t *list, int m, uint32_t rbits) const {
+		if (wg)
+			hipLaunchKernelGGL((k_aggregate_wg<W, THREADS, KS, RS, true>), dim3(grid), dim3(THREADS), 0, h->stream, recs, begin, nlist, k, log, log_cap, h->d_counters,
+			                   flag_unique, list, (uint32_t *)nullptr, m, rbits);
+		else
+			hipLaunchKernelGGL((k_aggregate<W, true>), dim3(grid), dim3(64 * AGG_WAVES), 0, h->stream, recs, begin, nlist, k, log, log_cap, h->d_counters, flag_unique,
+			                   list, (uint32_t *)nullptr, m, rbits);
+	}
+};
+
 template <int W>
 static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bool *ok, const void *ext = nullptr, uint64_t ext_n = 0) {
 	*ok = false;
@@ -1241,10 +1283,12 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	// number of buckets: at most 2048 k-mer occurrences each, so that at the coverage assemblies are run at (>= 10)
 	// a bucket's distinct k-mers fit the LDS table of k_aggregate; buckets of more diverse inputs are split further
 	// by k_aggregate<SLOW> itself
+	AggLaunch<W> agg;
+	agg.plan((h->cfg.reserved0 & 0x200000) != 0);  // bit 21: a workgroup per bucket of a coarser partition (slower as it stands: DESIGN.md)
 	int bits = (h->cfg.reserved0 >> 8) & 0xFF;
 	if (bits == 0) {
-		bits = 8;
-		while (bits < MAX_BUCKET_BITS && (occ_bound >> bits) > 2048) bits++;
+		bits = agg.wg ? 12 : 8;
+		while (bits < MAX_BUCKET_BITS && (occ_bound >> bits) > agg.occ_per_bucket()) bits++;
 	}
 	if (bits < 8) bits = 8;
 	if (bits > MAX_BUCKET_BITS) bits = MAX_BUCKET_BITS;
@@ -1259,12 +1303,10 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	const uint64_t NBUCK = 1ull << bits;
 	// persistent grids sized to what is resident at once, so that no second, nearly empty round of
 	// workgroups runs behind the first
-	int n_cu = 256, occ3 = 4;
+	int n_cu = 256;
 	(void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
 	SuperkmerLaunch<W> sk;
 	sk.plan(h, n_cu, k, m, total_reads);
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ3, k_aggregate<W, false>, 64 * AGG_WAVES, 0) != hipSuccess || occ3 < 1) occ3 = 4;
-	(void)hipGetLastError();
 	const int grid1 = sk.grid_max();
 	uint64_t launches1 = 0;  // every launch of k_superkmers leaves up to one open chunk per wavefront
 	for (const ReadBatch &b : h->reads)
@@ -1410,8 +1452,8 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	// 3. aggregate per bucket into the log, one entry per distinct k-mer.  A quarter of the occurrences is a
 	// deterministic size (the pool reuses the block) that only inputs of little redundancy (coverage below 4, or
 	// errors in most reads) exceed; for them the aggregation is run again with a larger log.
-	const unsigned agg_grid = (unsigned)std::min<uint64_t>((NBUCK + AGG_WAVES - 1) / AGG_WAVES, (uint64_t)n_cu * occ3);
-	const uint64_t log_slack = (uint64_t)agg_grid * AGG_WAVES * LOG_CHUNK;
+	const unsigned agg_grid = agg.grid_for_buckets(NBUCK, n_cu);
+	const uint64_t log_slack = agg.slack(agg_grid);
 	uint64_t log_cap = std::min<uint64_t>(occ_bound, std::max<uint64_t>(occ_bound / 4, 1ull << 20)) + log_slack;
 	if (h->cfg.reserved0 & 64) log_cap = LOG_CHUNK;  // tests: the first attempt overflows
 	uint32_t *d_retry = nullptr;
@@ -1440,15 +1482,11 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 			bool fine = hipMemsetAsync(h->d_counters + PC_LOG_CURSOR, 0, 6 * sizeof(unsigned long long), h->stream) == hipSuccess;
 			if (fine) {
 				ProfScope ps(h, "k_aggregate_probe");
-				const unsigned g1 = (unsigned)std::min<uint64_t>((P + AGG_WAVES - 1) / AGG_WAVES, (uint64_t)agg_grid);
-				hipLaunchKernelGGL((k_aggregate<W, false>), dim3(g1), dim3(64 * AGG_WAVES), 0, h->stream, level_in, d_begin, P, k, log, log_cap,
-				                   h->d_counters, flag_unique, (const uint32_t *)nullptr, d_retry, m, (uint32_t)(24 - bits));
+				agg.fast(h, agg.grid_for_buckets(P, n_cu), level_in, d_begin, P, k, log, log_cap, flag_unique, d_retry, m, (uint32_t)(24 - bits));
 				fine = hipGetLastError() == hipSuccess && sync_counters(h) == RG_OK;
 				const uint64_t n_retry = fine ? h->h_counters[PC_AGG_RETRY] : 0;
-				if (fine && n_retry && !h->h_counters[PC_LOG_OVF] && h->h_counters[PC_LOG_CURSOR] + n_retry * (uint64_t)AGG_LIMIT <= log_cap) {
-					const unsigned g2 = (unsigned)std::min<uint64_t>((n_retry + AGG_WAVES - 1) / AGG_WAVES, (uint64_t)agg_grid);
-					hipLaunchKernelGGL((k_aggregate<W, true>), dim3(g2), dim3(64 * AGG_WAVES), 0, h->stream, level_in, d_begin, (uint32_t)n_retry, k, log, log_cap,
-					                   h->d_counters, flag_unique, (const uint32_t *)d_retry, (uint32_t *)nullptr, m, (uint32_t)(24 - bits));
+				if (fine && n_retry && !h->h_counters[PC_LOG_OVF] && h->h_counters[PC_LOG_CURSOR] + n_retry * agg.key_limit() <= log_cap) {
+					agg.slow(h, agg.grid_for_buckets(n_retry, n_cu), level_in, d_begin, (uint32_t)n_retry, k, log, log_cap, flag_unique, d_retry, m, (uint32_t)(24 - bits));
 					fine = hipGetLastError() == hipSuccess && sync_counters(h) == RG_OK;
 				} else if (n_retry) {
 					fine = false;  // the sample alone does not fit: the attempt below finds out and the log doubles
@@ -1480,20 +1518,17 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 		hipError_t e0 = hipMemsetAsync(h->d_counters + PC_LOG_CURSOR, 0, 6 * sizeof(unsigned long long), h->stream);
 		if (e0 == hipSuccess) {
 			ProfScope ps(h, "k_aggregate");
-			hipLaunchKernelGGL((k_aggregate<W, false>), dim3(agg_grid), dim3(64 * AGG_WAVES), 0, h->stream, level_in, d_begin, (uint32_t)NBUCK, k, log, log_cap,
-			                   h->d_counters, flag_unique, (const uint32_t *)nullptr, d_retry, m, (uint32_t)(24 - bits));
+			agg.fast(h, agg_grid, level_in, d_begin, (uint32_t)NBUCK, k, log, log_cap, flag_unique, d_retry, m, (uint32_t)(24 - bits));
 			e0 = hipGetLastError();
 		}
 		if (e0 == hipSuccess) {
 			rc = sync_counters(h);
 			const uint64_t n_retry = rc ? 0 : h->h_counters[PC_AGG_RETRY];
 			// every bucket left over holds more k-mers than the LDS table: if even that many cannot fit, skip the launch
-			if (!rc && n_retry && h->h_counters[PC_LOG_CURSOR] + n_retry * (uint64_t)AGG_LIMIT > log_cap) too_small = true;
+			if (!rc && n_retry && h->h_counters[PC_LOG_CURSOR] + n_retry * agg.key_limit() > log_cap) too_small = true;
 			if (n_retry && !too_small && !h->h_counters[PC_LOG_OVF]) {  // the buckets whose k-mers did not fit the LDS table: split further
 				ProfScope ps(h, "k_aggregate_retry");
-				const unsigned g2 = (unsigned)std::min<uint64_t>((n_retry + AGG_WAVES - 1) / AGG_WAVES, (uint64_t)n_cu * occ3);
-				hipLaunchKernelGGL((k_aggregate<W, true>), dim3(g2), dim3(64 * AGG_WAVES), 0, h->stream, level_in, d_begin, (uint32_t)n_retry, k, log, log_cap,
-				                   h->d_counters, flag_unique, (const uint32_t *)d_retry, (uint32_t *)nullptr, m, (uint32_t)(24 - bits));
+				agg.slow(h, agg.grid_for_buckets(n_retry, n_cu), level_in, d_begin, (uint32_t)n_retry, k, log, log_cap, flag_unique, d_retry, m, (uint32_t)(24 - bits));
 			}
 		}
 		hipError_t e = (e0 != hipSuccess) ? e0 : hipGetLastError();
@@ -1503,6 +1538,12 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 			cleanup();
 			pool_free(dev, log);
 			return e != hipSuccess ? fail(h, RG_ERR_HIP, "k_aggregate: %s", hipGetErrorString(e)) : rc;
+		}
+		if (agg.wg && h->h_counters[PC_LDS_SPILL]) {  // a share of a bucket that no split could make fit: count with the direct sweep instead
+			pool_free(dev, d_retry);
+			cleanup();
+			pool_free(dev, log);
+			return RG_OK;
 		}
 		if (!h->h_counters[PC_LOG_OVF] && !too_small) break;
 		pool_free(dev, log);
@@ -1516,6 +1557,16 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 		const uint64_t doubled = (h->cfg.reserved0 & 64) ? 0 : 2 * (log_cap - log_slack);
 		log_cap = ((attempt == 0 && doubled) ? std::min<uint64_t>(occ_bound, doubled) : occ_bound) + log_slack;
 	}
+#ifdef RG_AGG_TIMING
+	{
+		unsigned long long dbg[16];
+		(void)hipMemcpyFromSymbol(dbg, HIP_SYMBOL(g_dbg), sizeof dbg);
+		fprintf(stderr, "[raygraph] agg cycles of thread 0 (sum over workgroups): hash %llu ph1 %llu barA %llu ph2 %llu barB %llu expand_end %llu flush %llu expand_mid %llu\n", dbg[0], dbg[1], dbg[2],
+		        dbg[3], dbg[4], dbg[5], dbg[6], dbg[7]);
+		memset(dbg, 0, sizeof dbg);
+		(void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), dbg, sizeof dbg);
+	}
+#endif
 	pool_free(dev, d_retry);
 	cleanup();
 	*out_log = log;

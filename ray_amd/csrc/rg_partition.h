@@ -1294,6 +1294,489 @@ __global__ __launch_bounds__(64 * AGG_WAVES) void k_aggregate(const Rec<W> *__re
 			if (chunk_base + i < log_cap) log[chunk_base + i].k0 = EMPTY;
 }
 
+// ------------------------------------------------------------------------------------------------
+// One *workgroup* per bucket: the aggregation over a two-level partition (2^16 buckets of ~9 K records on C2 instead
+// of 2^22 of ~140), so that the third partition level, its histogram and its read + write of every record go away.
+// Same two-table scheme as k_aggregate, the tables shared by all wavefronts of the workgroup:
+//  1. the record table merges bit-identical records.  A slot is claimed with a compare-and-swap on a 64-bit
+//     fingerprint; whether a record really equals the slot's (fingerprints can collide) is checked after a barrier,
+//     when the owner's words are in place.  New slots are ticketed (rfill): a record that finds the table at its
+//     limit stays pending, the table is expanded into the k-mer table and emptied, and the record tries again;
+//  2. the expansion hands the distinct records out to the wavefronts 64 at a time; inside a wavefront their k-mers
+//     are laid out flat, a lane per k-mer, exactly as in k_aggregate, and go to the shared k-mer table with LDS
+//     atomics.  A round of 64 k-mers only starts while the table holds at most KLIMIT keys, so with THREADS k-mers
+//     in flight it never fills up; above that the attempt is void (nothing was written) and the bucket goes to the
+//     retry list (SLOW == false) or is split further (SLOW == true), as in k_aggregate;
+//  3. the k-mer table is flushed once per bucket (or per node of the split): one global atomic reserves exactly its
+//     number of entries in the log, so the log has no holes.  There are no partial flushes: a share of a bucket that
+//     4096 hash sub-passes below the record levels cannot hold is counted in PC_LDS_SPILL and the host falls back.
+template <int W, int KS, int RS>
+struct WgTables {
+	uint64_t k0[KS];
+	uint64_t k1[W == 2 ? KS : 1];
+	uint64_t stamp[KS];
+	uint32_t cnt[KS];
+	uint32_t edges[KS / 4];  // one byte per slot
+	uint16_t klist[KS];
+	unsigned long long rfp[RS];  // 0 = free, else a 63-bit fingerprint of the record | 1
+	uint64_t rw[2 * W][RS];
+	uint64_t rstamp[RS];
+	uint32_t rcnt[RS];
+	uint16_t rtag[RS];  // header bits 16..30: length, neighbour flags, minimizer offset
+	uint16_t rlist[RS];
+	uint32_t kfill, rfill, rnlist, flag;
+	uint32_t any[2];  // "a thread still holds a record", alternating between rounds
+	unsigned long long log_base;
+};
+
+// Workgroup barrier for data that travels through LDS only.  __syncthreads() also waits for every global load of the
+// wavefront (vmcnt(0)): the records prefetched for the next round would be waited for at the first barrier after their
+// request, with all 16 wavefronts of the CU idle meanwhile.  LDS operations of a wavefront complete in order, so waiting
+// for its own (lgkmcnt(0)) before the barrier is what visibility inside the workgroup needs.
+__device__ __forceinline__ void lds_barrier() {
+	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int KS>
+__device__ __forceinline__ uint32_t wg_slot(uint32_t hash) {
+	return hash >> (32 - __builtin_ctz(KS));
+}
+
+// One LDS atomic per wavefront instead of one per lane on a counter that every lane wants to bump: the lanes for which
+// pred holds get consecutive values.  Called by the whole wavefront (all 64 lanes active).
+__device__ __forceinline__ uint32_t wave_claim(uint32_t *counter, bool pred, uint32_t lane) {
+	const unsigned long long bal = __ballot(pred);
+	if (bal == 0) return 0;  // uniform
+	const uint32_t leader = (uint32_t)__ffsll((long long)bal) - 1u;
+	const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+	uint32_t base = 0;
+	if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(bal));
+	base = (uint32_t)__shfl((int)base, (int)leader);
+	return base + rank;
+}
+
+// Merge (stamp, weight, edge bits) of the lanes for which `active` holds into the shared k-mer table.  Called by the whole
+// wavefront; returns false for a lane whose key found no slot.
+template <int W, int KS, int RS>
+__device__ __forceinline__ bool wg_upsert(WgTables<W, KS, RS> &t, bool active, uint32_t hash, uint64_t i0, uint64_t i1, uint64_t stamp,
+                                          uint32_t emask, uint32_t weight, uint32_t lane) {
+	// double hashing: the step is odd, so a probe sequence visits every slot; with linear probing the longest cluster of a
+	// table decides how long a wavefront (its slowest lane) probes
+	uint32_t s = wg_slot<KS>(hash);
+	const uint32_t step = ((hash >> 4) & (KS - 1)) | 1u;
+	bool searching = active;
+	for (uint32_t probe = 0; probe < (uint32_t)KS && __any(searching); ++probe) {
+		uint64_t c0 = searching ? t.k0[s] : 0;
+		bool claimed = false;
+		if (searching && c0 == EMPTY) {
+			const uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long *>(&t.k0[s]), EMPTY, i0);
+			claimed = prev == EMPTY;
+			c0 = claimed ? i0 : prev;
+		}
+		const uint32_t idx = wave_claim(&t.kfill, claimed, lane);
+		if (claimed) t.klist[idx] = (uint16_t)s;
+		if (searching && c0 == i0) {
+			bool match = true;
+			if (W == 2) {
+				uint64_t c1 = t.k1[s];
+				if (c1 == EMPTY) {
+					const uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long *>(&t.k1[s]), EMPTY, i1);
+					c1 = (prev == EMPTY) ? i1 : prev;
+				}
+				match = (c1 == i1);
+			}
+			if (match) {
+				atomicMin(reinterpret_cast<unsigned long long *>(&t.stamp[s]), stamp);
+				atomicAdd(&t.cnt[s], weight);
+				if (emask) atomicOr(&t.edges[s >> 2], emask << ((s & 3u) * 8u));
+				searching = false;
+			}
+		}
+		if (searching) s = (s + step) & (KS - 1);
+	}
+	return !searching;
+}
+
+#ifdef RG_AGG_TIMING
+static __device__ unsigned long long g_dbg[16];
+#define DBG_T(i) do { if (tid == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); dbg_acc[i] += now_ - dbg_t; dbg_t = now_; } } while (0)
+#else
+#define DBG_T(i) do {} while (0)
+#endif
+template <int W, int THREADS, int KS, int RS, bool SLOW>
+__global__ __launch_bounds__(THREADS) void k_aggregate_wg(const Rec<W> *__restrict__ recs, const unsigned long long *__restrict__ bucket_begin,
+                                                          uint32_t nbuckets, int k, Slot *__restrict__ log, uint64_t log_cap,
+                                                          unsigned long long *__restrict__ counters, uint32_t flag_unique,
+                                                          const uint32_t *__restrict__ bucket_list, uint32_t *__restrict__ retry_list, int m,
+                                                          uint32_t rbits) {
+	constexpr int NB = 2 * W;
+	constexpr uint32_t KLIMIT = KS * 5 / 8;  // a round of the expansion starts only at or below this: at most THREADS more keys arrive
+	constexpr uint32_t RLIMIT = RS / 2;
+	static_assert(KLIMIT + THREADS < KS, "the k-mer table must hold a full round above its limit");
+	static_assert((KS & (KS - 1)) == 0 && (RS & (RS - 1)) == 0 && KS <= 65536 && RS <= 65536, "table sizes");
+	__shared__ WgTables<W, KS, RS> T;
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	const uint64_t mask0 = (2 * k >= 64) ? ~0ull : ((1ull << (2 * k)) - 1);
+	const uint64_t mask1 = (k > 32) ? ((1ull << (2 * k - 64)) - 1) : 0ull;
+	unsigned long long keys_written = 0;  // thread 0 only
+	uint32_t nonunique_flushes = 0;
+	bool log_full = false;  // uniform
+	uint32_t round = 0;     // uniform: parity selects the word of T.any in use
+#ifdef RG_AGG_TIMING
+	unsigned long long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dbg_t = __builtin_readcyclecounter();
+#endif
+
+	auto clear_all = [&]() {
+		for (uint32_t i = tid; i < (uint32_t)KS; i += THREADS) {
+			T.k0[i] = EMPTY;
+			if (W == 2) T.k1[i] = EMPTY;
+			T.stamp[i] = INF_STAMP;
+			T.cnt[i] = 0;
+			if (i < (uint32_t)KS / 4) T.edges[i] = 0;
+		}
+		for (uint32_t i = tid; i < (uint32_t)RS; i += THREADS) {
+			T.rfp[i] = 0;
+			T.rcnt[i] = 0;
+			T.rstamp[i] = INF_STAMP;
+		}
+		if (tid == 0) {
+			T.kfill = 0;
+			T.rfill = 0;
+			T.rnlist = 0;
+			T.flag = 0;
+			T.any[0] = T.any[1] = 0;
+		}
+		round = 0;
+		lds_barrier();
+	};
+
+	// the k-mer table's entries go to the log; called by all threads between barriers
+	auto flush = [&]() {
+		const uint32_t n = T.kfill;
+		lds_barrier();
+		if (n == 0) return;
+		const uint64_t mark = flag_unique ? LOG_UNIQUE : 0ull;
+		if (tid == 0) {
+			const unsigned long long base = atomicAdd(&counters[PC_LOG_CURSOR], (unsigned long long)n);
+			if (base + n > log_cap) atomicAdd(&counters[PC_LOG_OVF], 1ull);
+			T.log_base = base;
+			keys_written += n;
+			if (!mark) nonunique_flushes++;
+		}
+		lds_barrier();
+		const unsigned long long base = T.log_base;
+		if (base + n > log_cap) log_full = true;  // the launch is void: this workgroup stops after this bucket
+		for (uint32_t i = tid; i < n; i += THREADS) {
+			const uint32_t sl = T.klist[i];
+			if (base + i < log_cap) {
+				Slot e;
+				e.k0 = T.k0[sl];
+				e.k1 = (W == 2) ? T.k1[sl] : EMPTY;
+				e.stamp = T.stamp[sl];
+				const uint32_t eb = (T.edges[sl >> 2] >> ((sl & 3u) * 8u)) & 0xFFu;
+				e.meta = (uint64_t)T.cnt[sl] | ((uint64_t)eb << PEND_SHIFT) | mark;
+				log[base + i] = e;
+			}
+		}
+		lds_barrier();  // every edge byte has been read before its word is cleared
+		for (uint32_t i = tid; i < n; i += THREADS) {
+			const uint32_t sl = T.klist[i];
+			T.k0[sl] = EMPTY;
+			if (W == 2) T.k1[sl] = EMPTY;
+			T.stamp[sl] = INF_STAMP;
+			T.cnt[sl] = 0;
+			T.edges[sl >> 2] = 0;
+		}
+		if (tid == 0) T.kfill = 0;
+		lds_barrier();
+	};
+
+	// every distinct record of the record table goes through the k-mer table once, weighted; of its k-mers only those
+	// of sub-pass `sub` (of `nsub`, a power of two) are taken.  Called by all threads; returns false when the k-mer
+	// table would overfill (the caller drops the attempt).  Leaves the record table empty.
+	auto expand = [&](uint32_t sub, uint32_t nsub) -> bool {
+		const uint32_t n = T.rnlist;  // settled: the callers are behind a barrier
+		for (uint32_t e0 = wave * 64u; e0 < n; e0 += THREADS) {
+			const uint32_t e = e0 + lane;
+			uint32_t rlen = 0, rsl = 0, rweight = 0;
+			uint64_t rstamp = 0;
+			if (e < n) {
+				rsl = T.rlist[e];
+				rlen = ((uint32_t)T.rtag[rsl] & 63u) + 1;
+				rweight = T.rcnt[rsl];
+				rstamp = T.rstamp[rsl];
+				T.rfp[rsl] = 0;  // the slot is free again (its words and tag stay readable: nothing is claimed during an expansion)
+				T.rcnt[rsl] = 0;
+				T.rstamp[rsl] = INF_STAMP;
+			}
+			uint32_t incl = rlen;  // inclusive prefix sums of the lengths
+#pragma unroll
+			for (int d = 1; d < 64; d <<= 1) {
+				const uint32_t o = __shfl_up(incl, d);
+				if (lane >= (uint32_t)d) incl += o;
+			}
+			const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+			const uint32_t rpre = incl - rlen;
+			for (uint32_t t0 = 0; t0 < total; t0 += 64) {
+				// the fill as this wavefront sees it now; whatever it misses is in flight and covered by the margin above the limit
+				if ((uint32_t)__builtin_amdgcn_readfirstlane((int)*(volatile uint32_t *)&T.kfill) > KLIMIT) {
+					if (lane == 0) T.flag = 2;  // the attempt is void
+					break;
+				}
+				const uint32_t t = t0 + lane;
+				uint32_t own = 0;  // number of records whose prefix sum is <= t (all lanes take part in the shuffles)
+#pragma unroll
+				for (uint32_t st = 32; st; st >>= 1) {
+					const uint32_t v = (uint32_t)__shfl((int)incl, (int)(own + st - 1));
+					if (v <= t) own += st;
+				}
+				own = own < 63u ? own : 63u;
+				const uint32_t sl = (uint32_t)__shfl((int)rsl, (int)own);
+				const uint32_t i = t - (uint32_t)__shfl((int)rpre, (int)own);
+				const uint32_t weight = (uint32_t)__shfl((int)rweight, (int)own);
+				const uint64_t stamp0 = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(rstamp >> 32), (int)own) << 32) | (uint32_t)__shfl((int)(uint32_t)rstamp, (int)own);
+				bool take = t < total;
+				uint64_t i0 = 0, i1 = 0, kstamp = 0;
+				uint32_t hx = 0, em = 0;
+				if (take) {
+					uint64_t bw[NB];
+#pragma unroll
+					for (int q = 0; q < NB; ++q) bw[q] = T.rw[q][sl];
+					const uint32_t tag = T.rtag[sl];
+					const uint32_t len = (tag & 63u) + 1, hasL = (tag >> 6) & 1u, hasR = (tag >> 7) & 1u;
+					const uint32_t pos = hasL + i;  // the k-mer's first base in the record
+					uint64_t f0, f1 = 0, r0, r1;
+					f0 = rec_ext<W>(bw, pos) & mask0;
+					if (W == 2 && k > 32) f1 = rec_ext<W>(bw, pos + 32) & mask1;
+					revcomp<W>(f0, f1, k, r0, r1);
+					const bool use_rc = kmer_less<W>(r0, r1, f0, f1);
+					if (pos > 0) {  // a k-mer precedes this one in its read
+						const uint32_t prev = rec_base<W>(bw, pos - 1);
+						em = 1u << (use_rc ? 7u - prev : prev);
+					}
+					if (i + 1 < len || hasR) {
+						const uint32_t nb = rec_base<W>(bw, pos + (uint32_t)k);
+						em |= 1u << (use_rc ? 3u - nb : 4u + nb);
+					}
+					to_internal<W>(use_rc ? r0 : f0, use_rc ? r1 : f1, i0, i1);
+					hx = agg_hash<W>(i0, i1);
+					kstamp = stamp0 + i;
+					if (SLOW && (((hx * 0x85ebca6bu) >> 16) & (nsub - 1)) != sub) take = false;  // another sub-pass owns this k-mer
+				}
+				if (!wg_upsert<W, KS, RS>(T, take, hx, i0, i1, kstamp, em, weight, lane)) T.flag = 2;  // no slot left (cannot happen below the limit): the attempt is void
+			}
+		}
+		lds_barrier();
+		const bool ok = T.flag != 2;
+		lds_barrier();
+		if (tid == 0) {
+			T.rfill = 0;
+			T.rnlist = 0;
+		}
+		lds_barrier();
+		return ok;
+	};
+
+	clear_all();
+	Rec<W> nxt;  // this thread's record of the coming round
+#pragma unroll
+	for (int i = 0; i <= NB; ++i) nxt.w[i] = 0;
+	bool prefetched = false;  // nxt holds records [cb, cb + THREADS) of the current bucket
+	uint64_t cb = 0, ce = 0;
+	if (blockIdx.x < nbuckets) {
+		const uint32_t bb = SLOW ? bucket_list[blockIdx.x] : blockIdx.x;
+		cb = bucket_begin[bb];
+		ce = bucket_begin[bb + 1];
+	}
+	for (uint32_t b = blockIdx.x; b < nbuckets && !log_full; b += gridDim.x) {
+		// the bucket after this one: its bounds are requested now, its first round of records during this bucket's last
+		uint64_t nb_begin = 0, nb_end = 0;
+		if (b + gridDim.x < nbuckets) {
+			const uint32_t bb = SLOW ? bucket_list[b + gridDim.x] : b + gridDim.x;
+			nb_begin = bucket_begin[bb];
+			nb_end = bucket_begin[bb + 1];
+		}
+		bool next_ready = false;  // nxt already holds the next bucket's first round
+		// one pass over the bucket's records for sub-pass `sub` of `nsub`; true = the k-mer table overflowed
+		auto pass = [&](uint32_t sub, uint32_t nsub) -> bool {
+			bool overflow = false;
+			const uint32_t rl = SLOW ? min(31u - (uint32_t)__clz((int)nsub), rbits) : 0u;  // record levels of the split, then hash levels
+			const uint32_t rmask = (1u << rl) - 1u, rsub = sub & rmask;
+			const uint32_t hsub = sub >> rl, hn = nsub >> rl;
+			next_ready = false;
+			if (!prefetched && cb + tid < ce) nxt = recs[cb + tid];
+			prefetched = false;
+			for (uint64_t base = cb; base < ce && !overflow; base += THREADS) {
+				const Rec<W> rec = nxt;
+				bool pending = base + tid < ce;
+				if (SLOW && rl && pending && (rec_bucket<W>(rec, m) & rmask) != rsub) pending = false;  // a record of another pass
+				if (base + THREADS < ce) {
+					if (base + THREADS + tid < ce) nxt = recs[base + THREADS + tid];
+				} else if (sub + 1 == nsub) {  // last round of the last sub-pass: the next bucket's first round
+					if (nb_begin + tid < nb_end) nxt = recs[nb_begin + tid];
+					prefetched = true;
+					next_ready = true;
+				}
+				uint64_t bw[NB], stamp0 = 0;
+				unsigned long long fp = 0;
+				uint32_t tag = 0, sl = 0, rstep = 1;
+				{
+					const uint64_t hdr = rec.w[NB];
+					tag = (uint32_t)(hdr >> 16) & 0x7FFFu;
+					stamp0 = ((hdr >> 31) << 16) | ((uint32_t)hdr & 0xFFFFu);
+					uint64_t h = (uint64_t)tag * 0x9E3779B97F4A7C15ull;
+#pragma unroll
+					for (int i = 0; i < NB; ++i) {
+						bw[i] = rec.w[i];
+						h = (h ^ bw[i]) * 0xC2B2AE3D27D4EB4Full;
+						h ^= h >> 29;
+					}
+					h *= 0xBF58476D1CE4E5B9ull;
+					h ^= h >> 32;
+					fp = h | 1ull;
+					sl = (uint32_t)(h >> 40) & (RS - 1);
+					rstep = ((uint32_t)(h >> 20) & (RS - 1)) | 1u;
+				}
+				DBG_T(0);  // load/hash
+				for (;;) {
+					bool owner = false, cand = false, searching = pending;
+					for (uint32_t probe = 0; probe < (uint32_t)RS && __any(searching); ++probe) {
+						unsigned long long cur = searching ? T.rfp[sl] : 1ull;
+						const bool empty = searching && cur == 0;
+						// a new slot needs a ticket below the limit; one atomic per wavefront hands them out
+						const uint32_t ticket = wave_claim(&T.rfill, empty, lane);
+						const bool full = empty && ticket >= RLIMIT;  // the table is at its limit: wait for the expansion
+						bool won = false;
+						if (empty && !full) {
+							cur = atomicCAS(&T.rfp[sl], 0ull, fp);
+							won = cur == 0;
+						}
+						const uint32_t back = (uint32_t)__popcll(__ballot(empty && !won));  // tickets that took no slot
+						if (back && lane == 0) atomicSub(&T.rfill, back);
+						if (won) {
+							owner = cand = true;
+							searching = false;
+						} else if (full) {
+							searching = false;
+						} else if (searching && cur == fp) {
+							cand = true;
+							searching = false;
+						} else if (searching) {
+							sl = (sl + rstep) & (RS - 1);
+						}
+					}
+					{
+						const uint32_t li = wave_claim(&T.rnlist, owner, lane);
+						if (owner) {
+#pragma unroll
+							for (int i = 0; i < NB; ++i) T.rw[i][sl] = bw[i];
+							T.rtag[sl] = (uint16_t)tag;
+							T.rlist[li] = (uint16_t)sl;
+						}
+					}
+					DBG_T(1);  // phase 1 (thread 0's wave)
+					lds_barrier();
+					DBG_T(2);  // barrier A
+					if (cand) {
+						bool same = true;
+						if (!owner) {
+							same = ((uint32_t)T.rtag[sl] == tag);
+#pragma unroll
+							for (int i = 0; i < NB; ++i) same = same && (T.rw[i][sl] == bw[i]);
+						}
+						if (same) {
+							atomicAdd(&T.rcnt[sl], 1u);
+							atomicMin(reinterpret_cast<unsigned long long *>(&T.rstamp[sl]), (unsigned long long)stamp0);
+							pending = false;
+						} else {
+							sl = (sl + rstep) & (RS - 1);  // same fingerprint, different record: keep probing
+						}
+					}
+					if (pending) T.any[round & 1u] = 1u;
+					if (tid == 0) T.any[(round + 1u) & 1u] = 0u;  // nobody reads or sets that word before the next barrier pair
+					DBG_T(3);  // phase 2
+					lds_barrier();
+					DBG_T(4);  // barrier B
+					const bool left = T.any[round & 1u] != 0u;
+					++round;
+					if (!left) break;
+					// somebody is left: the table was at its limit (or fingerprints collided)
+					if (T.rfill >= RLIMIT) {
+						lds_barrier();
+						DBG_T(0);
+						if (!expand(hsub, hn)) {
+							overflow = true;
+							break;
+						}
+						DBG_T(7);  // expansions inside the bucket
+					}
+				}
+			}
+			DBG_T(0);
+			if (!overflow) overflow = !expand(hsub, hn);
+			DBG_T(5);  // final expansion
+			return overflow;
+		};
+		if (!SLOW) {
+			if (!pass(0, 1)) {
+				flush();  // once per bucket: the entries are unique in the log
+				DBG_T(6);
+			} else {      // leave the bucket to the second launch; nothing of it was written
+				clear_all();
+				if (tid == 0) retry_list[atomicAdd(&counters[PC_AGG_RETRY], 1ull)] = b;
+				prefetched = next_ready;
+			}
+		} else {
+			// node (nsub, sub) = the k-mers whose log2(nsub) split bits equal sub; see k_aggregate
+			uint32_t nsub = 2, sub = 0;  // a listed bucket is known not to fit in one pass
+			for (;;) {
+				if (!pass(sub, nsub)) {
+					flush();
+					bool done = false;
+					for (;;) {
+						if (nsub == 1) {
+							done = true;
+							break;
+						}
+						const uint32_t top = nsub >> 1;
+						if (sub & top) {  // high half done: so is the parent
+							sub &= top - 1;
+							nsub = top;
+						} else {
+							sub |= top;
+							break;
+						}
+					}
+					if (done) break;
+					continue;
+				}
+				clear_all();  // nothing of this node was written
+				prefetched = false;
+				if ((nsub >> min(31u - (uint32_t)__clz((int)nsub), rbits)) < AGG_MAX_SUBPASSES) {
+					nsub *= 2;  // low half first: sub keeps its value
+				} else {
+					// 2^rbits x 4096 shares and one of them still holds more k-mers than the table: no input that fits the
+					// device gets here; the host then counts with the direct sweep instead (nothing wrong is ever written)
+					if (tid == 0) atomicAdd(&counters[PC_LDS_SPILL], 1ull);
+					break;
+				}
+			}
+		}
+		if (tid == 0) T.flag = 0;
+		lds_barrier();
+		cb = nb_begin;
+		ce = nb_end;
+	}
+#ifdef RG_AGG_TIMING
+	if (tid == 0)
+		for (int i = 0; i < 8; ++i) atomicAdd(&g_dbg[i], dbg_acc[i]);
+#endif
+	if (tid == 0) {
+		if (keys_written) atomicAdd(&counters[PC_LOG_KEYS], keys_written);
+		if (nonunique_flushes) atomicAdd(&counters[PC_NONUNIQUE], (unsigned long long)nonunique_flushes);
+	}
+}
+
 // Fallback of the record path: every k-mer of every record goes straight to the vertex table (one upsert per
 // occurrence), used when an estimate of the partitioned path was exceeded.
 template <int W>
