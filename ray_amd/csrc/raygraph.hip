@@ -23,6 +23,7 @@
 #include "rg_device.h"
 #include "rg_partition.h"
 #include "rg_bloom.h"
+#include "rg_table.h"
 
 using namespace rg;
 
@@ -65,7 +66,7 @@ __global__ void k_init_table(Slot *tab, uint64_t cap) {
 template <int W>
 __global__ __launch_bounds__(BLOCK) void k_count(const uint64_t *__restrict__ P, const uint64_t *__restrict__ offsets,
                                                  const uint32_t *__restrict__ lengths, uint64_t read_begin, uint64_t read_end,
-                                                 uint64_t stamp_base, int k, Slot *__restrict__ tab, uint64_t mask,
+                                                 uint64_t stamp_base, int k, Slot *__restrict__ tab, uint64_t cap,
                                                  unsigned long long *__restrict__ counters, int fill_counter) {
 	__shared__ uint32_t s_pre[TILE_READS + 1];
 	__shared__ uint64_t s_off[TILE_READS];
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(BLOCK) void k_count(const uint64_t *__restrict__ P,
 			uint64_t i0, i1;
 			to_internal<W>(K0, K1, i0, i1);
 			const uint64_t stamp = ((stamp_base + tile * TILE_READS + (uint64_t)lo) << 16) | p;
-			if (!upsert<W>(tab, mask, i0, i1, stamp, 1ull, em, claimed)) failed = true;
+			if (!upsert<W>(tab, cap, i0, i1, stamp, 1ull, em, claimed)) failed = true;
 		}
 	}
 	if (claimed) atomicAdd(&s_claimed, claimed);
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(BLOCK) void k_count(const uint64_t *__restrict__ P,
 
 // re-insert every entry of an old table into a bigger one (keys are unique: plain payload stores)
 template <int W>
-__global__ __launch_bounds__(BLOCK) void k_rehash(const Slot *__restrict__ old, uint64_t oldcap, Slot *__restrict__ tab, uint64_t mask,
+__global__ __launch_bounds__(BLOCK) void k_rehash(const Slot *__restrict__ old, uint64_t oldcap, Slot *__restrict__ tab, uint64_t cap,
                                                   unsigned long long *__restrict__ counters) {
 	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(BLOCK) void k_rehash(const Slot *__restrict__ old, 
 		Slot v = old[i];
 		if (v.k0 == EMPTY) continue;
 		uint32_t dummy = 0;
-		uint64_t s = slot_hash<W>(v.k0, v.k1) & mask;
+		uint64_t s = slot_home(slot_hash<W>(v.k0, v.k1), cap);
 		bool done = false;
 		for (uint32_t probe = 0; probe < MAX_PROBE && !done; ++probe) {
 			Slot *p = tab + s;
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(BLOCK) void k_rehash(const Slot *__restrict__ old, 
 				p->meta = v.meta;
 				done = true;
 			}
-			s = (s + 1) & mask;
+			s = slot_next(s, cap);
 		}
 		(void)dummy;
 		if (!done) failed = true;
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(BLOCK) void k_rehash(const Slot *__restrict__ old, 
 
 // receiver half of the owner exchange: merge 32-byte entries (same layout as Slot) into the table
 template <int W>
-__global__ __launch_bounds__(BLOCK) void k_merge(const Slot *__restrict__ in, uint64_t n, Slot *__restrict__ tab, uint64_t mask,
+__global__ __launch_bounds__(BLOCK) void k_merge(const Slot *__restrict__ in, uint64_t n, Slot *__restrict__ tab, uint64_t cap,
                                                  unsigned long long *__restrict__ counters) {
 	__shared__ uint32_t s_claimed;
 	if (threadIdx.x == 0) s_claimed = 0;
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(BLOCK) void k_merge(const Slot *__restrict__ in, ui
 		if (v.k0 == EMPTY) continue;  // unused entry of a log chunk
 		uint64_t add = v.meta & COUNT_MASK & ~LOG_UNIQUE;
 		uint32_t em = (uint32_t)(v.meta >> PEND_SHIFT) & 0xFFu;
-		if (!upsert<W>(tab, mask, v.k0, W == 2 ? v.k1 : 0, v.stamp, add, em, claimed, (v.meta & LOG_UNIQUE) != 0)) failed = true;
+		if (!upsert<W>(tab, cap, v.k0, W == 2 ? v.k1 : 0, v.stamp, add, em, claimed, (v.meta & LOG_UNIQUE) != 0)) failed = true;
 	}
 	if (claimed) atomicAdd(&s_claimed, claimed);
 	__syncthreads();
@@ -462,7 +463,6 @@ __device__ __forceinline__ void canonical_internal(uint64_t f0, uint64_t f1, int
 // (Kmer.cpp:176-282).  Reads only coverage of other slots, writes only its own edge byte.
 template <int W>
 __global__ __launch_bounds__(BLOCK) void k_purge(Slot *__restrict__ tab, uint64_t cap, int k) {
-	const uint64_t mask = cap - 1;
 	const uint64_t mask0 = (2 * k >= 64) ? ~0ull : ((1ull << (2 * k)) - 1);
 	const uint64_t mask1 = (k > 32) ? ((1ull << (2 * k - 64)) - 1) : 0ull;
 	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(BLOCK) void k_purge(Slot *__restrict__ tab, uint64_
 				uint64_t i0, i1;
 				bool rc;
 				canonical_internal<W>(n0, n1, k, i0, i1, rc);
-				const Slot *q = lookup<W>(tab, mask, i0, i1);
+				const Slot *q = lookup<W>(tab, cap, i0, i1);
 				if (!q || (q->meta & COUNT_MASK) == 0) keep &= ~(1u << c);
 			}
 			if (e & (1u << (4 + c))) {  // child: shift right one base, base c enters at position k-1
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(BLOCK) void k_purge(Slot *__restrict__ tab, uint64_
 				uint64_t i0, i1;
 				bool rc;
 				canonical_internal<W>(n0, n1, k, i0, i1, rc);
-				const Slot *q = lookup<W>(tab, mask, i0, i1);
+				const Slot *q = lookup<W>(tab, cap, i0, i1);
 				if (!q || (q->meta & COUNT_MASK) == 0) keep &= ~(1u << (4 + c));
 			}
 		}
@@ -575,7 +575,7 @@ __global__ __launch_bounds__(BLOCK) void k_pack_reads(const uint8_t *__restrict_
 template <int W>
 __global__ __launch_bounds__(256) void k_read_markers(const uint64_t *__restrict__ P, const uint64_t *__restrict__ offsets,
                                                       const uint32_t *__restrict__ lengths, uint64_t nreads, int k,
-                                                      const Slot *__restrict__ tab, uint64_t mask,
+                                                      const Slot *__restrict__ tab, uint64_t cap,
                                                       int32_t *__restrict__ forward, int32_t *__restrict__ reverse) {
 	__shared__ uint32_t s_le[4][10], s_ge[4][10], s_first[4][10], s_last[4][10];
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(256) void k_read_markers(const uint64_t *__restrict
 			uint64_t i0, i1;
 			bool rc;
 			canonical_internal<W>(f0, f1, k, i0, i1, rc);
-			const Slot *q = lookup<W>(tab, mask, i0, i1);
+			const Slot *q = lookup<W>(tab, cap, i0, i1);
 			// the reference compares the coverage as an int (IndexerWorker.cpp:92)
 			const int cov = q ? (int)(uint32_t)(q->meta & COUNT_MASK) : 0;
 #pragma unroll
@@ -654,7 +654,7 @@ __global__ __launch_bounds__(256) void k_read_markers(const uint64_t *__restrict
 // Vertex::load for a whole checkpoint (Vertex.cpp:422-436, MessageProcessor.cpp:596-655): records in Vertex::dump
 // layout go straight into the table with their coverage and edge byte
 template <int W>
-__global__ __launch_bounds__(BLOCK) void k_import(const uint8_t *__restrict__ rec, uint64_t n, Slot *__restrict__ tab, uint64_t mask,
+__global__ __launch_bounds__(BLOCK) void k_import(const uint8_t *__restrict__ rec, uint64_t n, Slot *__restrict__ tab, uint64_t cap,
                                                   unsigned long long *__restrict__ counters) {
 	constexpr int REC = W * 8 + 5;
 	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -673,7 +673,7 @@ __global__ __launch_bounds__(BLOCK) void k_import(const uint8_t *__restrict__ re
 		uint64_t i0, i1;
 		to_internal<W>(K0, K1, i0, i1);
 		// the keys of a checkpoint are distinct: claim a free slot and store the payload plainly (as k_rehash does)
-		uint64_t sl = slot_hash<W>(i0, W == 2 ? i1 : 0) & mask;
+		uint64_t sl = slot_home(slot_hash<W>(i0, W == 2 ? i1 : 0), cap);
 		bool done = false;
 		for (uint32_t probe = 0; probe < MAX_PROBE && !done; ++probe) {
 			Slot *q = tab + sl;
@@ -685,7 +685,7 @@ __global__ __launch_bounds__(BLOCK) void k_import(const uint8_t *__restrict__ re
 				claimed++;
 				done = true;
 			}
-			sl = (sl + 1) & mask;
+			sl = slot_next(sl, cap);
 		}
 		if (!done) failed = true;
 	}
@@ -697,7 +697,7 @@ __global__ __launch_bounds__(BLOCK) void k_import(const uint8_t *__restrict__ re
 // (the admission ran on the log itself), so a slot is claimed and the payload stored plainly; entries that were
 // not admitted (coverage 0) never reach the table -- like the reference, whose Bloom filter stands before its table.
 template <int W>
-__global__ __launch_bounds__(BLOCK) void k_insert_admitted(const Slot *__restrict__ log, uint64_t n, Slot *__restrict__ tab, uint64_t mask,
+__global__ __launch_bounds__(BLOCK) void k_insert_admitted(const Slot *__restrict__ log, uint64_t n, Slot *__restrict__ tab, uint64_t cap,
                                                            unsigned long long *__restrict__ counters) {
 	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -706,7 +706,7 @@ __global__ __launch_bounds__(BLOCK) void k_insert_admitted(const Slot *__restric
 	for (; i < n; i += stride) {
 		const Slot v = log[i];
 		if (v.k0 == EMPTY || (v.meta & COUNT_MASK) == 0) continue;
-		uint64_t sl = slot_hash<W>(v.k0, W == 2 ? v.k1 : 0) & mask;
+		uint64_t sl = slot_home(slot_hash<W>(v.k0, W == 2 ? v.k1 : 0), cap);
 		bool done = false;
 		for (uint32_t probe = 0; probe < MAX_PROBE && !done; ++probe) {
 			Slot *q = tab + sl;
@@ -717,7 +717,7 @@ __global__ __launch_bounds__(BLOCK) void k_insert_admitted(const Slot *__restric
 				claimed++;
 				done = true;
 			}
-			sl = (sl + 1) & mask;
+			sl = slot_next(sl, cap);
 		}
 		if (!done) failed = true;
 	}
@@ -785,12 +785,12 @@ __global__ __launch_bounds__(BLOCK) void k_purge_queries(const Slot *__restrict_
 
 // the owner's side of RAY_MPI_TAG_REQUEST_VERTEX_COVERAGE (MessageProcessor.cpp:1224-1256): 1 = stored, 0 = not
 template <int W>
-__global__ __launch_bounds__(BLOCK) void k_purge_answer(const Slot *__restrict__ tab, uint64_t mask, const uint64_t *__restrict__ keys,
+__global__ __launch_bounds__(BLOCK) void k_purge_answer(const Slot *__restrict__ tab, uint64_t cap, const uint64_t *__restrict__ keys,
                                                         uint64_t n, uint8_t *__restrict__ answers) {
 	uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
 	for (; q < n; q += stride) {
-		const Slot *p = lookup<W>(tab, mask, keys[q * W], W == 2 ? keys[q * W + 1] : 0);
+		const Slot *p = lookup<W>(tab, cap, keys[q * W], W == 2 ? keys[q * W + 1] : 0);
 		answers[q] = (p && (p->meta & COUNT_MASK) != 0) ? 1 : 0;
 	}
 }
@@ -811,7 +811,6 @@ __global__ __launch_bounds__(BLOCK) void k_purge_apply(Slot *__restrict__ tab, c
 template <int W>
 __global__ __launch_bounds__(BLOCK) void k_find(const Slot *__restrict__ tab, uint64_t cap, int k, const uint64_t *__restrict__ q,
                                                 uint64_t n, uint32_t *__restrict__ cov, uint8_t *__restrict__ edges, uint32_t edge_mask) {
-	const uint64_t mask = cap - 1;
 	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
 	for (; i < n; i += stride) {
@@ -819,7 +818,7 @@ __global__ __launch_bounds__(BLOCK) void k_find(const Slot *__restrict__ tab, ui
 		uint64_t i0, i1;
 		bool rc;
 		canonical_internal<W>(f0, f1, k, i0, i1, rc);
-		const Slot *s = lookup<W>(tab, mask, i0, i1);
+		const Slot *s = lookup<W>(tab, cap, i0, i1);
 		uint32_t c = 0, e = 0;
 		if (s) {
 			c = (uint32_t)(s->meta & COUNT_MASK);
@@ -1155,8 +1154,8 @@ static int table_reserve(rg_handle *h, Table &t, uint64_t need, int fill_counter
 	Table bigger;
 	rc = table_alloc(h, bigger, cap);
 	if (rc) return rc;
-	if (h->W == 1) hipLaunchKernelGGL(k_rehash<1>, dim3(grid_for(t.cap)), dim3(BLOCK), 0, h->stream, t.slots, t.cap, bigger.slots, cap - 1, h->d_counters);
-	else hipLaunchKernelGGL(k_rehash<2>, dim3(grid_for(t.cap)), dim3(BLOCK), 0, h->stream, t.slots, t.cap, bigger.slots, cap - 1, h->d_counters);
+	if (h->W == 1) hipLaunchKernelGGL(k_rehash<1>, dim3(grid_for(t.cap)), dim3(BLOCK), 0, h->stream, t.slots, t.cap, bigger.slots, cap, h->d_counters);
+	else hipLaunchKernelGGL(k_rehash<2>, dim3(grid_for(t.cap)), dim3(BLOCK), 0, h->stream, t.slots, t.cap, bigger.slots, cap, h->d_counters);
 	HIP_TRY(h, hipGetLastError());
 	HIP_TRY(h, hipStreamSynchronize(h->stream));
 	pool_free(h->cfg.device, t.slots);
@@ -1938,8 +1937,8 @@ static int materialize_pending_log(rg_handle *h) {
 	if (rc) return rc;
 	{
 		ProfScope ps(h, "k_merge");
-		if (h->W == 1) hipLaunchKernelGGL(k_merge<1>, dim3(grid_for(h->pending_n)), dim3(BLOCK), 0, h->stream, h->pending_log, h->pending_n, T.slots, T.cap - 1, h->d_counters);
-		else hipLaunchKernelGGL(k_merge<2>, dim3(grid_for(h->pending_n)), dim3(BLOCK), 0, h->stream, h->pending_log, h->pending_n, T.slots, T.cap - 1, h->d_counters);
+		if (h->W == 1) hipLaunchKernelGGL(k_merge<1>, dim3(grid_for(h->pending_n)), dim3(BLOCK), 0, h->stream, h->pending_log, h->pending_n, T.slots, T.cap, h->d_counters);
+		else hipLaunchKernelGGL(k_merge<2>, dim3(grid_for(h->pending_n)), dim3(BLOCK), 0, h->stream, h->pending_log, h->pending_n, T.slots, T.cap, h->d_counters);
 	}
 	if (hipGetLastError() != hipSuccess) return fail(h, RG_ERR_HIP, "k_merge launch failed");
 	rc = sync_counters(h);
@@ -1978,6 +1977,190 @@ static int collect_histogram(rg_handle *h, const unsigned long long *dense, cons
 		i = e2;
 	}
 	h->hist_valid = true;
+	return RG_OK;
+}
+
+// ---- the vertex table from the admitted entries of a log, range by range (rg_table.h) ---------------------
+// *done = false: not applicable (too few entries, no memory, overflow list full); the caller then inserts the classic way.
+static int build_table_ranges(rg_handle *h, const Slot *log, uint64_t n_log, uint64_t retained, bool *done) {
+	*done = false;
+	const int dev = h->cfg.device;
+	Table &T = h->tab;
+	if (T.slots || retained == 0 || n_log == 0) return RG_OK;
+	uint64_t cap = (uint64_t)((double)retained / 0.7) + 1;
+	if (cap < 4096) cap = 4096;
+	if (h->cfg.table_slots > cap) cap = h->cfg.table_slots;
+	// ranges of 2048 slots while two partition levels reach them, of 4096 beyond
+	int span_log2 = 11;
+	if (((cap + 2047) >> 11) > 65536) span_log2 = 12;
+	const uint64_t NR = (cap + (1ull << span_log2) - 1) >> span_log2;
+	if (NR >= (1ull << 24)) return RG_OK;
+	int bits = 1;
+	while ((1ull << bits) < NR) bits++;
+	const int nlev = bits <= 8 ? 1 : (bits <= 16 ? 2 : 3);
+	int dbits[3] = {0, 0, 0};
+	for (int l = 0, left = bits; l < nlev; ++l) {
+		dbits[l] = left / (nlev - l);
+		left -= dbits[l];
+	}
+	const uint64_t NBUCK = 1ull << bits;
+	Slot *tab = nullptr, *buf[2] = {nullptr, nullptr}, *ovf = nullptr;
+	unsigned long long *d_seg = nullptr, *d_hist = nullptr, *d_begin = nullptr, *d_sums = nullptr;
+	uint32_t *d_tile = nullptr;
+	uint8_t *d_side = nullptr;
+	const uint64_t ovf_cap = retained / 16 + 4096;
+	auto cleanup = [&]() {
+		pool_free(dev, buf[0]);
+		pool_free(dev, buf[1]);
+		pool_free(dev, ovf);
+		pool_free(dev, d_seg);
+		pool_free(dev, d_hist);
+		pool_free(dev, d_begin);
+		pool_free(dev, d_sums);
+		pool_free(dev, d_tile);
+		pool_free(dev, d_side);
+	};
+	const uint64_t SEGMAX = 65536;
+	hipError_t e = pool_alloc(dev, (void **)&tab, cap * sizeof(Slot));
+	if (e == hipSuccess) e = pool_alloc(dev, (void **)&buf[0], retained * sizeof(Slot));
+	if (e == hipSuccess && nlev > 1) e = pool_alloc(dev, (void **)&buf[1], retained * sizeof(Slot));
+	if (e == hipSuccess) e = pool_alloc(dev, (void **)&ovf, ovf_cap * sizeof(Slot));
+	if (e == hipSuccess) e = pool_alloc(dev, (void **)&d_seg, (SEGMAX + 1) * sizeof(unsigned long long));
+	if (e == hipSuccess) e = pool_alloc(dev, (void **)&d_tile, (SEGMAX + 1) * sizeof(uint32_t));
+	if (e == hipSuccess) e = pool_alloc(dev, (void **)&d_hist, NBUCK * sizeof(unsigned long long));
+	if (e == hipSuccess) e = pool_alloc(dev, (void **)&d_begin, (NBUCK + 1) * sizeof(unsigned long long));
+	if (e == hipSuccess) e = pool_alloc(dev, (void **)&d_sums, (NBUCK / SCAN_PER_BLOCK + 2) * sizeof(unsigned long long));
+	if (e == hipSuccess && nlev > 1) e = pool_alloc(dev, (void **)&d_side, retained);
+	if (e != hipSuccess) {  // not enough memory for the partition buffers: the classic insert needs none
+		(void)hipGetLastError();
+		cleanup();
+		pool_free(dev, tab);
+		return RG_OK;
+	}
+#define TTRY(call)                                                                                          \
+	do {                                                                                                    \
+		hipError_t e_ = (call);                                                                             \
+		if (e_ != hipSuccess) {                                                                             \
+			cleanup();                                                                                      \
+			pool_free(dev, tab);                                                                            \
+			return fail(h, e_ == hipErrorOutOfMemory ? RG_ERR_NOMEM : RG_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+		}                                                                                                   \
+	} while (0)
+	TTRY(hipMemsetAsync(h->d_counters + TC_OVF_CURSOR, 0, 2 * sizeof(unsigned long long), h->stream));
+	TTRY(hipMemsetAsync(h->d_counters + C_FILL, 0, sizeof(unsigned long long), h->stream));
+	std::vector<unsigned long long> seg_begin = {0, n_log};
+	std::vector<uint32_t> tile_first;
+	const Slot *level_in = log;
+	int used_bits = 0, cur = 0;
+	for (int level = 0; level < nlev; ++level) {
+		const uint32_t S = (uint32_t)seg_begin.size() - 1;
+		const int db = dbits[level];
+		const int shift = bits - used_bits - db;
+		tile_first.assign(S + 1, 0);
+		uint64_t ntiles = 0;
+		for (uint32_t sgi = 0; sgi < S; ++sgi) {
+			tile_first[sgi] = (uint32_t)ntiles;
+			ntiles += (seg_begin[sgi + 1] - seg_begin[sgi] + ENT_TILE - 1) / ENT_TILE;
+		}
+		tile_first[S] = (uint32_t)ntiles;
+		TTRY(hipMemcpyAsync(d_seg, seg_begin.data(), (S + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
+		TTRY(hipMemcpyAsync(d_tile, tile_first.data(), (S + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+		const uint64_t nout = (uint64_t)S << db;
+		TTRY(hipMemsetAsync(d_hist, 0, nout * sizeof(unsigned long long), h->stream));
+		if (level == 0) {
+			ProfScope ps(h, "k_entry_hist");
+			const int grid = (int)std::min<uint64_t>(2048, (n_log + 255) / 256);
+			if (h->W == 1) hipLaunchKernelGGL(k_entry_hist<1>, dim3(grid), dim3(256), 0, h->stream, log, n_log, cap, span_log2, shift, (1u << db) - 1u, d_hist);
+			else hipLaunchKernelGGL(k_entry_hist<2>, dim3(grid), dim3(256), 0, h->stream, log, n_log, cap, span_log2, shift, (1u << db) - 1u, d_hist);
+		} else {
+			ProfScope ps(h, "k_level_hist_side");
+			hipLaunchKernelGGL(k_level_hist_side<ENT_TILE>, dim3((unsigned)ntiles), dim3(256), 0, h->stream, d_side, S, d_seg, d_tile, db, d_hist);
+		}
+		TTRY(hipGetLastError());
+		const uint32_t nblk = (uint32_t)((nout + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK);
+		hipLaunchKernelGGL(k_scan_local, dim3(nblk), dim3(256), 0, h->stream, d_hist, d_begin, nout, d_sums);
+		hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(64), 0, h->stream, d_sums, nblk, d_sums + nblk);
+		hipLaunchKernelGGL(k_scan_add, dim3(nblk), dim3(256), 0, h->stream, d_begin, nout, d_sums, d_sums + nblk, d_hist);
+		TTRY(hipGetLastError());
+		{
+			ProfScope ps(h, "k_scatter_entries");
+			const bool have_next = level + 1 < nlev;
+			const int ndb = have_next ? dbits[level + 1] : 0;
+			uint8_t *side_out = have_next ? d_side : nullptr;
+			Slot *out = buf[cur];
+			if (h->W == 1) {
+				if (level == 0) hipLaunchKernelGGL((k_scatter_entries<1, true>), dim3((unsigned)ntiles), dim3(ENT_THREADS), 0, h->stream, level_in, S, d_seg, d_tile, cap, span_log2, shift, db, d_hist, out, side_out, shift - ndb, (1u << ndb) - 1u);
+				else hipLaunchKernelGGL((k_scatter_entries<1, false>), dim3((unsigned)ntiles), dim3(ENT_THREADS), 0, h->stream, level_in, S, d_seg, d_tile, cap, span_log2, shift, db, d_hist, out, side_out, shift - ndb, (1u << ndb) - 1u);
+			} else {
+				if (level == 0) hipLaunchKernelGGL((k_scatter_entries<2, true>), dim3((unsigned)ntiles), dim3(ENT_THREADS), 0, h->stream, level_in, S, d_seg, d_tile, cap, span_log2, shift, db, d_hist, out, side_out, shift - ndb, (1u << ndb) - 1u);
+				else hipLaunchKernelGGL((k_scatter_entries<2, false>), dim3((unsigned)ntiles), dim3(ENT_THREADS), 0, h->stream, level_in, S, d_seg, d_tile, cap, span_log2, shift, db, d_hist, out, side_out, shift - ndb, (1u << ndb) - 1u);
+			}
+		}
+		TTRY(hipGetLastError());
+		used_bits += db;
+		level_in = buf[cur];
+		cur ^= 1;
+		if (level + 1 < nlev) {
+			seg_begin.resize(nout + 1);
+			TTRY(hipMemcpyAsync(seg_begin.data(), d_begin, (nout + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+			TTRY(hipStreamSynchronize(h->stream));
+			if (seg_begin[nout] != retained) {
+				cleanup();
+				pool_free(dev, tab);
+				return fail(h, RG_ERR_STATE, "table partition level %d holds %llu of %llu admitted entries", level, seg_begin[nout], (unsigned long long)retained);
+			}
+		}
+	}
+	{
+		ProfScope ps(h, "k_build_ranges");
+		int n_cu = 256;
+		(void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+		if (span_log2 == 11) {
+			const unsigned grid = (unsigned)std::min<uint64_t>(NR, (uint64_t)n_cu * 2);
+			if (h->W == 1) hipLaunchKernelGGL((k_build_ranges<1, 11>), dim3(grid), dim3(1024), 0, h->stream, level_in, d_begin, (uint32_t)NR, tab, cap, ovf, ovf_cap, h->d_counters);
+			else hipLaunchKernelGGL((k_build_ranges<2, 11>), dim3(grid), dim3(1024), 0, h->stream, level_in, d_begin, (uint32_t)NR, tab, cap, ovf, ovf_cap, h->d_counters);
+		} else {
+			const unsigned grid = (unsigned)std::min<uint64_t>(NR, (uint64_t)n_cu);
+			if (h->W == 1) hipLaunchKernelGGL((k_build_ranges<1, 12>), dim3(grid), dim3(1024), 0, h->stream, level_in, d_begin, (uint32_t)NR, tab, cap, ovf, ovf_cap, h->d_counters);
+			else hipLaunchKernelGGL((k_build_ranges<2, 12>), dim3(grid), dim3(1024), 0, h->stream, level_in, d_begin, (uint32_t)NR, tab, cap, ovf, ovf_cap, h->d_counters);
+		}
+	}
+	TTRY(hipGetLastError());
+	int rc = sync_counters(h);
+	if (rc) {
+		cleanup();
+		pool_free(dev, tab);
+		return rc;
+	}
+	const uint64_t n_ovf = h->h_counters[TC_OVF_CURSOR];
+	if (h->h_counters[TC_OVF_LOST]) {  // more entries left their range than the list holds (never seen): build the classic way
+		cleanup();
+		pool_free(dev, tab);
+		TTRY(hipMemsetAsync(h->d_counters + C_FILL, 0, sizeof(unsigned long long), h->stream));
+		return RG_OK;
+	}
+	if (n_ovf) {
+		ProfScope ps(h, "k_insert_admitted");
+		if (h->W == 1) hipLaunchKernelGGL(k_insert_admitted<1>, dim3(grid_for(n_ovf)), dim3(BLOCK), 0, h->stream, ovf, n_ovf, tab, cap, h->d_counters);
+		else hipLaunchKernelGGL(k_insert_admitted<2>, dim3(grid_for(n_ovf)), dim3(BLOCK), 0, h->stream, ovf, n_ovf, tab, cap, h->d_counters);
+		TTRY(hipGetLastError());
+		rc = sync_counters(h);
+		if (rc) {
+			cleanup();
+			pool_free(dev, tab);
+			return rc;
+		}
+	}
+	if (getenv("RG_DEBUG"))
+		fprintf(stderr, "[raygraph] table of %llu slots built from %llu admitted entries in %llu ranges of %u slots (%d partition levels), %llu entries left their range\n",
+		        (unsigned long long)cap, (unsigned long long)retained, (unsigned long long)NR, 1u << span_log2, nlev, (unsigned long long)n_ovf);
+	cleanup();
+	T.slots = tab;
+	T.cap = cap;
+	T.fill_known = h->h_counters[C_FILL];
+	T.fill_pending = 0;
+	*done = true;
+#undef TTRY
 	return RG_OK;
 }
 
@@ -2149,8 +2332,8 @@ int rg_count_local(rg_handle *h) {
 					rc = table_reserve(h, T, n_log ? n_log : 1, fill_counter);
 					if (rc == RG_OK && n_log) {
 						ProfScope ps(h, "k_merge");
-						if (h->W == 1) hipLaunchKernelGGL(k_merge<1>, dim3(grid_for(n_log)), dim3(BLOCK), 0, h->stream, log, n_log, T.slots, T.cap - 1, h->d_counters);
-						else hipLaunchKernelGGL(k_merge<2>, dim3(grid_for(n_log)), dim3(BLOCK), 0, h->stream, log, n_log, T.slots, T.cap - 1, h->d_counters);
+						if (h->W == 1) hipLaunchKernelGGL(k_merge<1>, dim3(grid_for(n_log)), dim3(BLOCK), 0, h->stream, log, n_log, T.slots, T.cap, h->d_counters);
+						else hipLaunchKernelGGL(k_merge<2>, dim3(grid_for(n_log)), dim3(BLOCK), 0, h->stream, log, n_log, T.slots, T.cap, h->d_counters);
 						if (hipGetLastError() != hipSuccess) rc = fail(h, RG_ERR_HIP, "k_merge launch failed");
 					}
 					if (rc == RG_OK) rc = sync_counters(h);
@@ -2189,10 +2372,10 @@ int rg_count_local(rg_handle *h) {
 			ProfScope ps(h, "k_count");
 			if (h->W == 1)
 				hipLaunchKernelGGL(k_count<1>, dim3(grid), dim3(BLOCK), 0, h->stream, b.d_packed, b.d_off, b.d_len, r0, r1,
-				                   b.first_id + r0, k, T.slots, T.cap - 1, h->d_counters, fill_counter);
+				                   b.first_id + r0, k, T.slots, T.cap, h->d_counters, fill_counter);
 			else
 				hipLaunchKernelGGL(k_count<2>, dim3(grid), dim3(BLOCK), 0, h->stream, b.d_packed, b.d_off, b.d_len, r0, r1,
-				                   b.first_id + r0, k, T.slots, T.cap - 1, h->d_counters, fill_counter);
+				                   b.first_id + r0, k, T.slots, T.cap, h->d_counters, fill_counter);
 			HIP_TRY(h, hipGetLastError());
 			T.fill_pending += bound;
 		}
@@ -2272,8 +2455,8 @@ int rg_count_records(rg_handle *h, const void *d_records, uint64_t n_records) {
 		if (rc) return rc;
 		if (n_records) {
 			ProfScope ps(h, "k_count_records");
-			if (h->W == 1) hipLaunchKernelGGL(k_count_records<1>, dim3(grid_for(n_records)), dim3(256), 0, h->stream, (const Rec<1> *)d_records, n_records, h->cfg.k, h->local.slots, h->local.cap - 1, h->d_counters, (int)C_FILL_LOCAL);
-			else hipLaunchKernelGGL(k_count_records<2>, dim3(grid_for(n_records)), dim3(256), 0, h->stream, (const Rec<2> *)d_records, n_records, h->cfg.k, h->local.slots, h->local.cap - 1, h->d_counters, (int)C_FILL_LOCAL);
+			if (h->W == 1) hipLaunchKernelGGL(k_count_records<1>, dim3(grid_for(n_records)), dim3(256), 0, h->stream, (const Rec<1> *)d_records, n_records, h->cfg.k, h->local.slots, h->local.cap, h->d_counters, (int)C_FILL_LOCAL);
+			else hipLaunchKernelGGL(k_count_records<2>, dim3(grid_for(n_records)), dim3(256), 0, h->stream, (const Rec<2> *)d_records, n_records, h->cfg.k, h->local.slots, h->local.cap, h->d_counters, (int)C_FILL_LOCAL);
 			HIP_TRY(h, hipGetLastError());
 		}
 		rc = sync_counters(h);
@@ -2382,8 +2565,8 @@ int rg_merge_entries(rg_handle *h, const void *d_entries, uint64_t n_entries) {
 	int rc = table_reserve(h, h->tab, n_entries, C_FILL);
 	if (rc) return rc;
 	ProfScope ps(h, "k_merge");
-	if (h->W == 1) hipLaunchKernelGGL(k_merge<1>, dim3(grid_for(n_entries)), dim3(BLOCK), 0, h->stream, (const Slot *)d_entries, n_entries, h->tab.slots, h->tab.cap - 1, h->d_counters);
-	else hipLaunchKernelGGL(k_merge<2>, dim3(grid_for(n_entries)), dim3(BLOCK), 0, h->stream, (const Slot *)d_entries, n_entries, h->tab.slots, h->tab.cap - 1, h->d_counters);
+	if (h->W == 1) hipLaunchKernelGGL(k_merge<1>, dim3(grid_for(n_entries)), dim3(BLOCK), 0, h->stream, (const Slot *)d_entries, n_entries, h->tab.slots, h->tab.cap, h->d_counters);
+	else hipLaunchKernelGGL(k_merge<2>, dim3(grid_for(n_entries)), dim3(BLOCK), 0, h->stream, (const Slot *)d_entries, n_entries, h->tab.slots, h->tab.cap, h->d_counters);
 	HIP_TRY(h, hipGetLastError());
 	h->tab.fill_pending += n_entries;
 	HIP_TRY(h, hipStreamSynchronize(h->stream));  // the caller may now reuse d_entries
@@ -2493,11 +2676,15 @@ int rg_resolve_admission(rg_handle *h, uint64_t local_reads_for_bloom) {
 	if (from_log) {
 		candidates = h->pending_keys;
 		const uint64_t retained = h->h_counters[C_RETAINED];
-		rc = table_reserve(h, h->tab, std::max<uint64_t>(1, retained), C_FILL);
-		if (rc == RG_OK) {
+		// the table range by range, without global atomics (cfg.reserved0 bit 22 forces it on small inputs, bit 23 never: tests)
+		bool built = false;
+		if (!(h->cfg.reserved0 & 0x800000) && (retained >= (1ull << 20) || (h->cfg.reserved0 & 0x400000)))
+			rc = build_table_ranges(h, h->pending_log, h->pending_n, retained, &built);
+		if (rc == RG_OK && !built) rc = table_reserve(h, h->tab, std::max<uint64_t>(1, retained), C_FILL);
+		if (rc == RG_OK && !built) {
 			ProfScope ps(h, "k_insert_admitted");
-			if (h->W == 1) hipLaunchKernelGGL(k_insert_admitted<1>, dim3(grid_for(h->pending_n)), dim3(BLOCK), 0, h->stream, h->pending_log, h->pending_n, h->tab.slots, h->tab.cap - 1, h->d_counters);
-			else hipLaunchKernelGGL(k_insert_admitted<2>, dim3(grid_for(h->pending_n)), dim3(BLOCK), 0, h->stream, h->pending_log, h->pending_n, h->tab.slots, h->tab.cap - 1, h->d_counters);
+			if (h->W == 1) hipLaunchKernelGGL(k_insert_admitted<1>, dim3(grid_for(h->pending_n)), dim3(BLOCK), 0, h->stream, h->pending_log, h->pending_n, h->tab.slots, h->tab.cap, h->d_counters);
+			else hipLaunchKernelGGL(k_insert_admitted<2>, dim3(grid_for(h->pending_n)), dim3(BLOCK), 0, h->stream, h->pending_log, h->pending_n, h->tab.slots, h->tab.cap, h->d_counters);
 			if (hipGetLastError() != hipSuccess) rc = fail(h, RG_ERR_HIP, "k_insert_admitted launch failed");
 		}
 		if (rc == RG_OK) rc = sync_counters(h);
@@ -2647,8 +2834,8 @@ int rg_purge_answer(rg_handle *h, const void *d_queries, uint64_t n, uint8_t *d_
 	HIP_TRY(h, hipSetDevice(h->cfg.device));
 	{
 		ProfScope ps(h, "k_purge_answer");
-		if (h->W == 1) hipLaunchKernelGGL(k_purge_answer<1>, dim3(grid_for(n)), dim3(BLOCK), 0, h->stream, h->tab.slots, h->tab.cap - 1, (const uint64_t *)d_queries, n, d_answers);
-		else hipLaunchKernelGGL(k_purge_answer<2>, dim3(grid_for(n)), dim3(BLOCK), 0, h->stream, h->tab.slots, h->tab.cap - 1, (const uint64_t *)d_queries, n, d_answers);
+		if (h->W == 1) hipLaunchKernelGGL(k_purge_answer<1>, dim3(grid_for(n)), dim3(BLOCK), 0, h->stream, h->tab.slots, h->tab.cap, (const uint64_t *)d_queries, n, d_answers);
+		else hipLaunchKernelGGL(k_purge_answer<2>, dim3(grid_for(n)), dim3(BLOCK), 0, h->stream, h->tab.slots, h->tab.cap, (const uint64_t *)d_queries, n, d_answers);
 	}
 	HIP_TRY(h, hipGetLastError());
 	HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -2915,8 +3102,8 @@ int rg_read_markers(rg_handle *h, int32_t *d_forward, int32_t *d_reverse) {
 		if (b.n == 0) continue;
 		ProfScope ps(h, "k_read_markers");
 		const unsigned grid = (unsigned)std::min<uint64_t>((b.n + 3) / 4, 65536);
-		if (h->W == 1) hipLaunchKernelGGL(k_read_markers<1>, dim3(grid), dim3(256), 0, h->stream, b.d_packed, b.d_off, b.d_len, b.n, h->cfg.k, h->tab.slots, h->tab.cap - 1, d_forward + done, d_reverse + done);
-		else hipLaunchKernelGGL(k_read_markers<2>, dim3(grid), dim3(256), 0, h->stream, b.d_packed, b.d_off, b.d_len, b.n, h->cfg.k, h->tab.slots, h->tab.cap - 1, d_forward + done, d_reverse + done);
+		if (h->W == 1) hipLaunchKernelGGL(k_read_markers<1>, dim3(grid), dim3(256), 0, h->stream, b.d_packed, b.d_off, b.d_len, b.n, h->cfg.k, h->tab.slots, h->tab.cap, d_forward + done, d_reverse + done);
+		else hipLaunchKernelGGL(k_read_markers<2>, dim3(grid), dim3(256), 0, h->stream, b.d_packed, b.d_off, b.d_len, b.n, h->cfg.k, h->tab.slots, h->tab.cap, d_forward + done, d_reverse + done);
 		HIP_TRY(h, hipGetLastError());
 		done += b.n;
 	}
@@ -2937,8 +3124,8 @@ int rg_import_vertices(rg_handle *h, const void *records, uint64_t n_pairs) {
 		HIP_TRY(h, pool_alloc(h->cfg.device, (void **)&d, bytes));
 		hipError_t e = hipMemcpyAsync(d, records, bytes, hipMemcpyHostToDevice, h->stream);
 		if (e == hipSuccess) {
-			if (h->W == 1) hipLaunchKernelGGL(k_import<1>, dim3(grid_for(n_pairs)), dim3(BLOCK), 0, h->stream, d, n_pairs, h->tab.slots, h->tab.cap - 1, h->d_counters);
-			else hipLaunchKernelGGL(k_import<2>, dim3(grid_for(n_pairs)), dim3(BLOCK), 0, h->stream, d, n_pairs, h->tab.slots, h->tab.cap - 1, h->d_counters);
+			if (h->W == 1) hipLaunchKernelGGL(k_import<1>, dim3(grid_for(n_pairs)), dim3(BLOCK), 0, h->stream, d, n_pairs, h->tab.slots, h->tab.cap, h->d_counters);
+			else hipLaunchKernelGGL(k_import<2>, dim3(grid_for(n_pairs)), dim3(BLOCK), 0, h->stream, d, n_pairs, h->tab.slots, h->tab.cap, h->d_counters);
 			e = hipGetLastError();
 		}
 		rc = (e == hipSuccess) ? sync_counters(h) : fail(h, RG_ERR_HIP, "rg_import_vertices: %s", hipGetErrorString(e));

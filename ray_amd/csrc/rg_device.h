@@ -105,6 +105,18 @@ __host__ __device__ inline uint64_t slot_hash(uint64_t i0, uint64_t i1) {
 	return h;
 }
 
+// home slot of a hash in a table of `cap` slots (any capacity, not only powers of two): the top bits decide, so
+// keys in hash order are in slot order and a contiguous range of slots belongs to a contiguous range of hashes
+// (the table is built range by range from entries partitioned by their hash, raygraph.hip: k_build_ranges)
+__host__ __device__ inline uint64_t slot_home(uint64_t hash, uint64_t cap) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	return __umul64hi(hash, cap);
+#else
+	return (uint64_t)(((unsigned __int128)hash * cap) >> 64);
+#endif
+}
+__host__ __device__ inline uint64_t slot_next(uint64_t s, uint64_t cap) { return s + 1 == cap ? 0 : s + 1; }
+
 // ---- k-mer arithmetic ----------------------------------------------------------------------------
 // reverse the order of the 32 two-bit groups of a word
 __device__ __forceinline__ uint64_t rev2(uint64_t x) {
@@ -164,9 +176,9 @@ __host__ __device__ inline uint32_t convert_bitmap(uint32_t m) {
 // with atomics.  Every decision taken on a plain (possibly stale) load is safe: a key word only ever
 // changes EMPTY -> key, stamps only fall, edge bits only rise; a stale EMPTY is settled by the CAS.
 template <int W>
-__device__ __forceinline__ bool upsert(Slot *__restrict__ tab, uint64_t mask, uint64_t i0, uint64_t i1,
+__device__ __forceinline__ bool upsert(Slot *__restrict__ tab, uint64_t cap, uint64_t i0, uint64_t i1,
                                        uint64_t stamp, uint64_t add, uint32_t emask, uint32_t &claimed, bool unique = false) {
-	uint64_t s = slot_hash<W>(i0, i1) & mask;
+	uint64_t s = slot_home(slot_hash<W>(i0, i1), cap);
 	for (uint32_t probe = 0; probe < MAX_PROBE; ++probe) {
 		Slot *p = tab + s;
 		ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(&p->k0);
@@ -208,21 +220,21 @@ __device__ __forceinline__ bool upsert(Slot *__restrict__ tab, uint64_t mask, ui
 				return true;
 			}
 		}
-		s = (s + 1) & mask;
+		s = slot_next(s, cap);
 	}
 	return false;
 }
 
 // read-only probe, valid in a launch after the one that built the table
 template <int W>
-__device__ __forceinline__ const Slot *lookup(const Slot *__restrict__ tab, uint64_t mask, uint64_t i0, uint64_t i1) {
-	uint64_t s = slot_hash<W>(i0, i1) & mask;
+__device__ __forceinline__ const Slot *lookup(const Slot *__restrict__ tab, uint64_t cap, uint64_t i0, uint64_t i1) {
+	uint64_t s = slot_home(slot_hash<W>(i0, i1), cap);
 	for (uint32_t probe = 0; probe < MAX_PROBE; ++probe) {
 		const Slot *p = tab + s;
 		ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(&p->k0);
 		if (a.x == EMPTY) return nullptr;
 		if (a.x == i0 && (W == 1 || a.y == i1)) return p;
-		s = (s + 1) & mask;
+		s = slot_next(s, cap);
 	}
 	return nullptr;
 }

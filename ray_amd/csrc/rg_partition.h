@@ -1781,7 +1781,7 @@ __global__ __launch_bounds__(THREADS) void k_aggregate_wg(const Rec<W> *__restri
 // occurrence), used when an estimate of the partitioned path was exceeded.
 template <int W>
 __global__ __launch_bounds__(256) void k_count_records(const Rec<W> *__restrict__ recs, uint64_t n, int k, Slot *__restrict__ tab,
-                                                       uint64_t mask, unsigned long long *__restrict__ counters, int c_fill) {
+                                                       uint64_t cap, unsigned long long *__restrict__ counters, int c_fill) {
 	constexpr int NB = 2 * W;
 	__shared__ uint32_t s_claimed;
 	if (threadIdx.x == 0) s_claimed = 0;
@@ -1815,7 +1815,7 @@ __global__ __launch_bounds__(256) void k_count_records(const Rec<W> *__restrict_
 			if (has_next) em |= 1u << (use_rc ? 3u - nb : 4u + nb);
 			uint64_t i0, i1;
 			to_internal<W>(use_rc ? r0 : f0, use_rc ? r1 : f1, i0, i1);
-			if (!upsert<W>(tab, mask, i0, i1, stamp0 + i, 1ull, em, claimed)) failed = true;
+			if (!upsert<W>(tab, cap, i0, i1, stamp0 + i, 1ull, em, claimed)) failed = true;
 			prev = (uint32_t)f0 & 3u;
 			prev_valid = true;
 			if (i + 1 < len) {

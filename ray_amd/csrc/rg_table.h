@@ -1,0 +1,202 @@
+// rg_table.h -- the vertex table built without global atomics.
+//
+// k_insert_admitted claims one slot per vertex with a device-scope compare-and-swap on a random sector of a
+// multi-GiB table and writes the rest of the slot after the line has left L2: bound by the atomic rate (11.6 G/s)
+// and 3.6x its bytes in write traffic, on top of a memset of the whole table.  The admitted entries are distinct
+// keys, so nothing has to be atomic if one workgroup owns a whole stretch of the table:
+//
+//   k_entry_hist + k_scatter_entries   the admitted entries are partitioned by the table range their home slot
+//                   lies in (range = home slot >> SPAN_LOG2; one to three levels of at most 8 bits, tile-local
+//                   counting sort in LDS, runs out -- the scheme of k_scatter, on 32-byte entries)
+//   k_build_ranges  one workgroup per range: the range's slots are filled in LDS (linear probing inside the
+//                   range, LDS compare-and-swap), then written out once, free slots included -- no k_init_table,
+//                   every byte of the table is written exactly once, coalesced
+//   k_insert_admitted   only for the few entries whose probe sequence leaves their range (the overflow list)
+//
+// Look-ups are the table's usual linear probing from the home slot: an entry that left its range was placed by
+// the ordinary insert after every range had been written, so there is no free slot between its home and itself.
+#pragma once
+#include "rg_device.h"
+
+namespace rg {
+
+static constexpr int ENT_TILE = 2048;     // entries per scatter tile: 64 KB of LDS
+static constexpr int ENT_THREADS = 512;
+
+enum TableCounter { TC_OVF_CURSOR = 27, TC_OVF_LOST = 28 };
+
+// range index of an entry: the bits above SPAN_LOG2 of its home slot
+template <int W>
+__device__ __forceinline__ uint32_t entry_range(const Slot &v, uint64_t cap, int span_log2) {
+	return (uint32_t)(slot_home(slot_hash<W>(v.k0, W == 2 ? v.k1 : 0), cap) >> span_log2);
+}
+
+__device__ __forceinline__ bool entry_admitted(const Slot &v) { return v.k0 != EMPTY && (v.meta & COUNT_MASK) != 0; }
+
+// first level's digit histogram: admitted entries of the log per top digit
+template <int W>
+__global__ __launch_bounds__(256) void k_entry_hist(const Slot *__restrict__ in, uint64_t n, uint64_t cap, int span_log2, int shift, uint32_t dmask,
+                                                    unsigned long long *__restrict__ hist) {
+	__shared__ uint32_t s_cnt[256];
+	s_cnt[threadIdx.x] = 0;
+	__syncthreads();
+	for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+		const Slot v = in[i];
+		if (entry_admitted(v)) atomicAdd(&s_cnt[(entry_range<W>(v, cap, span_log2) >> shift) & dmask], 1u);
+	}
+	__syncthreads();
+	if (s_cnt[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
+}
+
+// One partition level of 32-byte entries (see k_scatter for the scheme).  FIRST: the input is the log of the sweep after
+// admission -- unused chunk entries and entries that were not admitted are dropped here.
+template <int W, bool FIRST>
+__global__ __launch_bounds__(ENT_THREADS) void k_scatter_entries(const Slot *__restrict__ in, uint32_t S, const unsigned long long *__restrict__ seg_begin,
+                                                                 const uint32_t *__restrict__ tile_first, uint64_t cap, int span_log2, int shift, int dbits,
+                                                                 unsigned long long *__restrict__ cursors, Slot *__restrict__ out,
+                                                                 uint8_t *__restrict__ side, int next_shift, uint32_t next_mask) {
+	constexpr int PER = ENT_TILE / ENT_THREADS;
+	__shared__ Slot s_ent[ENT_TILE];
+	__shared__ uint8_t s_dig[ENT_TILE], s_next[ENT_TILE];
+	__shared__ uint32_t s_cnt[256], s_off[256], s_scan[8];
+	__shared__ unsigned long long s_gbase[256];
+	uint32_t lo = 0, hi = S;  // largest s with tile_first[s] <= tile
+	while (hi - lo > 1) {
+		const uint32_t mid = (lo + hi) >> 1;
+		if (tile_first[mid] <= blockIdx.x) lo = mid;
+		else hi = mid;
+	}
+	const uint32_t seg = lo;
+	const uint64_t begin = seg_begin[seg] + (uint64_t)(blockIdx.x - tile_first[seg]) * ENT_TILE;
+	const uint64_t end = begin + ENT_TILE < seg_begin[seg + 1] ? begin + ENT_TILE : seg_begin[seg + 1];
+	const uint32_t dmask = (1u << dbits) - 1;
+	if (threadIdx.x < 256) s_cnt[threadIdx.x] = 0;
+	__syncthreads();
+	Slot mine[PER];
+	uint32_t dig[PER], rank[PER], nxt[PER];
+#pragma unroll
+	for (int j = 0; j < PER; ++j) {
+		const uint64_t i = begin + threadIdx.x + (uint64_t)j * ENT_THREADS;
+		dig[j] = 0xFFFFFFFFu;
+		rank[j] = 0;
+		nxt[j] = 0;
+		if (i < end) {
+			const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(&in[i].k0), b = *reinterpret_cast<const ulonglong2 *>(&in[i].stamp);
+			mine[j].k0 = a.x;
+			mine[j].k1 = a.y;
+			mine[j].stamp = b.x;
+			mine[j].meta = b.y;
+			if (!FIRST || entry_admitted(mine[j])) {
+				const uint32_t r = entry_range<W>(mine[j], cap, span_log2);
+				dig[j] = (r >> shift) & dmask;
+				nxt[j] = (r >> next_shift) & next_mask;
+				rank[j] = atomicAdd(&s_cnt[dig[j]], 1u);
+			}
+		}
+	}
+	__syncthreads();
+	{
+		const bool low = threadIdx.x < 256;  // one thread per digit
+		const uint32_t c = low ? s_cnt[threadIdx.x] : 0u;
+		const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+		uint32_t incl = c;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			const uint32_t o = __shfl_up(incl, d);
+			if (lane >= (uint32_t)d) incl += o;
+		}
+		if (lane == 63 && low) s_scan[wv] = incl;
+		__syncthreads();
+		uint32_t before = 0;
+#pragma unroll
+		for (uint32_t q = 0; q < 4; ++q)
+			if (q < wv) before += s_scan[q];
+		if (low) {
+			s_off[threadIdx.x] = before + incl - c;
+			if (threadIdx.x == 255) s_scan[4] = before + incl;
+			unsigned long long g = 0;
+			if (c) g = atomicAdd(&cursors[((uint64_t)seg << dbits) + threadIdx.x], (unsigned long long)c);
+			s_gbase[threadIdx.x] = g;
+		}
+	}
+	__syncthreads();
+	const uint32_t total = s_scan[4];
+#pragma unroll
+	for (int j = 0; j < PER; ++j)
+		if (dig[j] != 0xFFFFFFFFu) {
+			const uint32_t pos = s_off[dig[j]] + rank[j];
+			*reinterpret_cast<ulonglong2 *>(&s_ent[pos].k0) = make_ulonglong2(mine[j].k0, mine[j].k1);
+			*reinterpret_cast<ulonglong2 *>(&s_ent[pos].stamp) = make_ulonglong2(mine[j].stamp, mine[j].meta);
+			s_dig[pos] = (uint8_t)dig[j];
+			s_next[pos] = (uint8_t)nxt[j];
+		}
+	__syncthreads();
+	// two threads per entry: 16 bytes each, so that a wavefront writes 1 KB of consecutive bytes of a run
+	for (uint32_t i2 = threadIdx.x; i2 < 2 * total; i2 += ENT_THREADS) {
+		const uint32_t i = i2 >> 1, half = i2 & 1u;
+		const uint32_t d = s_dig[i];
+		const unsigned long long dst = s_gbase[d] + (i - s_off[d]);
+		const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(reinterpret_cast<const uint64_t *>(&s_ent[i]) + 2 * half);
+		*reinterpret_cast<ulonglong2 *>(reinterpret_cast<uint64_t *>(&out[dst]) + 2 * half) = v;
+		if (side && half == 0) side[dst] = s_next[i];
+	}
+}
+
+// One workgroup per table range of SPAN slots: fill it in LDS, write it out whole.  range_begin[r] .. range_begin[r+1] are
+// the entries whose home slot lies in range r.  An entry that finds no free slot between its home and the end of the range
+// goes to the overflow list (ovf, at most ovf_cap entries; beyond that TC_OVF_LOST counts and the host rebuilds the
+// classic way).
+template <int W, int SPAN_LOG2>
+__global__ __launch_bounds__(1024) void k_build_ranges(const Slot *__restrict__ entries, const unsigned long long *__restrict__ range_begin,
+                                                       uint32_t nranges, Slot *__restrict__ tab, uint64_t cap, Slot *__restrict__ ovf,
+                                                       uint64_t ovf_cap, unsigned long long *__restrict__ counters) {
+	constexpr uint32_t SPAN = 1u << SPAN_LOG2;
+	__shared__ Slot s_tab[SPAN];
+	uint32_t placed = 0;
+	for (uint32_t r = blockIdx.x; r < nranges; r += gridDim.x) {
+		const uint64_t lo = (uint64_t)r << SPAN_LOG2;
+		const uint32_t span = (cap - lo < SPAN) ? (uint32_t)(cap - lo) : SPAN;
+		for (uint32_t i = threadIdx.x; i < span; i += blockDim.x) {
+			*reinterpret_cast<ulonglong2 *>(&s_tab[i].k0) = make_ulonglong2(EMPTY, EMPTY);
+			*reinterpret_cast<ulonglong2 *>(&s_tab[i].stamp) = make_ulonglong2(INF_STAMP, 0);
+		}
+		__syncthreads();
+		const uint64_t begin = range_begin[r], end = range_begin[r + 1];
+		for (uint64_t e = begin + threadIdx.x; e < end; e += blockDim.x) {
+			const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(&entries[e].k0), b = *reinterpret_cast<const ulonglong2 *>(&entries[e].stamp);
+			const uint64_t home = slot_home(slot_hash<W>(a.x, W == 2 ? a.y : 0), cap);
+			uint32_t s = (uint32_t)(home - lo);  // the partition guarantees lo <= home < lo + span
+			bool done = false;
+			for (; s < span; ++s) {
+				// the keys are distinct: whoever sets word 0 owns the slot, nobody else looks at the rest of it
+				if (s_tab[s].k0 == EMPTY && atomicCAS(reinterpret_cast<unsigned long long *>(&s_tab[s].k0), EMPTY, a.x) == EMPTY) {
+					s_tab[s].k1 = (W == 2) ? a.y : 0;
+					*reinterpret_cast<ulonglong2 *>(&s_tab[s].stamp) = b;
+					done = true;
+					break;
+				}
+			}
+			if (done) {
+				placed++;
+			} else {
+				const unsigned long long pos = atomicAdd(&counters[TC_OVF_CURSOR], 1ull);
+				if (pos < ovf_cap) {
+					*reinterpret_cast<ulonglong2 *>(&ovf[pos].k0) = a;
+					*reinterpret_cast<ulonglong2 *>(&ovf[pos].stamp) = b;
+				} else {
+					atomicAdd(&counters[TC_OVF_LOST], 1ull);
+				}
+			}
+		}
+		__syncthreads();
+		// 16 bytes per thread and step
+		const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(s_tab);
+		ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(tab + lo);
+		for (uint32_t i = threadIdx.x; i < 2 * span; i += blockDim.x) dst[i] = src[i];
+		__syncthreads();
+	}
+	for (int d = 32; d > 0; d >>= 1) placed += __shfl_down(placed, d);
+	if ((threadIdx.x & 63) == 0 && placed) atomicAdd(&counters[0 /*C_FILL*/], (unsigned long long)placed);
+}
+
+}  // namespace rg
