@@ -42,7 +42,7 @@ typedef struct rg_config {
 	int32_t rank;           /* MPI rank == GPU owner index */
 	int32_t size;           /* number of ranks */
 	int32_t device;         /* HIP device ordinal */
-	int32_t reserved0;      /* sweep selection, bits 0-7: 0 = automatic, 1 = force the partitioned sweep, 2 = force the direct sweep; bits 8-15: log2 of the bucket count of the partitioned sweep (0 = automatic); bit 4 / bit 5: force the partitioned / the dense Bloom resolution; bit 6: start with a one-chunk log (tests of the overflow path); bit 16: cut super-k-mer records with the wavefront-per-read kernel even where the lane-per-read one applies; bit 17: produce the Bloom items straight into their first partition level even from a sparse key array; bit 18: size the log from a sample of the buckets even on small inputs (tests); bit 19: rg_merge_entries never keeps received entries as a log (tests); bit 20: the partition levels' histograms read the records instead of the digit bytes the previous level left (tests); bit 21: aggregate with a workgroup per bucket of a two-level partition (k_aggregate_wg) instead of a wavefront per bucket of a three-level one (tests); bit 22 / bit 23: always / never build the vertex table range by range from partitioned entries (tests) */
+	int32_t reserved0;      /* sweep selection, bits 0-7: 0 = automatic, 1 = force the partitioned sweep, 2 = force the direct sweep; bits 8-15: log2 of the bucket count of the partitioned sweep (0 = automatic); bit 4 / bit 5: force the partitioned / the dense Bloom resolution; bit 6: start with a one-chunk log (tests of the overflow path); bit 16: cut super-k-mer records with the wavefront-per-read kernel even where the lane-per-read one applies; bit 17: produce the Bloom items straight into their first partition level even from a sparse key array; bit 18: size the log from a sample of the buckets even on small inputs (tests); bit 19: rg_merge_entries never keeps received entries as a log (tests); bit 20: the partition levels' histograms read the records instead of the digit bytes the previous level left (tests); bit 21: aggregate with a workgroup per bucket of a two-level partition (k_aggregate_wg) instead of a wavefront per bucket of a three-level one (tests); bit 22 / bit 23: always / never build the vertex table range by range from partitioned entries (tests); bit 24: resolve a power-of-two Bloom filter by key partitions whatever its fill (tests) */
 	uint64_t bloom_bits;    /* RG_BLOOM_DEFAULT, 0 = Bloom filter off, else -bloom-filter-bits */
 	uint64_t table_slots;   /* initial open-addressing capacity hint (like -hash-table-buckets); 0 = auto */
 	uint64_t first_read_id; /* global id of this rank's first read (SequencesLoader.cpp:287-297) */
@@ -235,7 +235,7 @@ typedef struct rg_stats {
 	uint64_t superkmer_records; /* partitioned sweep: super-k-mer records written */
 	uint64_t partition_levels;  /* partitioned sweep: scatter levels run (1..3) */
 	uint64_t log_entries;       /* partitioned sweep: aggregated entries handed to the table merge */
-	uint64_t bloom_partitioned; /* 1 if admission was resolved by Bloom-region partitioning, 0 if by dense stamps */
+	uint64_t bloom_partitioned; /* admission resolved by: 0 dense first-touch stamps, 1 Bloom-region partitioning of (bit, key) items, 2 key partitions (filters of 2^B bits) */
 } rg_stats;
 int rg_get_stats(rg_handle *h, rg_stats *out);
 

@@ -24,6 +24,7 @@
 #include "rg_partition.h"
 #include "rg_bloom.h"
 #include "rg_table.h"
+#include "rg_bloomx.h"
 
 using namespace rg;
 
@@ -1912,6 +1913,198 @@ static int bloom_partitioned(rg_handle *h, Table &T, uint64_t m_bits, uint64_t k
 	return RG_OK;
 }
 
+// ---- Bloom admission for power-of-two filters at any fill (rg_bloomx.h) ------------------------------------
+// *ok = false: not applicable (filter size not a power of two, no memory); the caller then uses another method.
+static int bloom_xor(rg_handle *h, Table &T, uint64_t m_bits, uint64_t keys, bool *ok) {
+	*ok = false;
+	const int dev = h->cfg.device;
+	if (m_bits == 0 || (m_bits & (m_bits - 1)) || T.cap >= (1ull << 31) || keys == 0) return RG_OK;
+	int B = 0;
+	while ((1ull << B) < m_bits) B++;
+	// region size: 2^14 bits, one workgroup of 1024 threads per CU (C2 with 1 % errors: k_xor_region 58 ms; 2^13 bits x 2
+	// workgroups of 512: 73 ms; 2^12 x 4 of 256: 77 ms -- RG_XOR_R selects them for experiments)
+	int rmax = 14;
+	if (const char *ev = getenv("RG_XOR_R")) rmax = std::max(12, std::min(XOR_REGION_LOG2_MAX, atoi(ev)));
+	const int R = std::min(B, rmax);
+	const int PB = B - R;  // partition bits
+	if (PB > 24) return RG_OK;
+	const uint64_t P = 1ull << PB;
+	int c1 = 0, c2 = 0, c3 = PB;
+	if (PB > 16) {
+		c1 = PB / 3;
+		c2 = (PB - c1) / 2;
+		c3 = PB - c1 - c2;
+	} else if (PB > 8) {
+		c1 = PB / 2;
+		c3 = PB - c1;
+	}
+	const uint64_t m_mask = m_bits - 1;
+	int n_cu = 256;
+	(void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+	const uint64_t npos_cap = keys + 64 * P;  // every partition is padded to whole wavefronts
+	Item16 *A = nullptr, *Bb = nullptr;
+	unsigned long long *pk = nullptr, *planes = nullptr, *d_seg = nullptr, *d_hist = nullptr, *d_begin = nullptr, *d_sums = nullptr;
+	uint32_t *ix = nullptr, *d_tile = nullptr;
+	uint8_t *d_side = nullptr, *d_lost = nullptr;
+	auto cleanup = [&]() {
+		pool_free(dev, A);
+		pool_free(dev, Bb);
+		pool_free(dev, pk);
+		pool_free(dev, planes);
+		pool_free(dev, ix);
+		pool_free(dev, d_seg);
+		pool_free(dev, d_hist);
+		pool_free(dev, d_begin);
+		pool_free(dev, d_sums);
+		pool_free(dev, d_tile);
+		pool_free(dev, d_side);
+		pool_free(dev, d_lost);
+	};
+	const uint64_t plane_words = (npos_cap + 63) / 64;
+	const uint64_t NB = std::max<uint64_t>(P, 256);
+	const uint64_t SEGMAX = 65536;
+	hipError_t e = pool_alloc(dev, (void **)&A, keys * sizeof(Item16));
+	if (e == hipSuccess && c2) e = pool_alloc(dev, (void **)&Bb, keys * sizeof(Item16));
+	if (e == hipSuccess) e = pool_alloc(dev, (void **)&pk, npos_cap * 8);
+	if (e == hipSuccess) e = pool_alloc(dev, (void **)&ix, npos_cap * 4);
+	if (e == hipSuccess) e = pool_alloc(dev, (void **)&planes, 8 * plane_words * 8);
+	if (e == hipSuccess) e = pool_alloc(dev, (void **)&d_side, keys);
+	if (e == hipSuccess) e = pool_alloc(dev, (void **)&d_lost, T.cap + 4);
+	if (e == hipSuccess) e = pool_alloc(dev, (void **)&d_seg, (SEGMAX + 1) * sizeof(unsigned long long));
+	if (e == hipSuccess) e = pool_alloc(dev, (void **)&d_tile, (SEGMAX + 1) * sizeof(uint32_t));
+	if (e == hipSuccess) e = pool_alloc(dev, (void **)&d_hist, NB * sizeof(unsigned long long));
+	if (e == hipSuccess) e = pool_alloc(dev, (void **)&d_begin, (NB + 1) * sizeof(unsigned long long));
+	if (e == hipSuccess) e = pool_alloc(dev, (void **)&d_sums, (NB / SCAN_PER_BLOCK + 2) * sizeof(unsigned long long));
+	if (e != hipSuccess) {
+		(void)hipGetLastError();
+		cleanup();
+		return RG_OK;
+	}
+#define XTRY(call)                                                                                          \
+	do {                                                                                                    \
+		hipError_t e_ = (call);                                                                             \
+		if (e_ != hipSuccess) {                                                                             \
+			cleanup();                                                                                      \
+			return fail(h, e_ == hipErrorOutOfMemory ? RG_ERR_NOMEM : RG_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+		}                                                                                                   \
+	} while (0)
+	auto scan = [&](uint64_t n) {  // d_hist[n] -> d_begin[n + 1], d_hist = copy of the begins (the scatter's cursors)
+		const uint32_t nblk = (uint32_t)((n + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK);
+		hipLaunchKernelGGL(k_scan_local, dim3(nblk), dim3(256), 0, h->stream, d_hist, d_begin, n, d_sums);
+		hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(64), 0, h->stream, d_sums, nblk, d_sums + nblk);
+		hipLaunchKernelGGL(k_scan_add, dim3(nblk), dim3(256), 0, h->stream, d_begin, n, d_sums, d_sums + nblk, d_hist);
+	};
+	XTRY(hipMemsetAsync(pk, 0xFF, npos_cap * 8, h->stream));
+	XTRY(hipMemsetAsync(d_lost, 0, T.cap + 4, h->stream));
+	XTRY(hipMemsetAsync(d_hist, 0, 256 * sizeof(unsigned long long), h->stream));
+	// level 1: histogram of the top c1 bits, items produced straight into their ranges
+	const int grid_scan = (int)std::min<uint64_t>((uint64_t)n_cu * 8, (T.cap + 255) / 256);
+	{
+		ProfScope ps(h, "k_xor_hist");
+		if (h->W == 1) hipLaunchKernelGGL(k_xor_hist<1>, dim3(grid_scan), dim3(256), 0, h->stream, T.slots, T.cap, m_mask, B - c1, (1u << c1) - 1u, d_hist);
+		else hipLaunchKernelGGL(k_xor_hist<2>, dim3(grid_scan), dim3(256), 0, h->stream, T.slots, T.cap, m_mask, B - c1, (1u << c1) - 1u, d_hist);
+		XTRY(hipGetLastError());
+	}
+	scan(1ull << c1);
+	const int nd = c2 ? c2 : c3;                 // bits of the level after the first
+	const int nshift = B - c1 - nd;
+	{
+		ProfScope ps(h, "k_xor_keys");
+		const unsigned grid = (unsigned)((T.cap + XOR_TILE - 1) / XOR_TILE);
+		if (h->W == 1) hipLaunchKernelGGL(k_xor_keys<1>, dim3(grid), dim3(XOR_THREADS), 0, h->stream, T.slots, T.cap, m_mask, B - c1, (1u << c1) - 1u, d_hist, A, d_side, nshift, (1u << nd) - 1u);
+		else hipLaunchKernelGGL(k_xor_keys<2>, dim3(grid), dim3(XOR_THREADS), 0, h->stream, T.slots, T.cap, m_mask, B - c1, (1u << c1) - 1u, d_hist, A, d_side, nshift, (1u << nd) - 1u);
+		XTRY(hipGetLastError());
+	}
+	std::vector<unsigned long long> seg_begin;
+	std::vector<uint32_t> tile_first;
+	const Item16 *level_in = A;
+	int used = c1;
+	for (int level = 1; level <= (c2 ? 2 : 1); ++level) {
+		const bool final_level = level == (c2 ? 2 : 1);
+		const int db = final_level ? c3 : c2;
+		const uint64_t S64 = 1ull << used;
+		seg_begin.resize(S64 + 1);
+		XTRY(hipMemcpyAsync(seg_begin.data(), d_begin, (S64 + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+		XTRY(hipStreamSynchronize(h->stream));
+		if (seg_begin[S64] != keys) {
+			cleanup();
+			return fail(h, RG_ERR_STATE, "Bloom key partition holds %llu of %llu keys", seg_begin[S64], (unsigned long long)keys);
+		}
+		const uint32_t S = (uint32_t)S64;
+		tile_first.assign(S + 1, 0);
+		uint64_t ntiles = 0;
+		for (uint32_t sgi = 0; sgi < S; ++sgi) {
+			tile_first[sgi] = (uint32_t)ntiles;
+			ntiles += (seg_begin[sgi + 1] - seg_begin[sgi] + XOR_TILE - 1) / XOR_TILE;
+		}
+		tile_first[S] = (uint32_t)ntiles;
+		XTRY(hipMemcpyAsync(d_seg, seg_begin.data(), (S + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
+		XTRY(hipMemcpyAsync(d_tile, tile_first.data(), (S + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+		const uint64_t nout = (uint64_t)S << db;
+		XTRY(hipMemsetAsync(d_hist, 0, nout * sizeof(unsigned long long), h->stream));
+		{
+			ProfScope ps(h, "k_level_hist_side");
+			hipLaunchKernelGGL(k_level_hist_side<XOR_TILE>, dim3((unsigned)ntiles), dim3(256), 0, h->stream, d_side, S, d_seg, d_tile, db, d_hist);
+			XTRY(hipGetLastError());
+		}
+		if (final_level) hipLaunchKernelGGL(k_round64, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, h->stream, d_hist, nout);
+		scan(nout);
+		XTRY(hipGetLastError());
+		{
+			ProfScope ps(h, "k_scatter16");
+			const int shift = B - used - db;
+			if (final_level)
+				hipLaunchKernelGGL((k_scatter16<true>), dim3((unsigned)ntiles), dim3(XOR_THREADS), 0, h->stream, level_in, S, d_seg, d_tile, shift, db, d_hist, (Item16 *)nullptr,
+				                   (uint8_t *)nullptr, 0, 0u, pk, ix, (1ull << R) - 1ull);
+			else
+				hipLaunchKernelGGL((k_scatter16<false>), dim3((unsigned)ntiles), dim3(XOR_THREADS), 0, h->stream, level_in, S, d_seg, d_tile, shift, db, d_hist, Bb, d_side,
+				                   shift - c3, (1u << c3) - 1u, (unsigned long long *)nullptr, (uint32_t *)nullptr, 0ull);
+			XTRY(hipGetLastError());
+		}
+		used += db;
+		level_in = Bb;
+	}
+	// regions
+	XorConsts K;
+	static const uint64_t MAGIC[8] = {0xe70b369c4c19f0f9ULL, 0xbeb7f38b993441a2ULL, 0x3149cd9246ca7995ULL, 0x2ef5b2c17d479ee8ULL,
+	                                  0xfb8daceab90fe233ULL, 0x20fa74e37d497859ULL, 0x9007d0caef749698ULL, 0x4e4100a5605ef967ULL};  // BloomFilter.cpp:72-79
+	for (int i = 0; i < 8; ++i) {
+		K.c[i] = (uint32_t)((MAGIC[i] & m_mask) >> R);
+		K.low[i] = (uint32_t)(MAGIC[i] & ((1ull << R) - 1ull));
+	}
+	XTRY(hipMemsetAsync(h->d_counters + C_SETBITS, 0, sizeof(unsigned long long), h->stream));
+	{
+		ProfScope ps(h, "k_xor_region");
+		if (rmax == 14)
+			hipLaunchKernelGGL((k_xor_region<14, 1024>), dim3((unsigned)std::min<uint64_t>(P, (uint64_t)n_cu)), dim3(1024), 0, h->stream, pk, d_begin, (uint32_t)P, R, K, planes, plane_words, h->d_counters, (int)C_SETBITS);
+		else if (rmax == 13)
+			hipLaunchKernelGGL((k_xor_region<13, 512>), dim3((unsigned)std::min<uint64_t>(P, (uint64_t)n_cu * 2)), dim3(512), 0, h->stream, pk, d_begin, (uint32_t)P, R, K, planes, plane_words, h->d_counters, (int)C_SETBITS);
+		else
+			hipLaunchKernelGGL((k_xor_region<12, 256>), dim3((unsigned)std::min<uint64_t>(P, (uint64_t)n_cu * 4)), dim3(256), 0, h->stream, pk, d_begin, (uint32_t)P, R, K, planes, plane_words, h->d_counters, (int)C_SETBITS);
+		XTRY(hipGetLastError());
+	}
+	{
+		ProfScope ps(h, "k_xor_fp");
+		hipLaunchKernelGGL(k_xor_fp, dim3(grid_for(npos_cap)), dim3(256), 0, h->stream, pk, ix, planes, plane_words, npos_cap, d_lost);
+		XTRY(hipGetLastError());
+	}
+	{
+		ProfScope ps(h, "k_admit");
+		const int grid = grid_for(T.cap);
+		if (h->W == 1) hipLaunchKernelGGL(k_admit_lost<1>, dim3(grid), dim3(BLOCK), 0, h->stream, T.slots, T.cap, (const uint32_t *)d_lost, h->d_counters, h->d_hist_dense, h->d_hist_ovf);
+		else hipLaunchKernelGGL(k_admit_lost<2>, dim3(grid), dim3(BLOCK), 0, h->stream, T.slots, T.cap, (const uint32_t *)d_lost, h->d_counters, h->d_hist_dense, h->d_hist_ovf);
+		XTRY(hipGetLastError());
+	}
+	XTRY(hipStreamSynchronize(h->stream));
+	if (getenv("RG_DEBUG"))
+		fprintf(stderr, "[raygraph] Bloom by key partitions: %llu keys, 2^%d bits, %llu partitions (levels %d+%d+%d bits), regions of 2^%d bits\n",
+		        (unsigned long long)keys, B, (unsigned long long)P, c1, c2, c3, R);
+	cleanup();
+	*ok = true;
+#undef XTRY
+	return RG_OK;
+}
+
 // rg_merge_entries, first call into an empty partition: the received entries are copied into a log of the library's own
 // and those that do not carry the unique mark (or hold no key) are counted; none = the copy can be admitted as a log
 __global__ __launch_bounds__(256) void k_adopt_entries(const Slot *__restrict__ in, uint64_t n, Slot *__restrict__ out,
@@ -2634,7 +2827,16 @@ int rg_resolve_admission(rg_handle *h, uint64_t local_reads_for_bloom) {
 		const double lambda = 8.0 * (double)keys / (double)m_bits;
 		// worth it while a region's contested bits (expected: 2^17 * P(two or more touchers)) fit the LDS rank table
 		const double contested = (double)REGION_BITS * (1.0 - std::exp(-lambda) * (1.0 + lambda));
-		if (!(flags & 32u) && ((flags & 16u) || (contested <= 0.9 * REGION_MULTI_CAP_BIG && keys >= (1ull << 20)))) {
+		const bool regions_fit = contested <= 0.9 * REGION_MULTI_CAP_BIG;
+		// filters of 2^B bits too full for the regions (or cfg.reserved0 bit 24: tests): one item per key, partitioned by the
+		// key's origin, eight streams per region (rg_bloomx.h)
+		const bool regions_cheap = contested <= 0.4 * REGION_MULTI_CAP;  // beyond: stamp gathers and several rounds per region (C2 with 0.2 % errors: 125 ms against 45)
+		if (!(flags & 32u) && !(flags & 16u) && ((h->cfg.reserved0 & 0x1000000) || (!regions_cheap && keys >= (1ull << 20)))) {
+			rc0 = bloom_xor(h, T, m_bits, keys, &resolved);
+			if (rc0) return rc0;
+			if (resolved) h->stats.bloom_partitioned = 2;
+		}
+		if (!resolved && !(flags & 32u) && ((flags & 16u) || (regions_fit && keys >= (1ull << 20)))) {
 			rc0 = bloom_partitioned(h, T, m_bits, keys, &resolved);
 			if (rc0) return rc0;
 			h->stats.bloom_partitioned = resolved ? 1 : 0;

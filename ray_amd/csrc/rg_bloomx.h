@@ -1,0 +1,348 @@
+// rg_bloomx.h -- Bloom admission for filters of 2^B bits at any fill, without one item per (key, bit).
+//
+// The reference caps its filter at 2^33 bits (VerticesExtractor.cpp:308-312), so every large input runs with a
+// power-of-two filter, and on error-rich reads that filter is dense (C2 with 1 % errors: 1.3e9 keys x 8 bits on
+// 8.6e9 bits).  rg_bloom.h then needs 8 items per key and a stamp fetch per contested bit, the dense method 8 B of
+// first-touch stamp per filter bit (64 GiB) and 8 scattered atomics per key.  With m_bits = 2^B
+//     bit_i(x) = (hash2(x) ^ M_i) & (2^B - 1)                       (BloomFilter.cpp:124-150)
+// so with o = hash2(x) & (2^B - 1), the region (bit >> R) of bit_i(x) is (o >> R) ^ c_i with the constants
+// c_i = (M_i & (2^B - 1)) >> R: the 8 bits of a key lie in 8 regions that depend on the key's *partition*
+// p = o >> R alone, and region r is touched, through hash i, by the keys of partition r ^ c_i and by no others.
+// So the keys are partitioned ONCE, by p (one 16-byte item per key instead of eight 8-byte ones), and a workgroup
+// that owns region r streams the eight partitions r ^ c_0 .. r ^ c_7:
+//
+//   k_xor_hist / k_xor_keys   one item (o, slot index, stamp) per key, produced straight into the ranges of the first
+//                   partition level (tile-local counting sort in LDS, as k_bloom_scatter_items)
+//   k_scatter16     a middle partition level of 16-byte items (filters beyond 2^30 bits)
+//   k_xor_final     the last level: writes, per partition and padded to whole wavefronts, the 8-byte
+//                   (stamp << 14 | low bits of o) array the regions read and the 4-byte slot indices
+//   k_xor_region    one workgroup per region of 2^14 bits: a first-touch stamp per bit in LDS (atomicMin over the
+//                   eight streams), then every key whose stamp is a bit's minimum has *won* that bit: one bit per
+//                   (hash, key position), written as whole ballots
+//   k_xor_fp        a key that won none of its 8 bits found them all set when it first arrived: a false positive
+//                   (MessageProcessor.cpp:741-750); those few get their mark, k_admit_lost applies the rule
+//
+// Same result as the other two methods bit for bit.  Cost per key: 16 B written and read per partition level, 8 x 8 B
+// read by the regions -- independent of the fill.
+#pragma once
+#include "rg_device.h"
+
+namespace rg {
+
+static constexpr int XOR_REGION_LOG2_MAX = 14;  // at most 2^14 first-touch stamps of 8 B = 128 KB of LDS per region
+static constexpr int XOR_TILE = 4096;            // 16-byte items per scatter tile (64 KB of LDS)
+static constexpr int XOR_THREADS = 512;
+static constexpr unsigned long long XOR_PAD = ~0ull;  // padding entry of the packed array
+static constexpr int XOR_PER = 24;               // items a thread of k_xor_region keeps in registers
+
+struct Item16 {
+	unsigned long long a;  // o << 31 | slot index
+	unsigned long long b;  // arrival stamp of the key
+};
+
+template <int W>
+__device__ __forceinline__ uint64_t xor_origin(uint64_t k0, uint64_t k1, uint64_t m_mask) {
+	uint64_t K0, K1;
+	from_internal<W>(k0, k1, K0, K1);
+	return hash2<W>(K0, K1) & m_mask;
+}
+
+// keys per first-level digit (digit = (o >> shift) & dmask)
+template <int W>
+__global__ __launch_bounds__(256) void k_xor_hist(const Slot *__restrict__ tab, uint64_t cap, uint64_t m_mask, int shift, uint32_t dmask,
+                                                  unsigned long long *__restrict__ hist) {
+	__shared__ uint32_t s_hist[256];
+	s_hist[threadIdx.x] = 0;
+	__syncthreads();
+	for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * 256) {
+		const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(&tab[i].k0);
+		if (a.x == EMPTY) continue;
+		atomicAdd(&s_hist[(uint32_t)(xor_origin<W>(a.x, a.y, m_mask) >> shift) & dmask], 1u);
+	}
+	__syncthreads();
+	if (s_hist[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)s_hist[threadIdx.x]);
+}
+
+// shared tail of the three scatter kernels: exclusive scan of the digit counts, one cursor claim per non-empty digit
+__device__ __forceinline__ uint32_t xor_claim(uint32_t *s_cnt, uint32_t *s_off, uint32_t *s_scan, unsigned long long *s_gbase,
+                                              unsigned long long *__restrict__ cursors) {
+	const bool low = threadIdx.x < 256;  // one thread per digit
+	const uint32_t c = low ? s_cnt[threadIdx.x] : 0u;
+	const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+	uint32_t incl = c;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		const uint32_t o = __shfl_up(incl, d);
+		if (lane >= (uint32_t)d) incl += o;
+	}
+	if (lane == 63 && low) s_scan[wv] = incl;
+	__syncthreads();
+	uint32_t before = 0;
+#pragma unroll
+	for (uint32_t q = 0; q < 4; ++q)
+		if (q < wv) before += s_scan[q];
+	if (low) {
+		s_off[threadIdx.x] = before + incl - c;
+		if (threadIdx.x == 255) s_scan[4] = before + incl;
+		unsigned long long g = 0;
+		if (c) g = atomicAdd(&cursors[threadIdx.x], (unsigned long long)c);
+		s_gbase[threadIdx.x] = g;
+	}
+	__syncthreads();
+	return s_scan[4];
+}
+
+// keys -> items, sorted by the first-level digit inside a tile of XOR_TILE slots and written as runs
+template <int W>
+__global__ __launch_bounds__(XOR_THREADS) void k_xor_keys(const Slot *__restrict__ tab, uint64_t cap, uint64_t m_mask, int shift, uint32_t dmask,
+                                                          unsigned long long *__restrict__ cursors, Item16 *__restrict__ out,
+                                                          uint8_t *__restrict__ side, int next_shift, uint32_t next_mask) {
+	constexpr int PER = XOR_TILE / XOR_THREADS;
+	__shared__ Item16 s_item[XOR_TILE];
+	__shared__ uint8_t s_dig[XOR_TILE];
+	__shared__ uint32_t s_cnt[256], s_off[256], s_scan[8];
+	__shared__ unsigned long long s_gbase[256];
+	const uint64_t base = (uint64_t)blockIdx.x * XOR_TILE;
+	if (threadIdx.x < 256) s_cnt[threadIdx.x] = 0;
+	__syncthreads();
+	Item16 mine[PER];
+	uint32_t dr[PER];  // digit << 16 | rank inside the tile
+#pragma unroll
+	for (int q = 0; q < PER; ++q) {
+		const uint64_t i = base + threadIdx.x + (uint64_t)q * XOR_THREADS;
+		dr[q] = 0xFFFFFFFFu;
+		if (i < cap) {
+			const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(&tab[i].k0);
+			if (a.x != EMPTY) {
+				const uint64_t o = xor_origin<W>(a.x, a.y, m_mask);
+				mine[q].a = (o << 31) | i;
+				mine[q].b = tab[i].stamp;
+				const uint32_t d = (uint32_t)(o >> shift) & dmask;
+				dr[q] = (d << 16) | atomicAdd(&s_cnt[d], 1u);
+			}
+		}
+	}
+	__syncthreads();
+	const uint32_t total = xor_claim(s_cnt, s_off, s_scan, s_gbase, cursors);
+#pragma unroll
+	for (int q = 0; q < PER; ++q)
+		if (dr[q] != 0xFFFFFFFFu) {
+			const uint32_t pos = s_off[dr[q] >> 16] + (dr[q] & 0xFFFFu);
+			s_item[pos] = mine[q];
+			s_dig[pos] = (uint8_t)(dr[q] >> 16);
+		}
+	__syncthreads();
+	for (uint32_t i = threadIdx.x; i < total; i += XOR_THREADS) {
+		const uint32_t d = s_dig[i];
+		const Item16 it = s_item[i];
+		const unsigned long long dst = s_gbase[d] + (i - s_off[d]);
+		*reinterpret_cast<ulonglong2 *>(&out[dst]) = make_ulonglong2(it.a, it.b);
+		if (side) side[dst] = (uint8_t)((uint32_t)(it.a >> (31 + next_shift)) & next_mask);
+	}
+}
+
+// A partition level of 16-byte items.  FINAL == false: items out (+ the next level's digit bytes).  FINAL == true: the
+// ranges (cursors) start on multiples of 64 positions; written are the packed (stamp << 14 | o & low_mask) words and the
+// slot indices.
+template <bool FINAL>
+__global__ __launch_bounds__(XOR_THREADS) void k_scatter16(const Item16 *__restrict__ in, uint32_t S, const unsigned long long *__restrict__ seg_begin,
+                                                           const uint32_t *__restrict__ tile_first, int shift, int dbits,
+                                                           unsigned long long *__restrict__ cursors, Item16 *__restrict__ out, uint8_t *__restrict__ side,
+                                                           int next_shift, uint32_t next_mask, unsigned long long *__restrict__ pk,
+                                                           uint32_t *__restrict__ ix, uint64_t low_mask) {
+	constexpr int PER = XOR_TILE / XOR_THREADS;
+	__shared__ Item16 s_item[XOR_TILE];
+	__shared__ uint8_t s_dig[XOR_TILE];
+	__shared__ uint32_t s_cnt[256], s_off[256], s_scan[8];
+	__shared__ unsigned long long s_gbase[256];
+	uint32_t lo = 0, hi = S;  // largest s with tile_first[s] <= tile
+	while (hi - lo > 1) {
+		const uint32_t mid = (lo + hi) >> 1;
+		if (tile_first[mid] <= blockIdx.x) lo = mid;
+		else hi = mid;
+	}
+	const uint32_t seg = lo;
+	const uint64_t begin = seg_begin[seg] + (uint64_t)(blockIdx.x - tile_first[seg]) * XOR_TILE;
+	const uint64_t end = begin + XOR_TILE < seg_begin[seg + 1] ? begin + XOR_TILE : seg_begin[seg + 1];
+	const uint32_t dmask = (1u << dbits) - 1;
+	if (threadIdx.x < 256) s_cnt[threadIdx.x] = 0;
+	__syncthreads();
+	Item16 mine[PER];
+	uint32_t dr[PER];
+#pragma unroll
+	for (int q = 0; q < PER; ++q) {
+		const uint64_t i = begin + threadIdx.x + (uint64_t)q * XOR_THREADS;
+		dr[q] = 0xFFFFFFFFu;
+		if (i < end) {
+			const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(&in[i]);
+			mine[q].a = v.x;
+			mine[q].b = v.y;
+			const uint32_t d = (uint32_t)(v.x >> (31 + shift)) & dmask;
+			dr[q] = (d << 16) | atomicAdd(&s_cnt[d], 1u);
+		}
+	}
+	__syncthreads();
+	const uint32_t total = xor_claim(s_cnt, s_off, s_scan, s_gbase, cursors + ((uint64_t)seg << dbits));
+#pragma unroll
+	for (int q = 0; q < PER; ++q)
+		if (dr[q] != 0xFFFFFFFFu) {
+			const uint32_t pos = s_off[dr[q] >> 16] + (dr[q] & 0xFFFFu);
+			s_item[pos] = mine[q];
+			s_dig[pos] = (uint8_t)(dr[q] >> 16);
+		}
+	__syncthreads();
+	for (uint32_t i = threadIdx.x; i < total; i += XOR_THREADS) {
+		const uint32_t d = s_dig[i];
+		const Item16 it = s_item[i];
+		const unsigned long long dst = s_gbase[d] + (i - s_off[d]);
+		if (FINAL) {
+			pk[dst] = (it.b << 14) | ((it.a >> 31) & low_mask);
+			ix[dst] = (uint32_t)(it.a & 0x7FFFFFFFull);
+		} else {
+			*reinterpret_cast<ulonglong2 *>(&out[dst]) = make_ulonglong2(it.a, it.b);
+			if (side) side[dst] = (uint8_t)((uint32_t)(it.a >> (31 + next_shift)) & next_mask);
+		}
+	}
+}
+
+// counts -> counts rounded up to whole wavefronts (the final level's ranges are padded so that a wavefront's 64
+// consecutive positions never straddle two partitions)
+__global__ __launch_bounds__(256) void k_round64(unsigned long long *__restrict__ v, uint64_t n) {
+	const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < n) v[i] = (v[i] + 63ull) & ~63ull;
+}
+
+struct XorConsts {
+	uint32_t c[8];    // partition that touches region r through hash i: r ^ c[i]
+	uint32_t low[8];  // M_i & (2^R - 1)
+};
+
+// One workgroup per region of 2^R filter bits (R <= 14).  part_begin: the padded ranges of the final level (P + 1
+// entries, multiples of 64).  planes: bit j of plane i = the key at position j won bit_i, i.e. its arrival set it.
+// RMAX, THREADS: 2^RMAX cells of LDS and the workgroup size -- (14, 1024): one workgroup per CU; (13, 512) / (12, 256): two /
+// four, whose loads and LDS phases overlap (a region is a chain of dependent loads: range bounds, then items).
+template <int RMAX, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_xor_region(const unsigned long long *__restrict__ pk, const unsigned long long *__restrict__ part_begin,
+                                                        uint32_t P, int R, XorConsts K, unsigned long long *__restrict__ planes, uint64_t plane_words,
+                                                        unsigned long long *__restrict__ counters, int c_setbits) {
+	__shared__ unsigned long long s_cell[1u << RMAX];
+	__shared__ uint32_t s_setbits;
+	const uint32_t ncell = 1u << R, cmask = ncell - 1;
+	const uint32_t lane = threadIdx.x & 63u;
+	uint32_t set_total = 0;
+	if (threadIdx.x == 0) s_setbits = 0;
+	for (uint32_t r = blockIdx.x; r < P; r += gridDim.x) {
+		for (uint32_t i = threadIdx.x; i < ncell; i += THREADS) s_cell[i] = INF_STAMP;
+		// the eight streams of this region, laid end to end (every length is a multiple of 64)
+		unsigned long long sb[8];
+		uint32_t pre[9];
+		pre[0] = 0;
+#pragma unroll
+		for (int i = 0; i < 8; ++i) {
+			const uint32_t q = r ^ K.c[i];
+			sb[i] = part_begin[q];
+			pre[i + 1] = pre[i] + (uint32_t)(part_begin[q + 1] - sb[i]);
+		}
+		const uint32_t total = pre[8];
+		__syncthreads();
+		if (total <= (uint32_t)THREADS * XOR_PER) {
+			// one read: the items stay in registers between the two passes
+			unsigned long long item[XOR_PER];
+			uint32_t where[XOR_PER];  // hash index << 28 | plane word (relative to the stream's first)
+#pragma unroll
+			for (int u = 0; u < XOR_PER; ++u) {
+				const uint32_t t = threadIdx.x + (uint32_t)THREADS * u;
+				item[u] = XOR_PAD;
+				where[u] = 0;
+				if (t < total) {
+					uint32_t i = 0;
+#pragma unroll
+					for (int q = 1; q < 8; ++q) i += (t >= pre[q]) ? 1u : 0u;
+					unsigned long long b = sb[0];
+					uint32_t p0 = 0;
+#pragma unroll
+					for (int q = 1; q < 8; ++q)
+						if (i == (uint32_t)q) {
+							b = sb[q];
+							p0 = pre[q];
+						}
+					item[u] = pk[b + (t - p0)];
+					where[u] = i;
+				}
+			}
+#pragma unroll
+			for (int u = 0; u < XOR_PER; ++u)
+				if (item[u] != XOR_PAD) {
+					const uint32_t bit = ((uint32_t)item[u] ^ K.low[where[u]]) & cmask;
+					atomicMin(&s_cell[bit], item[u] >> 14);
+				}
+			__syncthreads();
+#pragma unroll
+			for (int u = 0; u < XOR_PER; ++u) {
+				const uint32_t t = threadIdx.x + (uint32_t)THREADS * u;
+				if (t - lane < total) {  // wave-uniform: the 64 positions of a wavefront lie in one stream
+					bool win = false;
+					if (item[u] != XOR_PAD) {
+						const uint32_t bit = ((uint32_t)item[u] ^ K.low[where[u]]) & cmask;
+						win = s_cell[bit] == (item[u] >> 14);
+					}
+					const unsigned long long bal = __ballot(win);
+					if (lane == 0) {
+						const uint32_t i = where[u];
+						unsigned long long b = sb[0];
+						uint32_t p0 = 0;
+#pragma unroll
+						for (int q = 1; q < 8; ++q)
+							if (i == (uint32_t)q) {
+								b = sb[q];
+								p0 = pre[q];
+							}
+						planes[(uint64_t)i * plane_words + ((b + (t - p0)) >> 6)] = bal;
+					}
+				}
+			}
+		} else {
+			// a region with more keys than the registers hold: the streams are read twice
+#pragma unroll 1
+			for (int i = 0; i < 8; ++i) {
+				const uint32_t len = pre[i + 1] - pre[i];
+				for (uint32_t t = threadIdx.x; t < len; t += THREADS) {
+					const unsigned long long it = pk[sb[i] + t];
+					if (it != XOR_PAD) atomicMin(&s_cell[((uint32_t)it ^ K.low[i]) & cmask], it >> 14);
+				}
+			}
+			__syncthreads();
+#pragma unroll 1
+			for (int i = 0; i < 8; ++i) {
+				const uint32_t len = pre[i + 1] - pre[i];
+				for (uint32_t t = threadIdx.x; t < len; t += THREADS) {
+					const unsigned long long it = pk[sb[i] + t];
+					const bool win = it != XOR_PAD && s_cell[((uint32_t)it ^ K.low[i]) & cmask] == (it >> 14);
+					const unsigned long long bal = __ballot(win);
+					if (lane == 0) planes[(uint64_t)i * plane_words + ((sb[i] + t) >> 6)] = bal;
+				}
+			}
+		}
+		// bits of this region that any key touched
+		for (uint32_t i = threadIdx.x; i < ncell; i += THREADS) set_total += (s_cell[i] != INF_STAMP) ? 1u : 0u;
+		__syncthreads();
+	}
+	if (set_total) atomicAdd(&s_setbits, set_total);
+	__syncthreads();
+	if (threadIdx.x == 0 && s_setbits) atomicAdd(&counters[c_setbits], (unsigned long long)s_setbits);
+}
+
+// a key that won none of its eight bits is a false positive: its byte of `lost` becomes 8 (what k_admit_lost tests)
+__global__ __launch_bounds__(256) void k_xor_fp(const unsigned long long *__restrict__ pk, const uint32_t *__restrict__ ix,
+                                                const unsigned long long *__restrict__ planes, uint64_t plane_words, uint64_t npos,
+                                                uint8_t *__restrict__ lost) {
+	for (uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x; j < npos; j += (uint64_t)gridDim.x * 256) {
+		if (pk[j] == XOR_PAD) continue;
+		unsigned long long w = 0;
+#pragma unroll
+		for (int i = 0; i < 8; ++i) w |= planes[(uint64_t)i * plane_words + (j >> 6)];
+		if (!((w >> (j & 63)) & 1ull)) lost[ix[j]] = 8;
+	}
+}
+
+}  // namespace rg

@@ -228,3 +228,14 @@ def test_level_histograms_from_digit_bytes_and_from_records(oracle):
     gpu_vs_oracle(oracle, packed, offsets, lengths, 31, bloom_bits=None,
                   sweeps=(1 | 16 | (19 << 8), 1 | 16 | (19 << 8) | 0x100000, 1 | 16 | (13 << 8), 1 | 16 | (13 << 8) | 0x100000))
     gpu_vs_oracle(oracle, packed, offsets, lengths, 63, bloom_bits=200000, sweeps=(1 | 16 | (18 << 8), 1 | 16 | (18 << 8) | 0x100000))
+
+
+@pytest.mark.parametrize("k,log2_bits", [(31, 12), (31, 16), (31, 19), (21, 22), (31, 27), (63, 18), (63, 32), (31, 33)])
+def test_power_of_two_filters_by_key_partitions(oracle, k, log2_bits):
+    """rg_bloomx.h: one item per key partitioned by the key's origin, eight streams per region -- from a filter far
+    smaller than the key set (every late key a false positive) to the reference's cap of 2^33 bits; zero, one and two
+    partition levels below the one that makes the items; log and vertex table as the key array"""
+    packed, offsets, lengths = make_reads_numpy(genome=20000, read_len=150 if k < 63 else 200, n_reads=6000, seed=90 + log2_bits, error=0.02)
+    want = gpu_vs_oracle(oracle, packed, offsets, lengths, k, bloom_bits=1 << log2_bits, purge=False,
+                         sweeps=(1 | (10 << 8) | 0x1000000, 2 | 0x1000000))
+    assert want["builder"].stats()["bloom_partitioned"] == 2
