@@ -1477,6 +1477,7 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 		// redundancy (errors in most reads) then gets its larger log at once instead of losing a whole aggregation to
 		// find out.  Costs 1/256 of the aggregation; bit 18 of reserved0 runs it on small inputs too and always resizes (tests).
 		const bool force_probe = (h->cfg.reserved0 & 0x40000) != 0;
+		bool mostly_overflowing = false;  // the sample says that most buckets hold more k-mers than the LDS table: split them all from the start
 		if (attempt == 0 && !(h->cfg.reserved0 & 64) && (NBUCK >= (1u << 16) || force_probe)) {
 			const uint32_t P = force_probe ? std::max<uint32_t>((uint32_t)NBUCK / 4, 1u) : (uint32_t)NBUCK / 256;
 			bool fine = hipMemsetAsync(h->d_counters + PC_LOG_CURSOR, 0, 6 * sizeof(unsigned long long), h->stream) == hipSuccess;
@@ -1485,6 +1486,7 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 				agg.fast(h, agg.grid_for_buckets(P, n_cu), level_in, d_begin, P, k, log, log_cap, flag_unique, d_retry, m, (uint32_t)(24 - bits));
 				fine = hipGetLastError() == hipSuccess && sync_counters(h) == RG_OK;
 				const uint64_t n_retry = fine ? h->h_counters[PC_AGG_RETRY] : 0;
+				mostly_overflowing = fine && 2 * n_retry > P;
 				if (fine && n_retry && !h->h_counters[PC_LOG_OVF] && h->h_counters[PC_LOG_CURSOR] + n_retry * agg.key_limit() <= log_cap) {
 					agg.slow(h, agg.grid_for_buckets(n_retry, n_cu), level_in, d_begin, (uint32_t)n_retry, k, log, log_cap, flag_unique, d_retry, m, (uint32_t)(24 - bits));
 					fine = hipGetLastError() == hipSuccess && sync_counters(h) == RG_OK;
@@ -1516,7 +1518,13 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 		}
 		bool too_small = false;
 		hipError_t e0 = hipMemsetAsync(h->d_counters + PC_LOG_CURSOR, 0, 6 * sizeof(unsigned long long), h->stream);
-		if (e0 == hipSuccess) {
+		if (e0 == hipSuccess && mostly_overflowing) {
+			// an attempt at whole buckets would be thrown away for most of them (C2 with 1 % errors: 47 ms): every bucket goes
+			// through the splitting kernel at once
+			ProfScope ps(h, "k_aggregate_split");
+			agg.slow(h, agg_grid, level_in, d_begin, (uint32_t)NBUCK, k, log, log_cap, flag_unique, (const uint32_t *)nullptr, m, (uint32_t)(24 - bits));
+			e0 = hipGetLastError();
+		} else if (e0 == hipSuccess) {
 			ProfScope ps(h, "k_aggregate");
 			agg.fast(h, agg_grid, level_in, d_begin, (uint32_t)NBUCK, k, log, log_cap, flag_unique, d_retry, m, (uint32_t)(24 - bits));
 			e0 = hipGetLastError();
@@ -1557,16 +1565,6 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 		const uint64_t doubled = (h->cfg.reserved0 & 64) ? 0 : 2 * (log_cap - log_slack);
 		log_cap = ((attempt == 0 && doubled) ? std::min<uint64_t>(occ_bound, doubled) : occ_bound) + log_slack;
 	}
-#ifdef RG_AGG_TIMING
-	{
-		unsigned long long dbg[16];
-		(void)hipMemcpyFromSymbol(dbg, HIP_SYMBOL(g_dbg), sizeof dbg);
-		fprintf(stderr, "[raygraph] agg cycles of thread 0 (sum over workgroups): hash %llu ph1 %llu barA %llu ph2 %llu barB %llu expand_end %llu flush %llu expand_mid %llu\n", dbg[0], dbg[1], dbg[2],
-		        dbg[3], dbg[4], dbg[5], dbg[6], dbg[7]);
-		memset(dbg, 0, sizeof dbg);
-		(void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), dbg, sizeof dbg);
-	}
-#endif
 	pool_free(dev, d_retry);
 	cleanup();
 	*out_log = log;

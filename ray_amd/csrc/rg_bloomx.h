@@ -33,7 +33,7 @@ static constexpr int XOR_REGION_LOG2_MAX = 14;  // at most 2^14 first-touch stam
 static constexpr int XOR_TILE = 4096;            // 16-byte items per scatter tile (64 KB of LDS)
 static constexpr int XOR_THREADS = 512;
 static constexpr unsigned long long XOR_PAD = ~0ull;  // padding entry of the packed array
-static constexpr int XOR_PER = 24;               // items a thread of k_xor_region keeps in registers
+static constexpr int XOR_SPER = 3;               // items per stream a thread of k_xor_region keeps in registers (8 streams)
 
 struct Item16 {
 	unsigned long long a;  // o << 31 | slot index
@@ -243,61 +243,39 @@ __global__ __launch_bounds__(THREADS) void k_xor_region(const unsigned long long
 			sb[i] = part_begin[q];
 			pre[i + 1] = pre[i] + (uint32_t)(part_begin[q + 1] - sb[i]);
 		}
-		const uint32_t total = pre[8];
 		__syncthreads();
-		if (total <= (uint32_t)THREADS * XOR_PER) {
-			// one read: the items stay in registers between the two passes
-			unsigned long long item[XOR_PER];
-			uint32_t where[XOR_PER];  // hash index << 28 | plane word (relative to the stream's first)
+		uint32_t longest = 0;
 #pragma unroll
-			for (int u = 0; u < XOR_PER; ++u) {
-				const uint32_t t = threadIdx.x + (uint32_t)THREADS * u;
-				item[u] = XOR_PAD;
-				where[u] = 0;
-				if (t < total) {
-					uint32_t i = 0;
+		for (int i = 0; i < 8; ++i) longest = max(longest, pre[i + 1] - pre[i]);
+		if (longest <= (uint32_t)THREADS * XOR_SPER) {
+			// one read: the items stay in registers between the two passes, XOR_SPER per stream and thread (the stream index
+			// is a compile-time constant everywhere: no selects, the constants stay in scalar registers)
+			unsigned long long item[8][XOR_SPER];
 #pragma unroll
-					for (int q = 1; q < 8; ++q) i += (t >= pre[q]) ? 1u : 0u;
-					unsigned long long b = sb[0];
-					uint32_t p0 = 0;
+			for (int i = 0; i < 8; ++i) {
+				const uint32_t len = pre[i + 1] - pre[i];
 #pragma unroll
-					for (int q = 1; q < 8; ++q)
-						if (i == (uint32_t)q) {
-							b = sb[q];
-							p0 = pre[q];
-						}
-					item[u] = pk[b + (t - p0)];
-					where[u] = i;
+				for (int u = 0; u < XOR_SPER; ++u) {
+					const uint32_t t = threadIdx.x + (uint32_t)THREADS * u;
+					item[i][u] = (t < len) ? pk[sb[i] + t] : XOR_PAD;
 				}
 			}
 #pragma unroll
-			for (int u = 0; u < XOR_PER; ++u)
-				if (item[u] != XOR_PAD) {
-					const uint32_t bit = ((uint32_t)item[u] ^ K.low[where[u]]) & cmask;
-					atomicMin(&s_cell[bit], item[u] >> 14);
-				}
+			for (int i = 0; i < 8; ++i)
+#pragma unroll
+				for (int u = 0; u < XOR_SPER; ++u)
+					if (item[i][u] != XOR_PAD) atomicMin(&s_cell[((uint32_t)item[i][u] ^ K.low[i]) & cmask], item[i][u] >> 14);
 			__syncthreads();
 #pragma unroll
-			for (int u = 0; u < XOR_PER; ++u) {
-				const uint32_t t = threadIdx.x + (uint32_t)THREADS * u;
-				if (t - lane < total) {  // wave-uniform: the 64 positions of a wavefront lie in one stream
-					bool win = false;
-					if (item[u] != XOR_PAD) {
-						const uint32_t bit = ((uint32_t)item[u] ^ K.low[where[u]]) & cmask;
-						win = s_cell[bit] == (item[u] >> 14);
-					}
-					const unsigned long long bal = __ballot(win);
-					if (lane == 0) {
-						const uint32_t i = where[u];
-						unsigned long long b = sb[0];
-						uint32_t p0 = 0;
+			for (int i = 0; i < 8; ++i) {
+				const uint32_t len = pre[i + 1] - pre[i];
 #pragma unroll
-						for (int q = 1; q < 8; ++q)
-							if (i == (uint32_t)q) {
-								b = sb[q];
-								p0 = pre[q];
-							}
-						planes[(uint64_t)i * plane_words + ((b + (t - p0)) >> 6)] = bal;
+				for (int u = 0; u < XOR_SPER; ++u) {
+					const uint32_t t = threadIdx.x + (uint32_t)THREADS * u;
+					if (t - lane < len) {  // wave-uniform: every stream is a whole number of wavefronts long
+						const bool win = item[i][u] != XOR_PAD && s_cell[((uint32_t)item[i][u] ^ K.low[i]) & cmask] == (item[i][u] >> 14);
+						const unsigned long long bal = __ballot(win);
+						if (lane == 0) planes[(uint64_t)i * plane_words + ((sb[i] + t) >> 6)] = bal;
 					}
 				}
 			}

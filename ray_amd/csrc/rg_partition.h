@@ -1133,7 +1133,7 @@ __global__ __launch_bounds__(64 * AGG_WAVES) void k_aggregate(const Rec<W> *__re
 	uint32_t b = blockIdx.x * AGG_WAVES + wave;
 	uint64_t cb = 0, ce = 0;
 	if (b < nbuckets) {
-		const uint32_t bb = SLOW ? bucket_list[b] : b;
+		const uint32_t bb = (SLOW && bucket_list) ? bucket_list[b] : b;  // no list: every bucket
 		cb = bucket_begin[bb];
 		ce = bucket_begin[bb + 1];
 	}
@@ -1145,7 +1145,7 @@ __global__ __launch_bounds__(64 * AGG_WAVES) void k_aggregate(const Rec<W> *__re
 		const uint32_t b2 = b + stride;  // the bucket after this one: its bounds are fetched now, used at the last round
 		uint64_t nb_begin = 0, nb_end = 0;
 		if (b2 < nbuckets) {
-			const uint32_t bb = SLOW ? bucket_list[b2] : b2;
+			const uint32_t bb = (SLOW && bucket_list) ? bucket_list[b2] : b2;
 			nb_begin = bucket_begin[bb];
 			nb_end = bucket_begin[bb + 1];
 		}
@@ -1397,12 +1397,6 @@ __device__ __forceinline__ bool wg_upsert(WgTables<W, KS, RS> &t, bool active, u
 	return !searching;
 }
 
-#ifdef RG_AGG_TIMING
-static __device__ unsigned long long g_dbg[16];
-#define DBG_T(i) do { if (tid == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); dbg_acc[i] += now_ - dbg_t; dbg_t = now_; } } while (0)
-#else
-#define DBG_T(i) do {} while (0)
-#endif
 template <int W, int THREADS, int KS, int RS, bool SLOW>
 __global__ __launch_bounds__(THREADS) void k_aggregate_wg(const Rec<W> *__restrict__ recs, const unsigned long long *__restrict__ bucket_begin,
                                                           uint32_t nbuckets, int k, Slot *__restrict__ log, uint64_t log_cap,
@@ -1410,8 +1404,10 @@ __global__ __launch_bounds__(THREADS) void k_aggregate_wg(const Rec<W> *__restri
                                                           const uint32_t *__restrict__ bucket_list, uint32_t *__restrict__ retry_list, int m,
                                                           uint32_t rbits) {
 	constexpr int NB = 2 * W;
+	constexpr uint32_t NWAVES = THREADS / 64;
 	constexpr uint32_t KLIMIT = KS * 5 / 8;  // a round of the expansion starts only at or below this: at most THREADS more keys arrive
-	constexpr uint32_t RLIMIT = RS / 2;
+	constexpr uint32_t RLIMIT = RS / 2;      // distinct records the record table takes before it is expanded
+	constexpr uint32_t GROUP = 32;           // distinct records a wavefront expands at a time
 	static_assert(KLIMIT + THREADS < KS, "the k-mer table must hold a full round above its limit");
 	static_assert((KS & (KS - 1)) == 0 && (RS & (RS - 1)) == 0 && KS <= 65536 && RS <= 65536, "table sizes");
 	__shared__ WgTables<W, KS, RS> T;
@@ -1419,12 +1415,8 @@ __global__ __launch_bounds__(THREADS) void k_aggregate_wg(const Rec<W> *__restri
 	const uint64_t mask0 = (2 * k >= 64) ? ~0ull : ((1ull << (2 * k)) - 1);
 	const uint64_t mask1 = (k > 32) ? ((1ull << (2 * k - 64)) - 1) : 0ull;
 	unsigned long long keys_written = 0;  // thread 0 only
-	uint32_t nonunique_flushes = 0;
-	bool log_full = false;  // uniform
-	uint32_t round = 0;     // uniform: parity selects the word of T.any in use
-#ifdef RG_AGG_TIMING
-	unsigned long long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dbg_t = __builtin_readcyclecounter();
-#endif
+	bool log_full = false;                // uniform
+	volatile unsigned long long *const vfp = T.rfp;
 
 	auto clear_all = [&]() {
 		for (uint32_t i = tid; i < (uint32_t)KS; i += THREADS) {
@@ -1446,7 +1438,6 @@ __global__ __launch_bounds__(THREADS) void k_aggregate_wg(const Rec<W> *__restri
 			T.flag = 0;
 			T.any[0] = T.any[1] = 0;
 		}
-		round = 0;
 		lds_barrier();
 	};
 
@@ -1461,7 +1452,7 @@ __global__ __launch_bounds__(THREADS) void k_aggregate_wg(const Rec<W> *__restri
 			if (base + n > log_cap) atomicAdd(&counters[PC_LOG_OVF], 1ull);
 			T.log_base = base;
 			keys_written += n;
-			if (!mark) nonunique_flushes++;
+			if (!mark) atomicAdd(&counters[PC_NONUNIQUE], 1ull);
 		}
 		lds_barrier();
 		const unsigned long long base = T.log_base;
@@ -1492,15 +1483,20 @@ __global__ __launch_bounds__(THREADS) void k_aggregate_wg(const Rec<W> *__restri
 	};
 
 	// every distinct record of the record table goes through the k-mer table once, weighted; of its k-mers only those
-	// of sub-pass `sub` (of `nsub`, a power of two) are taken.  Called by all threads; returns false when the k-mer
-	// table would overfill (the caller drops the attempt).  Leaves the record table empty.
+	// of sub-pass `sub` (of `nsub`, a power of two) are taken.  Called by all threads behind a barrier; returns false when
+	// the k-mer table would overfill (the caller drops the attempt).  Leaves the record table empty.  The wavefronts
+	// fetch groups of GROUP records from a counter (T.any[0]) until none is left.
 	auto expand = [&](uint32_t sub, uint32_t nsub) -> bool {
 		const uint32_t n = T.rnlist;  // settled: the callers are behind a barrier
-		for (uint32_t e0 = wave * 64u; e0 < n; e0 += THREADS) {
-			const uint32_t e = e0 + lane;
+		for (;;) {
+			uint32_t g0 = 0;
+			if (lane == 0) g0 = atomicAdd(&T.any[0], GROUP);
+			g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)g0);
+			if (g0 >= n) break;
+			const uint32_t e = g0 + lane;
 			uint32_t rlen = 0, rsl = 0, rweight = 0;
 			uint64_t rstamp = 0;
-			if (e < n) {
+			if (lane < GROUP && e < n) {
 				rsl = T.rlist[e];
 				rlen = ((uint32_t)T.rtag[rsl] & 63u) + 1;
 				rweight = T.rcnt[rsl];
@@ -1511,11 +1507,11 @@ __global__ __launch_bounds__(THREADS) void k_aggregate_wg(const Rec<W> *__restri
 			}
 			uint32_t incl = rlen;  // inclusive prefix sums of the lengths
 #pragma unroll
-			for (int d = 1; d < 64; d <<= 1) {
+			for (int d = 1; d < (int)GROUP; d <<= 1) {
 				const uint32_t o = __shfl_up(incl, d);
 				if (lane >= (uint32_t)d) incl += o;
 			}
-			const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+			const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, GROUP - 1);
 			const uint32_t rpre = incl - rlen;
 			for (uint32_t t0 = 0; t0 < total; t0 += 64) {
 				// the fill as this wavefront sees it now; whatever it misses is in flight and covered by the margin above the limit
@@ -1526,11 +1522,11 @@ __global__ __launch_bounds__(THREADS) void k_aggregate_wg(const Rec<W> *__restri
 				const uint32_t t = t0 + lane;
 				uint32_t own = 0;  // number of records whose prefix sum is <= t (all lanes take part in the shuffles)
 #pragma unroll
-				for (uint32_t st = 32; st; st >>= 1) {
+				for (uint32_t st = GROUP / 2; st; st >>= 1) {
 					const uint32_t v = (uint32_t)__shfl((int)incl, (int)(own + st - 1));
 					if (v <= t) own += st;
 				}
-				own = own < 63u ? own : 63u;
+				own = own < GROUP - 1 ? own : GROUP - 1;
 				const uint32_t sl = (uint32_t)__shfl((int)rsl, (int)own);
 				const uint32_t i = t - (uint32_t)__shfl((int)rpre, (int)own);
 				const uint32_t weight = (uint32_t)__shfl((int)rweight, (int)own);
@@ -1572,159 +1568,146 @@ __global__ __launch_bounds__(THREADS) void k_aggregate_wg(const Rec<W> *__restri
 		if (tid == 0) {
 			T.rfill = 0;
 			T.rnlist = 0;
+			T.any[0] = 0;
 		}
 		lds_barrier();
 		return ok;
 	};
 
 	clear_all();
-	Rec<W> nxt;  // this thread's record of the coming round
-#pragma unroll
-	for (int i = 0; i <= NB; ++i) nxt.w[i] = 0;
-	bool prefetched = false;  // nxt holds records [cb, cb + THREADS) of the current bucket
-	uint64_t cb = 0, ce = 0;
-	if (blockIdx.x < nbuckets) {
-		const uint32_t bb = SLOW ? bucket_list[blockIdx.x] : blockIdx.x;
-		cb = bucket_begin[bb];
-		ce = bucket_begin[bb + 1];
-	}
 	for (uint32_t b = blockIdx.x; b < nbuckets && !log_full; b += gridDim.x) {
-		// the bucket after this one: its bounds are requested now, its first round of records during this bucket's last
-		uint64_t nb_begin = 0, nb_end = 0;
-		if (b + gridDim.x < nbuckets) {
-			const uint32_t bb = SLOW ? bucket_list[b + gridDim.x] : b + gridDim.x;
-			nb_begin = bucket_begin[bb];
-			nb_end = bucket_begin[bb + 1];
-		}
-		bool next_ready = false;  // nxt already holds the next bucket's first round
-		// one pass over the bucket's records for sub-pass `sub` of `nsub`; true = the k-mer table overflowed
+		const uint32_t bb = (SLOW && bucket_list) ? bucket_list[b] : b;  // no list: every bucket
+		const uint64_t cb = bucket_begin[bb], ce = bucket_begin[bb + 1];
+		const uint32_t nblk = (uint32_t)((ce - cb + 63) / 64);  // blocks of 64 records, dealt to the wavefronts from a counter (T.any[1])
+		// One pass over the bucket's records for sub-pass `sub` of `nsub`; true = the k-mer table overflowed.  The wavefronts
+		// work through blocks on their own (no barrier per block: a slot of the record table is claimed busy, filled and then
+		// published ready by its owner, everybody else waits for ready before comparing) and meet only when the record
+		// table has reached its limit -- the wavefront that needs a new slot waits at the barrier, the others arrive as
+		// they run into the limit too or run out of blocks -- for the expansion, and at the end.
 		auto pass = [&](uint32_t sub, uint32_t nsub) -> bool {
-			bool overflow = false;
 			const uint32_t rl = SLOW ? min(31u - (uint32_t)__clz((int)nsub), rbits) : 0u;  // record levels of the split, then hash levels
 			const uint32_t rmask = (1u << rl) - 1u, rsub = sub & rmask;
 			const uint32_t hsub = sub >> rl, hn = nsub >> rl;
-			next_ready = false;
-			if (!prefetched && cb + tid < ce) nxt = recs[cb + tid];
-			prefetched = false;
-			for (uint64_t base = cb; base < ce && !overflow; base += THREADS) {
-				const Rec<W> rec = nxt;
-				bool pending = base + tid < ce;
-				if (SLOW && rl && pending && (rec_bucket<W>(rec, m) & rmask) != rsub) pending = false;  // a record of another pass
-				if (base + THREADS < ce) {
-					if (base + THREADS + tid < ce) nxt = recs[base + THREADS + tid];
-				} else if (sub + 1 == nsub) {  // last round of the last sub-pass: the next bucket's first round
-					if (nb_begin + tid < nb_end) nxt = recs[nb_begin + tid];
-					prefetched = true;
-					next_ready = true;
-				}
-				uint64_t bw[NB], stamp0 = 0;
-				unsigned long long fp = 0;
-				uint32_t tag = 0, sl = 0, rstep = 1;
-				{
-					const uint64_t hdr = rec.w[NB];
-					tag = (uint32_t)(hdr >> 16) & 0x7FFFu;
-					stamp0 = ((hdr >> 31) << 16) | ((uint32_t)hdr & 0xFFFFu);
-					uint64_t h = (uint64_t)tag * 0x9E3779B97F4A7C15ull;
+			if (tid == 0) {
+				T.any[1] = NWAVES;  // the first NWAVES blocks are taken
+				T.flag = (T.flag == 2) ? 2u : 0u;
+			}
+			if (tid == 0) T.log_base = 0;  // counts the wavefronts that have run out of blocks (the word is free until the flush)
+			lds_barrier();
+			uint32_t blk = wave, next_blk = 0;
+			bool finished = false, counted = false, carry = false;
+			Rec<W> nxt;
 #pragma unroll
-					for (int i = 0; i < NB; ++i) {
-						bw[i] = rec.w[i];
-						h = (h ^ bw[i]) * 0xC2B2AE3D27D4EB4Full;
-						h ^= h >> 29;
+			for (int i = 0; i <= NB; ++i) nxt.w[i] = 0;
+			if (blk < nblk && cb + (uint64_t)blk * 64 + lane < ce) nxt = recs[cb + (uint64_t)blk * 64 + lane];
+			uint64_t bw[NB], stamp0 = 0;
+			unsigned long long fp = 0;
+			uint32_t tag = 0, sl = 0, home = 0, rstep = 1;
+			bool pending = false;
+			for (;;) {
+				while (!finished) {
+					if (!carry) {
+						if (blk >= nblk) {
+							finished = true;
+							break;
+						}
+						const Rec<W> rec = nxt;
+						pending = cb + (uint64_t)blk * 64 + lane < ce;
+						if (SLOW && rl && pending && (rec_bucket<W>(rec, m) & rmask) != rsub) pending = false;  // a record of another pass
+						next_blk = 0;
+						if (lane == 0) next_blk = atomicAdd(&T.any[1], 1u);
+						next_blk = (uint32_t)__builtin_amdgcn_readfirstlane((int)next_blk);
+						if (next_blk < nblk && cb + (uint64_t)next_blk * 64 + lane < ce) nxt = recs[cb + (uint64_t)next_blk * 64 + lane];
+						const uint64_t hdr = rec.w[NB];
+						tag = (uint32_t)(hdr >> 16) & 0x7FFFu;
+						stamp0 = ((hdr >> 31) << 16) | ((uint32_t)hdr & 0xFFFFu);
+						uint64_t h = (uint64_t)tag * 0x9E3779B97F4A7C15ull;
+#pragma unroll
+						for (int i = 0; i < NB; ++i) {
+							bw[i] = rec.w[i];
+							h = (h ^ bw[i]) * 0xC2B2AE3D27D4EB4Full;
+							h ^= h >> 29;
+						}
+						h *= 0xBF58476D1CE4E5B9ull;
+						h ^= h >> 32;
+						fp = h | (1ull << 63) | 1ull;  // ready form; the busy form has bit 0 clear and is never 0
+						home = (uint32_t)(h >> 40) & (RS - 1);
+						rstep = ((uint32_t)(h >> 20) & (RS - 1)) | 1u;
 					}
-					h *= 0xBF58476D1CE4E5B9ull;
-					h ^= h >> 32;
-					fp = h | 1ull;
-					sl = (uint32_t)(h >> 40) & (RS - 1);
-					rstep = ((uint32_t)(h >> 20) & (RS - 1)) | 1u;
-				}
-				DBG_T(0);  // load/hash
-				for (;;) {
-					bool owner = false, cand = false, searching = pending;
-					for (uint32_t probe = 0; probe < (uint32_t)RS && __any(searching); ++probe) {
-						unsigned long long cur = searching ? T.rfp[sl] : 1ull;
+					sl = home;  // (again after an expansion: the table is empty then)
+					// claim or find this record's slot, count it
+					bool searching = pending, blocked = false;
+					for (uint32_t probe = 0; probe < 4u * RS && __any(searching); ++probe) {
+						unsigned long long cur = searching ? vfp[sl] : 1ull;
 						const bool empty = searching && cur == 0;
-						// a new slot needs a ticket below the limit; one atomic per wavefront hands them out
-						const uint32_t ticket = wave_claim(&T.rfill, empty, lane);
-						const bool full = empty && ticket >= RLIMIT;  // the table is at its limit: wait for the expansion
+						const uint32_t ticket = wave_claim(&T.rfill, empty, lane);  // a new slot needs a ticket below the limit
+						const bool full = empty && ticket >= RLIMIT;
 						bool won = false;
 						if (empty && !full) {
-							cur = atomicCAS(&T.rfp[sl], 0ull, fp);
+							cur = atomicCAS(&T.rfp[sl], 0ull, fp & ~1ull);
 							won = cur == 0;
 						}
 						const uint32_t back = (uint32_t)__popcll(__ballot(empty && !won));  // tickets that took no slot
 						if (back && lane == 0) atomicSub(&T.rfill, back);
+						const uint32_t li = wave_claim(&T.rnlist, won, lane);
 						if (won) {
-							owner = cand = true;
-							searching = false;
-						} else if (full) {
-							searching = false;
-						} else if (searching && cur == fp) {
-							cand = true;
-							searching = false;
-						} else if (searching) {
-							sl = (sl + rstep) & (RS - 1);
-						}
-					}
-					{
-						const uint32_t li = wave_claim(&T.rnlist, owner, lane);
-						if (owner) {
 #pragma unroll
 							for (int i = 0; i < NB; ++i) T.rw[i][sl] = bw[i];
 							T.rtag[sl] = (uint16_t)tag;
 							T.rlist[li] = (uint16_t)sl;
-						}
-					}
-					DBG_T(1);  // phase 1 (thread 0's wave)
-					lds_barrier();
-					DBG_T(2);  // barrier A
-					if (cand) {
-						bool same = true;
-						if (!owner) {
-							same = ((uint32_t)T.rtag[sl] == tag);
-#pragma unroll
-							for (int i = 0; i < NB; ++i) same = same && (T.rw[i][sl] == bw[i]);
-						}
-						if (same) {
+							asm volatile("" ::: "memory");  // LDS operations of a wavefront are carried out in order: the slot is complete before it reads as ready
+							vfp[sl] = fp;
 							atomicAdd(&T.rcnt[sl], 1u);
 							atomicMin(reinterpret_cast<unsigned long long *>(&T.rstamp[sl]), (unsigned long long)stamp0);
+							searching = false;
 							pending = false;
-						} else {
-							sl = (sl + rstep) & (RS - 1);  // same fingerprint, different record: keep probing
+						} else if (full) {
+							searching = false;  // stays pending: the table is at its limit, wait for the expansion
+							blocked = true;
+						} else if (searching && (cur | 1ull) == fp) {
+							if (cur & 1ull) {  // published: is it this record?
+								asm volatile("" ::: "memory");
+								bool same = ((uint32_t)T.rtag[sl] == tag);
+#pragma unroll
+								for (int i = 0; i < NB; ++i) same = same && (T.rw[i][sl] == bw[i]);
+								if (same) {
+									atomicAdd(&T.rcnt[sl], 1u);
+									atomicMin(reinterpret_cast<unsigned long long *>(&T.rstamp[sl]), (unsigned long long)stamp0);
+									searching = false;
+									pending = false;
+								} else {
+									sl = (sl + rstep) & (RS - 1);  // same fingerprint, different record
+								}
+							}
+							// else: its owner is still filling it in -- look again
+						} else if (searching) {
+							sl = (sl + rstep) & (RS - 1);
 						}
 					}
-					if (pending) T.any[round & 1u] = 1u;
-					if (tid == 0) T.any[(round + 1u) & 1u] = 0u;  // nobody reads or sets that word before the next barrier pair
-					DBG_T(3);  // phase 2
-					lds_barrier();
-					DBG_T(4);  // barrier B
-					const bool left = T.any[round & 1u] != 0u;
-					++round;
-					if (!left) break;
-					// somebody is left: the table was at its limit (or fingerprints collided)
-					if (T.rfill >= RLIMIT) {
-						lds_barrier();
-						DBG_T(0);
-						if (!expand(hsub, hn)) {
-							overflow = true;
-							break;
-						}
-						DBG_T(7);  // expansions inside the bucket
+					if (__any(blocked || searching)) {  // (searching: the probe bound ran out -- never seen; the expansion empties the table)
+						carry = true;                    // the lanes that are still pending try again after the expansion
+						break;
 					}
+					carry = false;
+					blk = next_blk;
 				}
+				if (finished && !counted) {
+					if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(&T.log_base), 1ull);
+					counted = true;
+				}
+				lds_barrier();
+				const bool all_done = T.log_base == (unsigned long long)NWAVES;
+				if (!expand(hsub, hn)) return true;
+				if (all_done) break;
 			}
-			DBG_T(0);
-			if (!overflow) overflow = !expand(hsub, hn);
-			DBG_T(5);  // final expansion
-			return overflow;
+			return false;
 		};
 		if (!SLOW) {
 			if (!pass(0, 1)) {
 				flush();  // once per bucket: the entries are unique in the log
-				DBG_T(6);
 			} else {      // leave the bucket to the second launch; nothing of it was written
 				clear_all();
 				if (tid == 0) retry_list[atomicAdd(&counters[PC_AGG_RETRY], 1ull)] = b;
-				prefetched = next_ready;
 			}
 		} else {
 			// node (nsub, sub) = the k-mers whose log2(nsub) split bits equal sub; see k_aggregate
@@ -1751,7 +1734,6 @@ __global__ __launch_bounds__(THREADS) void k_aggregate_wg(const Rec<W> *__restri
 					continue;
 				}
 				clear_all();  // nothing of this node was written
-				prefetched = false;
 				if ((nsub >> min(31u - (uint32_t)__clz((int)nsub), rbits)) < AGG_MAX_SUBPASSES) {
 					nsub *= 2;  // low half first: sub keeps its value
 				} else {
@@ -1764,17 +1746,8 @@ __global__ __launch_bounds__(THREADS) void k_aggregate_wg(const Rec<W> *__restri
 		}
 		if (tid == 0) T.flag = 0;
 		lds_barrier();
-		cb = nb_begin;
-		ce = nb_end;
 	}
-#ifdef RG_AGG_TIMING
-	if (tid == 0)
-		for (int i = 0; i < 8; ++i) atomicAdd(&g_dbg[i], dbg_acc[i]);
-#endif
-	if (tid == 0) {
-		if (keys_written) atomicAdd(&counters[PC_LOG_KEYS], keys_written);
-		if (nonunique_flushes) atomicAdd(&counters[PC_NONUNIQUE], (unsigned long long)nonunique_flushes);
-	}
+	if (tid == 0 && keys_written) atomicAdd(&counters[PC_LOG_KEYS], keys_written);
 }
 
 // Fallback of the record path: every k-mer of every record goes straight to the vertex table (one upsert per
