@@ -949,16 +949,37 @@ hipError_t pool_alloc(int device, void **out, uint64_t bytes) {
 		}
 	}
 	hipError_t e = hipMalloc(out, bytes);
-	if (e != hipSuccess) {  // give cached blocks back and retry once
+	if (e != hipSuccess) {
+		// The device is full.  A cached block of any larger size is better than releasing memory (hipFree of a touched
+		// multi-GiB block costs hundreds of milliseconds); failing that, cached blocks go back to the driver, largest first,
+		// until the request fits.
 		(void)hipGetLastError();
-		std::vector<void *> drop;
 		{
 			std::lock_guard<std::mutex> lk(g_pool.mu);
-			for (auto &kv : g_pool.free_blocks[device]) drop.push_back(kv.second);
-			g_pool.free_blocks[device].clear();
+			auto &fb = g_pool.free_blocks[device];
+			auto it = fb.lower_bound(bytes);
+			if (it != fb.end()) {
+				*out = it->second;
+				g_pool.live[device][*out] = it->first;
+				fb.erase(it);
+				return hipSuccess;
+			}
 		}
-		for (void *p : drop) (void)hipFree(p);
-		e = hipMalloc(out, bytes);
+		for (;;) {
+			void *victim = nullptr;
+			{
+				std::lock_guard<std::mutex> lk(g_pool.mu);
+				auto &fb = g_pool.free_blocks[device];
+				if (fb.empty()) break;
+				auto last = std::prev(fb.end());
+				victim = last->second;
+				fb.erase(last);
+			}
+			(void)hipFree(victim);
+			e = hipMalloc(out, bytes);
+			if (e == hipSuccess) break;
+			(void)hipGetLastError();
+		}
 		if (e != hipSuccess) return e;
 	}
 	std::lock_guard<std::mutex> lk(g_pool.mu);
@@ -1465,7 +1486,13 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	// entries may be marked unique unless other ranks aggregate the same keys (entry route, size > 1)
 	const uint32_t flag_unique = (h->cfg.size == 1 || ext) ? 1u : 0u;
 	for (int attempt = 0;; ++attempt) {
-		if (pool_alloc(dev, (void **)&log, log_cap * sizeof(Slot)) != hipSuccess) {
+		const bool force_probe = (h->cfg.reserved0 & 0x40000) != 0;
+		const bool will_probe = attempt == 0 && !(h->cfg.reserved0 & 64) && (NBUCK >= (1u << 16) || force_probe);
+		const uint32_t P = force_probe ? std::max<uint32_t>((uint32_t)NBUCK / 4, 1u) : (uint32_t)NBUCK / 256;
+		// the sample runs on a small log of its own (one entry per occurrence of its share would always do; 1.5 x the average
+		// share + the chunks left open is what it gets), the real log is allocated once its size is known
+		const uint64_t alloc_cap = will_probe ? std::min<uint64_t>(log_cap, (uint64_t)((double)occ_bound * 1.5 * (double)P / (double)NBUCK) + log_slack + (1ull << 16)) : log_cap;
+		if (pool_alloc(dev, (void **)&log, alloc_cap * sizeof(Slot)) != hipSuccess) {
 			(void)hipGetLastError();
 			log = nullptr;
 			pool_free(dev, d_retry);
@@ -1476,19 +1503,17 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 		// aggregated alone, overflowing buckets included, and the log sized from what it produced: an input of little
 		// redundancy (errors in most reads) then gets its larger log at once instead of losing a whole aggregation to
 		// find out.  Costs 1/256 of the aggregation; bit 18 of reserved0 runs it on small inputs too and always resizes (tests).
-		const bool force_probe = (h->cfg.reserved0 & 0x40000) != 0;
 		bool mostly_overflowing = false;  // the sample says that most buckets hold more k-mers than the LDS table: split them all from the start
-		if (attempt == 0 && !(h->cfg.reserved0 & 64) && (NBUCK >= (1u << 16) || force_probe)) {
-			const uint32_t P = force_probe ? std::max<uint32_t>((uint32_t)NBUCK / 4, 1u) : (uint32_t)NBUCK / 256;
+		if (will_probe) {
 			bool fine = hipMemsetAsync(h->d_counters + PC_LOG_CURSOR, 0, 6 * sizeof(unsigned long long), h->stream) == hipSuccess;
 			if (fine) {
 				ProfScope ps(h, "k_aggregate_probe");
-				agg.fast(h, agg.grid_for_buckets(P, n_cu), level_in, d_begin, P, k, log, log_cap, flag_unique, d_retry, m, (uint32_t)(24 - bits));
+				agg.fast(h, agg.grid_for_buckets(P, n_cu), level_in, d_begin, P, k, log, alloc_cap, flag_unique, d_retry, m, (uint32_t)(24 - bits));
 				fine = hipGetLastError() == hipSuccess && sync_counters(h) == RG_OK;
 				const uint64_t n_retry = fine ? h->h_counters[PC_AGG_RETRY] : 0;
 				mostly_overflowing = fine && 2 * n_retry > P;
-				if (fine && n_retry && !h->h_counters[PC_LOG_OVF] && h->h_counters[PC_LOG_CURSOR] + n_retry * agg.key_limit() <= log_cap) {
-					agg.slow(h, agg.grid_for_buckets(n_retry, n_cu), level_in, d_begin, (uint32_t)n_retry, k, log, log_cap, flag_unique, d_retry, m, (uint32_t)(24 - bits));
+				if (fine && n_retry && !h->h_counters[PC_LOG_OVF] && h->h_counters[PC_LOG_CURSOR] + n_retry * agg.key_limit() <= alloc_cap) {
+					agg.slow(h, agg.grid_for_buckets(n_retry, n_cu), level_in, d_begin, (uint32_t)n_retry, k, log, alloc_cap, flag_unique, d_retry, m, (uint32_t)(24 - bits));
 					fine = hipGetLastError() == hipSuccess && sync_counters(h) == RG_OK;
 				} else if (n_retry) {
 					fine = false;  // the sample alone does not fit: the attempt below finds out and the log doubles
@@ -1500,20 +1525,18 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 				if (getenv("RG_DEBUG"))
 					fprintf(stderr, "[raygraph] log probe: %llu keys in %u of %llu buckets -> %llu entries expected, log holds %llu\n",
 					        (unsigned long long)h->h_counters[PC_LOG_KEYS], P, (unsigned long long)NBUCK, (unsigned long long)proj,
-					        (unsigned long long)(log_cap - log_slack));
-				if (proj + log_slack > log_cap || force_probe) {
-					pool_free(dev, log);
-					log_cap = proj + log_slack;
-					if (pool_alloc(dev, (void **)&log, log_cap * sizeof(Slot)) != hipSuccess) {
-						(void)hipGetLastError();
-						log = nullptr;
-						pool_free(dev, d_retry);
-						cleanup();
-						return RG_OK;
-					}
-				}
+					        (unsigned long long)(alloc_cap - log_slack));
+				log_cap = std::max<uint64_t>(proj, 1ull << 20) + log_slack;
 			} else {
 				(void)hipGetLastError();
+			}
+			pool_free(dev, log);  // the sample's log; the real one has the size the sample asks for (or, if the sample failed, the default)
+			log = nullptr;
+			if (pool_alloc(dev, (void **)&log, log_cap * sizeof(Slot)) != hipSuccess) {
+				(void)hipGetLastError();
+				pool_free(dev, d_retry);
+				cleanup();
+				return RG_OK;
 			}
 		}
 		bool too_small = false;
@@ -1916,7 +1939,7 @@ static int bloom_partitioned(rg_handle *h, Table &T, uint64_t m_bits, uint64_t k
 static int bloom_xor(rg_handle *h, Table &T, uint64_t m_bits, uint64_t keys, bool *ok) {
 	*ok = false;
 	const int dev = h->cfg.device;
-	if (m_bits == 0 || (m_bits & (m_bits - 1)) || T.cap >= (1ull << 31) || keys == 0) return RG_OK;
+	if (m_bits == 0 || (m_bits & (m_bits - 1)) || T.cap >= (1ull << 32) || keys == 0) return RG_OK;
 	int B = 0;
 	while ((1ull << B) < m_bits) B++;
 	// region size: 2^14 bits, one workgroup of 1024 threads per CU (C2 with 1 % errors: k_xor_region 58 ms; 2^13 bits x 2
@@ -1947,9 +1970,11 @@ static int bloom_xor(rg_handle *h, Table &T, uint64_t m_bits, uint64_t keys, boo
 	auto cleanup = [&]() {
 		pool_free(dev, A);
 		pool_free(dev, Bb);
-		pool_free(dev, pk);
+		if ((void *)pk != (void *)A) {
+			pool_free(dev, pk);
+			pool_free(dev, ix);
+		}
 		pool_free(dev, planes);
-		pool_free(dev, ix);
 		pool_free(dev, d_seg);
 		pool_free(dev, d_hist);
 		pool_free(dev, d_begin);
@@ -1961,10 +1986,18 @@ static int bloom_xor(rg_handle *h, Table &T, uint64_t m_bits, uint64_t keys, boo
 	const uint64_t plane_words = (npos_cap + 63) / 64;
 	const uint64_t NB = std::max<uint64_t>(P, 256);
 	const uint64_t SEGMAX = 65536;
+	// with a middle level the last one reads Bb and A is free by then: the packed words and slot indices (12 B per position)
+	// take its place (16 B per key) when they fit -- at C5's share per GPU (3.5e9 keys) that is 42 GB less at the peak
+	const bool alias = c2 && npos_cap * 12 + 256 <= keys * sizeof(Item16);
 	hipError_t e = pool_alloc(dev, (void **)&A, keys * sizeof(Item16));
 	if (e == hipSuccess && c2) e = pool_alloc(dev, (void **)&Bb, keys * sizeof(Item16));
-	if (e == hipSuccess) e = pool_alloc(dev, (void **)&pk, npos_cap * 8);
-	if (e == hipSuccess) e = pool_alloc(dev, (void **)&ix, npos_cap * 4);
+	if (alias) {
+		pk = (unsigned long long *)A;
+		ix = (uint32_t *)((uint8_t *)A + ((npos_cap * 8 + 255) & ~255ull));
+	} else {
+		if (e == hipSuccess) e = pool_alloc(dev, (void **)&pk, npos_cap * 8);
+		if (e == hipSuccess) e = pool_alloc(dev, (void **)&ix, npos_cap * 4);
+	}
 	if (e == hipSuccess) e = pool_alloc(dev, (void **)&planes, 8 * plane_words * 8);
 	if (e == hipSuccess) e = pool_alloc(dev, (void **)&d_side, keys);
 	if (e == hipSuccess) e = pool_alloc(dev, (void **)&d_lost, T.cap + 4);
@@ -1992,7 +2025,7 @@ static int bloom_xor(rg_handle *h, Table &T, uint64_t m_bits, uint64_t keys, boo
 		hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(64), 0, h->stream, d_sums, nblk, d_sums + nblk);
 		hipLaunchKernelGGL(k_scan_add, dim3(nblk), dim3(256), 0, h->stream, d_begin, n, d_sums, d_sums + nblk, d_hist);
 	};
-	XTRY(hipMemsetAsync(pk, 0xFF, npos_cap * 8, h->stream));
+	if (!alias) XTRY(hipMemsetAsync(pk, 0xFF, npos_cap * 8, h->stream));
 	XTRY(hipMemsetAsync(d_lost, 0, T.cap + 4, h->stream));
 	XTRY(hipMemsetAsync(d_hist, 0, 256 * sizeof(unsigned long long), h->stream));
 	// level 1: histogram of the top c1 bits, items produced straight into their ranges
@@ -2046,6 +2079,7 @@ static int bloom_xor(rg_handle *h, Table &T, uint64_t m_bits, uint64_t keys, boo
 			XTRY(hipGetLastError());
 		}
 		if (final_level) hipLaunchKernelGGL(k_round64, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, h->stream, d_hist, nout);
+		if (final_level && alias) XTRY(hipMemsetAsync(pk, 0xFF, npos_cap * 8, h->stream));  // A has been read by the middle level
 		scan(nout);
 		XTRY(hipGetLastError());
 		{
@@ -2512,7 +2546,7 @@ int rg_count_local(rg_handle *h) {
 			if (rc) return rc;
 			if (ok) {
 				h->stats.sweep_partitioned = 1;
-				if (single && h->log_all_unique && n_log && n_log < (1ull << 31)) {
+				if (single && h->log_all_unique && n_log && n_log < (1ull << 32)) {
 					// admission first, insertion afterwards (rg_resolve_admission): only stored vertices reach the table
 					h->pending_log = log;
 					h->pending_n = n_log;
@@ -2722,7 +2756,7 @@ int rg_merge_entries(rg_handle *h, const void *d_entries, uint64_t n_entries) {
 	// k-mers like the one a single rank makes for itself (the entries carry the unique mark).  If the whole partition
 	// arrives in one call, it is kept as that log: admission runs on it and only admitted vertices reach the table
 	// (rg_resolve_admission).  A further call, or entries without the mark, take the classic merge.
-	if (!h->tab.slots && !h->pending_log && !h->merge_started && n_entries < (1ull << 31) && !(h->cfg.reserved0 & 0x80000)) {
+	if (!h->tab.slots && !h->pending_log && !h->merge_started && n_entries < (1ull << 32) && !(h->cfg.reserved0 & 0x80000)) {
 		h->merge_started = true;
 		Slot *copy = nullptr;
 		Slot first;  // entries of the entry route carry no mark: one look spares them the copy

@@ -36,8 +36,8 @@ static constexpr unsigned long long XOR_PAD = ~0ull;  // padding entry of the pa
 static constexpr int XOR_SPER = 3;               // items per stream a thread of k_xor_region keeps in registers (8 streams)
 
 struct Item16 {
-	unsigned long long a;  // o << 31 | slot index
-	unsigned long long b;  // arrival stamp of the key
+	unsigned long long a;  // o << 31 | low 31 bits of the slot index
+	unsigned long long b;  // arrival stamp of the key (49 bits) | bit 31 of the slot index << 63: key arrays of up to 2^32 slots
 };
 
 template <int W>
@@ -115,8 +115,8 @@ __global__ __launch_bounds__(XOR_THREADS) void k_xor_keys(const Slot *__restrict
 			const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(&tab[i].k0);
 			if (a.x != EMPTY) {
 				const uint64_t o = xor_origin<W>(a.x, a.y, m_mask);
-				mine[q].a = (o << 31) | i;
-				mine[q].b = tab[i].stamp;
+				mine[q].a = (o << 31) | (i & 0x7FFFFFFFull);
+				mine[q].b = tab[i].stamp | ((i >> 31) << 63);
 				const uint32_t d = (uint32_t)(o >> shift) & dmask;
 				dr[q] = (d << 16) | atomicAdd(&s_cnt[d], 1u);
 			}
@@ -196,8 +196,8 @@ __global__ __launch_bounds__(XOR_THREADS) void k_scatter16(const Item16 *__restr
 		const Item16 it = s_item[i];
 		const unsigned long long dst = s_gbase[d] + (i - s_off[d]);
 		if (FINAL) {
-			pk[dst] = (it.b << 14) | ((it.a >> 31) & low_mask);
-			ix[dst] = (uint32_t)(it.a & 0x7FFFFFFFull);
+			pk[dst] = ((it.b & ~(1ull << 63)) << 14) | ((it.a >> 31) & low_mask);
+			ix[dst] = (uint32_t)(it.a & 0x7FFFFFFFull) | ((uint32_t)(it.b >> 63) << 31);
 		} else {
 			*reinterpret_cast<ulonglong2 *>(&out[dst]) = make_ulonglong2(it.a, it.b);
 			if (side) side[dst] = (uint8_t)((uint32_t)(it.a >> (31 + next_shift)) & next_mask);
