@@ -45,7 +45,7 @@ def parse():
                          "a third of the bytes on the one link there is), records otherwise (less work per rank, and fewer bytes "
                          "once a rank's own reads hold most k-mers only a few times)")
     ap.add_argument("--parts", type=int, default=4, help="records route: slices of the reads whose record transfers overlap the next slice's kernels")
-    ap.add_argument("--sweep", type=lambda x: int(x, 0), default=0, help="rg_config.reserved0 (development: forces a sweep / bucket bits)")
+    ap.add_argument("--sweep", type=lambda x: int(x, 0), default=0, help="rg_debug_set flags (development: forces a sweep / bucket bits)")
     ap.add_argument("--breakdown", action="store_true", help="print per-call wall times of the last step to stderr")
     return ap.parse_args()
 

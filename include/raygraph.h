@@ -42,7 +42,7 @@ typedef struct rg_config {
 	int32_t rank;           /* MPI rank == GPU owner index */
 	int32_t size;           /* number of ranks */
 	int32_t device;         /* HIP device ordinal */
-	int32_t reserved0;      /* sweep selection, bits 0-7: 0 = automatic, 1 = force the partitioned sweep, 2 = force the direct sweep; bits 8-15: log2 of the bucket count of the partitioned sweep (0 = automatic); bit 4 / bit 5: force the partitioned / the dense Bloom resolution; bit 6: start with a one-chunk log (tests of the overflow path); bit 16: cut super-k-mer records with the wavefront-per-read kernel even where the lane-per-read one applies; bit 17: produce the Bloom items straight into their first partition level even from a sparse key array; bit 18: size the log from a sample of the buckets even on small inputs (tests); bit 19: rg_merge_entries never keeps received entries as a log (tests); bit 20: the partition levels' histograms read the records instead of the digit bytes the previous level left (tests); bit 21: aggregate with a workgroup per bucket of a two-level partition (k_aggregate_wg) instead of a wavefront per bucket of a three-level one (tests); bit 22 / bit 23: always / never build the vertex table range by range from partitioned entries (tests); bit 24: resolve a power-of-two Bloom filter by key partitions whatever its fill (tests) */
+	int32_t reserved0;      /* must be 0 */
 	uint64_t bloom_bits;    /* RG_BLOOM_DEFAULT, 0 = Bloom filter off, else -bloom-filter-bits */
 	uint64_t table_slots;   /* initial open-addressing capacity hint (like -hash-table-buckets); 0 = auto */
 	uint64_t first_read_id; /* global id of this rank's first read (SequencesLoader.cpp:287-297) */
@@ -198,8 +198,19 @@ int rg_pack_reads_noalloc(rg_handle *h, const char *d_text, uint64_t text_bytes,
  * k-mer position whose coverage reaches the read's threshold, the reverse marker = length-k-(last such
  * position); -1 = none (the reference then leaves the Read's offsets at 0 and attaches nothing).
  * Replaces one RAY_MPI_TAG_REQUEST_VERTEX_COVERAGE round trip per k-mer (:76-96).  Device pointers,
- * one int32 per read; size == 1 only in this version. */
+ * one int32 per read.  rg_read_markers: size == 1, one call.  size > 1 (works for size == 1 too), with one key exchange,
+ * like the purge:
+ *   rg_markers_query_counts    counts[r] = k-mers of this rank's reads whose owner is rank r (vertexRank, Kmer.cpp:165-170)
+ *   rg_markers_export_queries  the canonical keys grouped by owner in rank order, kmer_words*8 bytes each (opaque)
+ *   -- all-to-all(v) of the keys; every rank answers what it received: --
+ *   rg_markers_answer          coverage[i] = coverage of key i here, 0 if it is not stored (MessageProcessor.cpp:1224-1256)
+ *   -- all-to-all(v) of the answers (4 bytes each) back, same order as the exported keys --
+ *   rg_markers_apply           the marker rule of IndexerWorker.cpp:97-248 on the returned coverages */
 int rg_read_markers(rg_handle *h, int32_t *d_forward, int32_t *d_reverse);
+int rg_markers_query_counts(rg_handle *h, uint64_t *counts);
+int rg_markers_export_queries(rg_handle *h, void *d_queries, uint64_t cap_queries);
+int rg_markers_answer(rg_handle *h, const void *d_queries, uint64_t n, uint32_t *d_coverage);
+int rg_markers_apply(rg_handle *h, const uint32_t *d_coverage, uint64_t n, int32_t *d_forward, int32_t *d_reverse);
 /* On-disk formats.  records = rg_export output (Vertex::dump layout).
  * rg_write_genome_graph: Rank<r>.Checkpoint.GenomeGraph.ray (MessageProcessor.cpp:658-678, read back by
  * :596-655; record = Vertex::write, Vertex.cpp:257-273), vertices in the order of `records`.
@@ -245,6 +256,11 @@ int rg_get_stats(rg_handle *h, rg_stats *out);
  * __Malloc bookkeeping plays the same role on the host, KmerAcademyBuilder/BloomFilter.cpp:96).
  * This call gives every cached block back. */
 int rg_release_cached_memory(void);
+
+/* ---- test and experiment switches -------------------------------------------------------------- */
+/* Forces internal routes that the library otherwise chooses by itself; results never depend on them.  No counterpart
+ * in the reference; a plugin leaves it alone.  Must be called before the counting starts.  flags: bits 0-7: 0 = automatic, 1 = force the partitioned sweep, 2 = force the direct sweep; bits 8-15: log2 of the bucket count of the partitioned sweep (0 = automatic); bit 4 / bit 5: force the partitioned / the dense Bloom resolution; bit 6: start with a one-chunk log (tests of the overflow path); bit 16: cut super-k-mer records with the wavefront-per-read kernel even where the lane-per-read one applies; bit 17: produce the Bloom items straight into their first partition level even from a sparse key array; bit 18: size the log from a sample of the buckets even on small inputs (tests); bit 19: rg_merge_entries never keeps received entries as a log (tests); bit 20: the partition levels' histograms read the records instead of the digit bytes the previous level left (tests); bit 21: aggregate with a workgroup per bucket of a two-level partition (k_aggregate_wg) instead of a wavefront per bucket of a three-level one (tests); bit 22 / bit 23: always / never build the vertex table range by range from partitioned entries (tests); bit 24: resolve a power-of-two Bloom filter by key partitions whatever its fill (tests) */
+int rg_debug_set(rg_handle *h, uint32_t flags);
 
 /* ---- profiling (the reference's MACRO_COLLECT_PROFILING_INFORMATION probes,
  * KmerAcademyBuilder.cpp:50,73,116,...) ------------------------------------------------------- */

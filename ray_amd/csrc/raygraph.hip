@@ -652,6 +652,172 @@ __global__ __launch_bounds__(256) void k_read_markers(const uint64_t *__restrict
 	}
 }
 
+// ---- markers across ranks: the coverage requests of IndexerWorker.cpp:76-96 in bulk ---------------------
+// WRITE == false: counts[owner] += k-mers of the local reads that owner must answer for; WRITE == true: canonical keys
+// (internal form) written at cursors[owner]++, origin = (read index in the handle << 16) | position
+template <int W, bool WRITE>
+__global__ __launch_bounds__(256) void k_marker_queries(const uint64_t *__restrict__ P, const uint64_t *__restrict__ offsets,
+                                                        const uint32_t *__restrict__ lengths, uint64_t nreads, uint64_t read0, int k, uint32_t size,
+                                                        unsigned long long *__restrict__ counts_or_cursors, uint64_t *__restrict__ keys,
+                                                        uint64_t *__restrict__ origin) {
+	extern __shared__ unsigned long long s_dyn[];  // [size] global bases (WRITE), then [size] u32 counts
+	unsigned long long *s_base = s_dyn;
+	uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_dyn + size);
+	__shared__ uint32_t s_nmax;
+	for (uint32_t j = threadIdx.x; j < size; j += 256) s_cnt[j] = 0;
+	if (threadIdx.x == 0) s_nmax = 0;
+	__syncthreads();
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	const uint64_t mask0 = (2 * k >= 64) ? ~0ull : ((1ull << (2 * k)) - 1);
+	const uint64_t mask1 = (k > 32) ? ((1ull << (2 * k - 64)) - 1) : 0ull;
+	// four reads per step, one per wavefront; in WRITE mode every 256 k-mers reserve their places with one global atomic
+	// per owner (the ranks inside come from LDS), so the loops are uniform over the workgroup
+	for (uint64_t r0 = (uint64_t)blockIdx.x * 4; r0 < nreads; r0 += (uint64_t)gridDim.x * 4) {
+		const uint64_t r = r0 + wave;
+		const uint32_t L = (r < nreads) ? lengths[r] : 0u;
+		const uint32_t n = (L >= (uint32_t)k) ? L - (uint32_t)k + 1 : 0;
+		const uint64_t bit0 = (r < nreads) ? offsets[r] * 8 : 0;
+		if (WRITE) {
+			if (lane == 0 && n) atomicMax(&s_nmax, n);
+			__syncthreads();
+		}
+		const uint32_t nmax = WRITE ? s_nmax : n;
+		for (uint32_t p0 = 0; p0 < nmax; p0 += 64) {
+			const uint32_t p = p0 + lane;
+			uint64_t i0 = 0, i1 = 0;
+			uint32_t owner = 0, rank = 0;
+			const bool have = p < n;
+			if (have) {
+				uint64_t f0 = ext64(P, bit0 + 2ull * p) & mask0, f1 = 0;
+				if (W == 2 && k > 32) f1 = ext64(P, bit0 + 2ull * p + 64) & mask1;
+				bool rc;
+				canonical_internal<W>(f0, f1, k, i0, i1, rc);
+				uint64_t K0, K1;
+				from_internal<W>(i0, i1, K0, K1);
+				owner = (uint32_t)(hash1<W>(K0, K1) % (uint64_t)size);
+				rank = atomicAdd(&s_cnt[owner], 1u);
+			}
+			if (WRITE) {
+				__syncthreads();
+				for (uint32_t j = threadIdx.x; j < size; j += 256) {
+					const uint32_t c = s_cnt[j];
+					if (c) s_base[j] = atomicAdd(&counts_or_cursors[j], (unsigned long long)c);
+				}
+				__syncthreads();
+				if (have) {
+					const unsigned long long pos = s_base[owner] + rank;
+					keys[pos * W] = i0;
+					if (W == 2) keys[pos * W + 1] = i1;
+					origin[pos] = ((read0 + r) << 16) | p;
+				}
+				__syncthreads();
+				for (uint32_t j = threadIdx.x; j < size; j += 256) s_cnt[j] = 0;
+				if (threadIdx.x == 0) s_nmax = 0;
+				__syncthreads();
+			}
+		}
+		if (WRITE && nmax == 0) {  // s_nmax was read by everybody before anybody can raise it for the next step
+			__syncthreads();
+		}
+	}
+	if (!WRITE) {
+		__syncthreads();
+		for (uint32_t j = threadIdx.x; j < size; j += 256)
+			if (s_cnt[j]) atomicAdd(&counts_or_cursors[j], (unsigned long long)s_cnt[j]);
+	}
+}
+
+// the owner's answer: the coverage, 0 for a k-mer that is not stored (MessageProcessor.cpp:1224-1256)
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_marker_answer(const Slot *__restrict__ tab, uint64_t cap, const uint64_t *__restrict__ keys, uint64_t n,
+                                                         uint32_t *__restrict__ coverage) {
+	uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	for (; q < n; q += stride) {
+		const Slot *p = lookup<W>(tab, cap, keys[q * W], W == 2 ? keys[q * W + 1] : 0);
+		coverage[q] = p ? (uint32_t)(p->meta & COUNT_MASK) : 0u;
+	}
+}
+
+// answers back in the order the keys were exported -> coverage of (read, position): cov2d[read * maxn + position]
+__global__ __launch_bounds__(BLOCK) void k_marker_place(const uint64_t *__restrict__ origin, const uint32_t *__restrict__ answers, uint64_t n,
+                                                        uint32_t *__restrict__ cov2d, uint64_t maxn) {
+	uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	for (; q < n; q += stride) {
+		const uint64_t o = origin[q];
+		cov2d[(o >> 16) * maxn + (o & 0xFFFFu)] = answers[q];
+	}
+}
+
+// k_read_markers with the coverages given (one wavefront per read; see there for the rule)
+__global__ __launch_bounds__(256) void k_markers_from_coverage(const uint32_t *__restrict__ lengths, uint64_t nreads, uint64_t read0, int k,
+                                                               const uint32_t *__restrict__ cov2d, uint64_t maxn, int32_t *__restrict__ forward,
+                                                               int32_t *__restrict__ reverse) {
+	__shared__ uint32_t s_le[4][10], s_ge[4][10], s_first[4][10], s_last[4][10];
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+	for (uint64_t r = (uint64_t)blockIdx.x * 4 + wave; r < nreads; r += nwaves) {
+		const uint32_t L = lengths[r];
+		const uint32_t n = (L >= (uint32_t)k) ? L - (uint32_t)k + 1 : 0;
+		if (lane < 10) {
+			s_le[wave][lane] = 0;
+			s_ge[wave][lane] = 0;
+			s_first[wave][lane] = 0xFFFFFFFFu;
+			s_last[wave][lane] = 0;
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		uint32_t le[10], ge[10], first[10], last1[10];
+#pragma unroll
+		for (int v = 0; v < 10; ++v) {
+			le[v] = 0;
+			ge[v] = 0;
+			first[v] = 0xFFFFFFFFu;
+			last1[v] = 0;
+		}
+		for (uint32_t p = lane; p < n; p += 64) {
+			const int cov = (int)cov2d[(read0 + r) * maxn + p];  // the reference compares the coverage as an int (IndexerWorker.cpp:92)
+#pragma unroll
+			for (int v = 0; v < 10; ++v) {
+				if (cov <= v + 1) le[v]++;
+				if (cov >= 2 * (v + 1)) {
+					ge[v]++;
+					if (first[v] == 0xFFFFFFFFu) first[v] = p;
+					last1[v] = p + 1;
+				}
+			}
+		}
+#pragma unroll
+		for (int v = 0; v < 10; ++v) {
+			if (le[v]) atomicAdd(&s_le[wave][v], le[v]);
+			if (ge[v]) {
+				atomicAdd(&s_ge[wave][v], ge[v]);
+				atomicMin(&s_first[wave][v], first[v]);
+				atomicMax(&s_last[wave][v], last1[v]);
+			}
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		if (lane == 0) {
+			int bestEntry = -1;
+			uint32_t bestScore = 0;
+			for (int value = 10; value >= 1; --value) {
+				const uint32_t score = s_le[wave][value - 1] + s_ge[wave][value - 1];
+				if (bestEntry == -1 || score > bestScore) {
+					bestEntry = value;
+					bestScore = score;
+				}
+			}
+			const uint32_t fp = s_first[wave][bestEntry - 1], lp1 = s_last[wave][bestEntry - 1];
+			forward[r] = (fp == 0xFFFFFFFFu) ? -1 : (int32_t)fp;
+			reverse[r] = (lp1 == 0) ? -1 : (int32_t)(L - (uint32_t)k - (lp1 - 1));
+		}
+		__builtin_amdgcn_wave_barrier();
+	}
+}
+
 // Vertex::load for a whole checkpoint (Vertex.cpp:422-436, MessageProcessor.cpp:596-655): records in Vertex::dump
 // layout go straight into the table with their coverage and edge byte
 template <int W>
@@ -1059,6 +1225,7 @@ struct rg_handle {
 	std::vector<uint64_t> owner_counts;
 	bool owner_counts_valid = false;           // set by rg_owner_counts, cleared by whatever changes the entries it counted
 	Phase phase = PH_CREATED;
+	uint32_t dbg = 0;  // rg_debug_set: internal routes forced by tests and experiments (0 = automatic)
 	rg_stats stats{};
 	std::string err;
 	// optional per-kernel timing with HIP events on the launch stream (rg_set_profiling)
@@ -1073,6 +1240,9 @@ struct rg_handle {
 	void *rec_buf = nullptr;             // rg_records_local .. rg_export_records: super-k-mer records of the local reads
 	uint64_t rec_slots = 0;              // slots of rec_buf in use (holes included)
 	std::vector<uint64_t> rec_counts;    // valid records per destination rank
+	uint64_t *d_marker_origin = nullptr;  // rg_markers_export_queries .. rg_markers_apply: (read << 16 | position) per query
+	uint64_t marker_total = 0;
+	std::vector<uint64_t> marker_counts;
 	uint64_t *d_purge_origin = nullptr;  // rg_purge_export_queries .. rg_purge_apply: (slot << 3 | edge bit) per query
 	uint64_t purge_total = 0;
 	std::vector<uint64_t> purge_counts;
@@ -1193,7 +1363,7 @@ static int table_reserve(rg_handle *h, Table &t, uint64_t need, int fill_counter
 // received from all ranks) instead of from this handle's reads.
 
 // reads -> records: k_superkmers_lanes (a lane per read) for short reads and windows that fit its LDS block,
-// k_superkmers (a wavefront per read) otherwise; cfg.reserved0 bit 16 forces the latter (tests)
+// k_superkmers (a wavefront per read) otherwise; rg_debug_set bit 16 forces the latter (tests)
 static constexpr int SKL_HOST_MAX_W = 24;        // 4 wavefronts x w x 64 lanes x 8 B <= 48 KiB of dynamic LDS
 static constexpr uint32_t SKL_MAX_READ = 1024;   // longer reads: lanes of one wavefront would idle behind the longest
 template <int W>
@@ -1207,7 +1377,7 @@ struct SuperkmerLaunch {
 		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_superkmers<W>, 256, 0) != hipSuccess || occ < 1) occ = 4;
 		grid_wave = (int)std::min<uint64_t>((uint64_t)n_cu * occ, std::max<uint64_t>(1, (total_reads + 255) / 256));
 		grid_lane = 0;
-		if (w <= SKL_HOST_MAX_W && w <= SKL_MAX_W && !(h->cfg.reserved0 & 0x10000)) {
+		if (w <= SKL_HOST_MAX_W && w <= SKL_MAX_W && !(h->dbg & 0x10000)) {
 			lds_lane = (size_t)4 * w * 64 * sizeof(unsigned long long);
 			int occl = 0;
 			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occl, k_superkmers_lanes<W>, 256, lds_lane) == hipSuccess && occl >= 1)
@@ -1228,7 +1398,7 @@ struct SuperkmerLaunch {
 	}
 };
 
-// the aggregation kernel of the sweep: a wavefront per bucket of a three-level partition (k_aggregate), or -- cfg.reserved0
+// the aggregation kernel of the sweep: a wavefront per bucket of a three-level partition (k_aggregate), or -- rg_debug_set flags
 // bit 21 -- a workgroup per bucket of a two-level one (k_aggregate_wg)
 template <int W>
 struct AggLaunch {
@@ -1305,8 +1475,8 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	// a bucket's distinct k-mers fit the LDS table of k_aggregate; buckets of more diverse inputs are split further
 	// by k_aggregate<SLOW> itself
 	AggLaunch<W> agg;
-	agg.plan((h->cfg.reserved0 & 0x200000) != 0);  // bit 21: a workgroup per bucket of a coarser partition (slower as it stands: DESIGN.md)
-	int bits = (h->cfg.reserved0 >> 8) & 0xFF;
+	agg.plan((h->dbg & 0x200000) != 0);  // bit 21: a workgroup per bucket of a coarser partition (slower as it stands: DESIGN.md)
+	int bits = (h->dbg >> 8) & 0xFF;
 	if (bits == 0) {
 		bits = agg.wg ? 12 : 8;
 		while (bits < MAX_BUCKET_BITS && (occ_bound >> bits) > agg.occ_per_bucket()) bits++;
@@ -1450,7 +1620,7 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 		PTRY(hipGetLastError());
 		{
 			ProfScope ps(h, "k_scatter");
-			uint8_t *side_out = (have_next && !(h->cfg.reserved0 & 0x100000)) ? d_side : nullptr;  // bit 20: histograms read the records (tests)
+			uint8_t *side_out = (have_next && !(h->dbg & 0x100000)) ? d_side : nullptr;  // bit 20: histograms read the records (tests)
 			const int ndb = have_next ? dbits[level + 1] : 0;
 			hipLaunchKernelGGL(k_scatter<W>, dim3((unsigned)ntiles), dim3(SCATTER_THREADS), 0, h->stream, level_in, m, S, d_seg, d_tile, shift, db, d_hist,
 			                   buf[cur ^ 1], 0u, side_out, shift - ndb, (1u << ndb) - 1u);
@@ -1476,7 +1646,7 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	const unsigned agg_grid = agg.grid_for_buckets(NBUCK, n_cu);
 	const uint64_t log_slack = agg.slack(agg_grid);
 	uint64_t log_cap = std::min<uint64_t>(occ_bound, std::max<uint64_t>(occ_bound / 4, 1ull << 20)) + log_slack;
-	if (h->cfg.reserved0 & 64) log_cap = LOG_CHUNK;  // tests: the first attempt overflows
+	if (h->dbg & 64) log_cap = LOG_CHUNK;  // tests: the first attempt overflows
 	uint32_t *d_retry = nullptr;
 	if (pool_alloc(dev, (void **)&d_retry, NBUCK * sizeof(uint32_t)) != hipSuccess) {
 		(void)hipGetLastError();
@@ -1486,8 +1656,8 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	// entries may be marked unique unless other ranks aggregate the same keys (entry route, size > 1)
 	const uint32_t flag_unique = (h->cfg.size == 1 || ext) ? 1u : 0u;
 	for (int attempt = 0;; ++attempt) {
-		const bool force_probe = (h->cfg.reserved0 & 0x40000) != 0;
-		const bool will_probe = attempt == 0 && !(h->cfg.reserved0 & 64) && (NBUCK >= (1u << 16) || force_probe);
+		const bool force_probe = (h->dbg & 0x40000) != 0;
+		const bool will_probe = attempt == 0 && !(h->dbg & 64) && (NBUCK >= (1u << 16) || force_probe);
 		const uint32_t P = force_probe ? std::max<uint32_t>((uint32_t)NBUCK / 4, 1u) : (uint32_t)NBUCK / 256;
 		// the sample runs on a small log of its own (one entry per occurrence of its share would always do; 1.5 x the average
 		// share + the chunks left open is what it gets), the real log is allocated once its size is known
@@ -1502,7 +1672,7 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 		// Before the first attempt a sample of the buckets (the bucket number is a hash: any range is a fair sample) is
 		// aggregated alone, overflowing buckets included, and the log sized from what it produced: an input of little
 		// redundancy (errors in most reads) then gets its larger log at once instead of losing a whole aggregation to
-		// find out.  Costs 1/256 of the aggregation; bit 18 of reserved0 runs it on small inputs too and always resizes (tests).
+		// find out.  Costs 1/256 of the aggregation; bit 18 of rg_debug_set runs it on small inputs too and always resizes (tests).
 		bool mostly_overflowing = false;  // the sample says that most buckets hold more k-mers than the LDS table: split them all from the start
 		if (will_probe) {
 			bool fine = hipMemsetAsync(h->d_counters + PC_LOG_CURSOR, 0, 6 * sizeof(unsigned long long), h->stream) == hipSuccess;
@@ -1585,7 +1755,7 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 			return RG_OK;
 		}
 		// twice the size, then one slot per occurrence (releasing and mapping tens of GiB is what makes this slow: no more than needed)
-		const uint64_t doubled = (h->cfg.reserved0 & 64) ? 0 : 2 * (log_cap - log_slack);
+		const uint64_t doubled = (h->dbg & 64) ? 0 : 2 * (log_cap - log_slack);
 		log_cap = ((attempt == 0 && doubled) ? std::min<uint64_t>(occ_bound, doubled) : occ_bound) + log_slack;
 	}
 	pool_free(dev, d_retry);
@@ -1752,7 +1922,7 @@ static int bloom_partitioned(rg_handle *h, Table &T, uint64_t m_bits, uint64_t k
 	const uint64_t m_inv = (m_bits & (m_bits - 1)) ? (uint64_t)((((unsigned __int128)1) << 64) / m_bits) : 0;  // bloom_mod
 	// dense key array (the sweep's log: every chunk full) -> items made straight into their first-level ranges; sparse
 	// (a vertex table at load <= 0.7) -> items streamed out densely first, then one more partition level
-	const bool fused = (h->cfg.reserved0 & 0x20000) || keys * 5 >= T.cap * 4;  // bit 17 forces it (tests)
+	const bool fused = (h->dbg & 0x20000) || keys * 5 >= T.cap * 4;  // bit 17 forces it (tests)
 	const uint64_t item_cap = fused ? 8 * keys : 8 * (keys + (uint64_t)grid_items * 4 * ITEM_CHUNK_KEYS);
 	unsigned long long *A = nullptr, *B = nullptr, *d_seg = nullptr, *d_hist = nullptr, *d_begin = nullptr, *d_sums = nullptr;
 	uint32_t *d_tile = nullptr, *d_lost = nullptr;
@@ -1809,8 +1979,8 @@ static int bloom_partitioned(rg_handle *h, Table &T, uint64_t m_bits, uint64_t k
 		{
 			ProfScope ps(h, "k_bloom_scatter_items");
 			const unsigned grid = (unsigned)((T.cap + ITEM_TILE_SLOTS - 1) / ITEM_TILE_SLOTS);
-			// the second level's digits, one byte per item, for its histogram (reserved0 bit 20: it reads the items)
-			if (nlevels > 1 && !(h->cfg.reserved0 & 0x100000) && pool_alloc(dev, (void **)&d_side, 8 * keys) != hipSuccess) {
+			// the second level's digits, one byte per item, for its histogram (rg_debug_set bit 20: it reads the items)
+			if (nlevels > 1 && !(h->dbg & 0x100000) && pool_alloc(dev, (void **)&d_side, 8 * keys) != hipSuccess) {
 				(void)hipGetLastError();
 				d_side = nullptr;
 			}
@@ -2404,6 +2574,7 @@ int rg_create(const rg_config *cfg, rg_handle **out) {
 	if (cfg->k < 1 || (cfg->k % 2) == 0 || cfg->k > 32 * W - 1)
 		return fail(nullptr, RG_ERR_ARG, "k=%d must be odd and within 1..%d for %d-word k-mers", cfg->k, 32 * W - 1, W);
 	if (cfg->size < 1 || cfg->rank < 0 || cfg->rank >= cfg->size) return fail(nullptr, RG_ERR_ARG, "bad rank/size %d/%d", cfg->rank, cfg->size);
+	if (cfg->reserved0 != 0) return fail(nullptr, RG_ERR_ARG, "rg_config.reserved0 must be 0");
 	int ndev = 0;
 	hipError_t e = hipGetDeviceCount(&ndev);
 	if (e != hipSuccess || ndev <= 0) return fail(nullptr, RG_ERR_HIP, "no HIP device available (%s); this library has no CPU path", hipGetErrorString(e));
@@ -2457,6 +2628,7 @@ int rg_destroy(rg_handle *h) {
 	if (h->h_counters) (void)hipHostFree(h->h_counters);
 	if (h->d_owner) pool_free(h->cfg.device, h->d_owner);
 	if (h->d_purge_origin) pool_free(h->cfg.device, h->d_purge_origin);
+	if (h->d_marker_origin) pool_free(h->cfg.device, h->d_marker_origin);
 	if (h->rec_buf) pool_free(h->cfg.device, h->rec_buf);
 	if (h->pending_log) pool_free(h->cfg.device, h->pending_log);
 	if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -2532,12 +2704,12 @@ int rg_count_local(rg_handle *h) {
 	const int fill_counter = single ? C_FILL : C_FILL_LOCAL;
 	const int k = h->cfg.k;
 	// choose the sweep: partitioned (super-k-mers + LDS aggregation) for real inputs, direct for small
-	// ones; cfg.reserved0 bit 0 forces the partitioned sweep, bit 1 the direct one (tests)
+	// ones; rg_debug_set bit 0 forces the partitioned sweep, bit 1 the direct one (tests)
 	{
 		uint64_t occ_bound = 0;
 		for (const ReadBatch &b : h->reads)
 			if (b.maxlen >= (uint32_t)k) occ_bound += b.n * ((uint64_t)b.maxlen - k + 1);
-		const uint32_t flags = (uint32_t)h->cfg.reserved0 & 0xFFu;
+		const uint32_t flags = (uint32_t)h->dbg & 0xFFu;
 		if (!(flags & 2u) && ((flags & 1u) || occ_bound >= (1ull << 24))) {
 			Slot *log = nullptr;
 			uint64_t n_log = 0;
@@ -2662,7 +2834,7 @@ int rg_count_records(rg_handle *h, const void *d_records, uint64_t n_records) {
 	Slot *log = nullptr;
 	uint64_t n_log = 0;
 	bool ok = false;
-	const uint32_t flags = (uint32_t)h->cfg.reserved0 & 0xFFu;
+	const uint32_t flags = (uint32_t)h->dbg & 0xFFu;
 	if (!(flags & 2u)) {
 		int rc = sweep_partitioned(h, &log, &n_log, &ok, d_records ? d_records : (const void *)h /* non-null, never read */, n_records);
 		if (rc) return rc;
@@ -2756,7 +2928,7 @@ int rg_merge_entries(rg_handle *h, const void *d_entries, uint64_t n_entries) {
 	// k-mers like the one a single rank makes for itself (the entries carry the unique mark).  If the whole partition
 	// arrives in one call, it is kept as that log: admission runs on it and only admitted vertices reach the table
 	// (rg_resolve_admission).  A further call, or entries without the mark, take the classic merge.
-	if (!h->tab.slots && !h->pending_log && !h->merge_started && n_entries < (1ull << 32) && !(h->cfg.reserved0 & 0x80000)) {
+	if (!h->tab.slots && !h->pending_log && !h->merge_started && n_entries < (1ull << 32) && !(h->dbg & 0x80000)) {
 		h->merge_started = true;
 		Slot *copy = nullptr;
 		Slot first;  // entries of the entry route carry no mark: one look spares them the copy
@@ -2850,20 +3022,20 @@ int rg_resolve_admission(rg_handle *h, uint64_t local_reads_for_bloom) {
 	bool resolved = false;
 	if (m_bits > 0) {
 		// keys in the table decide the method: region partitioning when the filter stays sparse
-		// (8 touches per key), dense first-touch stamps otherwise.  cfg.reserved0 bit 4 forces the
+		// (8 touches per key), dense first-touch stamps otherwise.  rg_debug_set bit 4 forces the
 		// first, bit 5 the second (tests).
 		int rc0 = sync_counters(h);
 		if (rc0) return rc0;
 		const uint64_t keys = from_log ? h->pending_keys : h->h_counters[C_FILL];
-		const uint32_t flags = (uint32_t)h->cfg.reserved0 & 0xFFu;
+		const uint32_t flags = (uint32_t)h->dbg & 0xFFu;
 		const double lambda = 8.0 * (double)keys / (double)m_bits;
 		// worth it while a region's contested bits (expected: 2^17 * P(two or more touchers)) fit the LDS rank table
 		const double contested = (double)REGION_BITS * (1.0 - std::exp(-lambda) * (1.0 + lambda));
 		const bool regions_fit = contested <= 0.9 * REGION_MULTI_CAP_BIG;
-		// filters of 2^B bits too full for the regions (or cfg.reserved0 bit 24: tests): one item per key, partitioned by the
+		// filters of 2^B bits too full for the regions (or rg_debug_set bit 24: tests): one item per key, partitioned by the
 		// key's origin, eight streams per region (rg_bloomx.h)
 		const bool regions_cheap = contested <= 0.4 * REGION_MULTI_CAP;  // beyond: stamp gathers and several rounds per region (C2 with 0.2 % errors: 125 ms against 45)
-		if (!(flags & 32u) && !(flags & 16u) && ((h->cfg.reserved0 & 0x1000000) || (!regions_cheap && keys >= (1ull << 20)))) {
+		if (!(flags & 32u) && !(flags & 16u) && ((h->dbg & 0x1000000) || (!regions_cheap && keys >= (1ull << 20)))) {
 			rc0 = bloom_xor(h, T, m_bits, keys, &resolved);
 			if (rc0) return rc0;
 			if (resolved) h->stats.bloom_partitioned = 2;
@@ -2910,9 +3082,9 @@ int rg_resolve_admission(rg_handle *h, uint64_t local_reads_for_bloom) {
 	if (from_log) {
 		candidates = h->pending_keys;
 		const uint64_t retained = h->h_counters[C_RETAINED];
-		// the table range by range, without global atomics (cfg.reserved0 bit 22 forces it on small inputs, bit 23 never: tests)
+		// the table range by range, without global atomics (rg_debug_set bit 22 forces it on small inputs, bit 23 never: tests)
 		bool built = false;
-		if (!(h->cfg.reserved0 & 0x800000) && (retained >= (1ull << 20) || (h->cfg.reserved0 & 0x400000)))
+		if (!(h->dbg & 0x800000) && (retained >= (1ull << 20) || (h->dbg & 0x400000)))
 			rc = build_table_ranges(h, h->pending_log, h->pending_n, retained, &built);
 		if (rc == RG_OK && !built) rc = table_reserve(h, h->tab, std::max<uint64_t>(1, retained), C_FILL);
 		if (rc == RG_OK && !built) {
@@ -3345,6 +3517,122 @@ int rg_read_markers(rg_handle *h, int32_t *d_forward, int32_t *d_reverse) {
 	return RG_OK;
 }
 
+int rg_markers_query_counts(rg_handle *h, uint64_t *counts) {
+	if (!h || !counts) return RG_ERR_ARG;
+	if (h->phase < PH_RESOLVED) return fail(h, RG_ERR_STATE, "rg_markers_query_counts needs the k-mer count first");
+	HIP_TRY(h, hipSetDevice(h->cfg.device));
+	const uint32_t size = (uint32_t)h->cfg.size;
+	HIP_TRY(h, hipMemsetAsync(h->d_owner, 0, sizeof(unsigned long long) * 2 * size, h->stream));
+	uint64_t done = 0;
+	for (const ReadBatch &b : h->reads) {
+		if (b.n == 0) continue;
+		ProfScope ps(h, "k_marker_queries");
+		const unsigned grid = (unsigned)std::min<uint64_t>((b.n + 3) / 4, 65536);
+		if (h->W == 1) hipLaunchKernelGGL((k_marker_queries<1, false>), dim3(grid), dim3(256), size * 12, h->stream, b.d_packed, b.d_off, b.d_len, b.n, done, h->cfg.k, size, h->d_owner, (uint64_t *)nullptr, (uint64_t *)nullptr);
+		else hipLaunchKernelGGL((k_marker_queries<2, false>), dim3(grid), dim3(256), size * 12, h->stream, b.d_packed, b.d_off, b.d_len, b.n, done, h->cfg.k, size, h->d_owner, (uint64_t *)nullptr, (uint64_t *)nullptr);
+		HIP_TRY(h, hipGetLastError());
+		done += b.n;
+	}
+	std::vector<unsigned long long> tmp(size);
+	HIP_TRY(h, hipMemcpyAsync(tmp.data(), h->d_owner, sizeof(unsigned long long) * size, hipMemcpyDeviceToHost, h->stream));
+	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	h->marker_counts.assign(tmp.begin(), tmp.end());
+	h->marker_total = 0;
+	for (uint32_t r = 0; r < size; ++r) {
+		counts[r] = tmp[r];
+		h->marker_total += tmp[r];
+	}
+	return RG_OK;
+}
+
+int rg_markers_export_queries(rg_handle *h, void *d_queries, uint64_t cap_queries) {
+	if (!h || !d_queries) return RG_ERR_ARG;
+	if (h->phase < PH_RESOLVED || h->marker_counts.size() != (size_t)h->cfg.size) return fail(h, RG_ERR_STATE, "rg_markers_export_queries needs rg_markers_query_counts first");
+	if (cap_queries < h->marker_total) return fail(h, RG_ERR_CAPACITY, "query buffer holds %llu keys, %llu needed", (unsigned long long)cap_queries, (unsigned long long)h->marker_total);
+	HIP_TRY(h, hipSetDevice(h->cfg.device));
+	const uint32_t size = (uint32_t)h->cfg.size;
+	if (h->d_marker_origin) {
+		pool_free(h->cfg.device, h->d_marker_origin);
+		h->d_marker_origin = nullptr;
+	}
+	if (pool_alloc(h->cfg.device, (void **)&h->d_marker_origin, sizeof(uint64_t) * std::max<uint64_t>(1, h->marker_total)) != hipSuccess) {
+		(void)hipGetLastError();
+		return fail(h, RG_ERR_NOMEM, "rg_markers_export_queries: out of device memory");
+	}
+	std::vector<unsigned long long> cursors(size);
+	unsigned long long run = 0;
+	for (uint32_t r = 0; r < size; ++r) {
+		cursors[r] = run;
+		run += h->marker_counts[r];
+	}
+	HIP_TRY(h, hipMemcpyAsync(h->d_owner + size, cursors.data(), sizeof(unsigned long long) * size, hipMemcpyHostToDevice, h->stream));
+	uint64_t done = 0;
+	for (const ReadBatch &b : h->reads) {
+		if (b.n == 0) continue;
+		ProfScope ps(h, "k_marker_queries");
+		const unsigned grid = (unsigned)std::min<uint64_t>((b.n + 3) / 4, 65536);
+		if (h->W == 1) hipLaunchKernelGGL((k_marker_queries<1, true>), dim3(grid), dim3(256), size * 12, h->stream, b.d_packed, b.d_off, b.d_len, b.n, done, h->cfg.k, size, h->d_owner + size, (uint64_t *)d_queries, h->d_marker_origin);
+		else hipLaunchKernelGGL((k_marker_queries<2, true>), dim3(grid), dim3(256), size * 12, h->stream, b.d_packed, b.d_off, b.d_len, b.n, done, h->cfg.k, size, h->d_owner + size, (uint64_t *)d_queries, h->d_marker_origin);
+		HIP_TRY(h, hipGetLastError());
+		done += b.n;
+	}
+	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	return RG_OK;
+}
+
+int rg_markers_answer(rg_handle *h, const void *d_queries, uint64_t n, uint32_t *d_coverage) {
+	if (!h || (n && (!d_queries || !d_coverage))) return RG_ERR_ARG;
+	if (h->phase < PH_RESOLVED) return fail(h, RG_ERR_STATE, "rg_markers_answer needs the k-mer count first");
+	if (n == 0) return RG_OK;
+	HIP_TRY(h, hipSetDevice(h->cfg.device));
+	{
+		ProfScope ps(h, "k_marker_answer");
+		if (h->W == 1) hipLaunchKernelGGL(k_marker_answer<1>, dim3(grid_for(n)), dim3(BLOCK), 0, h->stream, h->tab.slots, h->tab.cap, (const uint64_t *)d_queries, n, d_coverage);
+		else hipLaunchKernelGGL(k_marker_answer<2>, dim3(grid_for(n)), dim3(BLOCK), 0, h->stream, h->tab.slots, h->tab.cap, (const uint64_t *)d_queries, n, d_coverage);
+	}
+	HIP_TRY(h, hipGetLastError());
+	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	return RG_OK;
+}
+
+int rg_markers_apply(rg_handle *h, const uint32_t *d_coverage, uint64_t n, int32_t *d_forward, int32_t *d_reverse) {
+	if (!h || (n && !d_coverage) || ((!d_forward || !d_reverse) && h->n_reads)) return RG_ERR_ARG;
+	if (!h->d_marker_origin) return fail(h, RG_ERR_STATE, "rg_markers_apply needs rg_markers_export_queries first");
+	if (n != h->marker_total) return fail(h, RG_ERR_ARG, "rg_markers_apply: %llu answers for %llu queries", (unsigned long long)n, (unsigned long long)h->marker_total);
+	const int dev = h->cfg.device;
+	HIP_TRY(h, hipSetDevice(dev));
+	uint64_t maxn = 1;
+	for (const ReadBatch &b : h->reads)
+		if (b.maxlen >= (uint32_t)h->cfg.k) maxn = std::max<uint64_t>(maxn, (uint64_t)b.maxlen - h->cfg.k + 1);
+	uint32_t *cov2d = nullptr;
+	if (pool_alloc(dev, (void **)&cov2d, std::max<uint64_t>(1, h->n_reads) * maxn * sizeof(uint32_t)) != hipSuccess) {
+		(void)hipGetLastError();
+		return fail(h, RG_ERR_NOMEM, "rg_markers_apply: out of device memory");
+	}
+	hipError_t e = hipSuccess;
+	if (n) {
+		ProfScope ps(h, "k_marker_place");
+		hipLaunchKernelGGL(k_marker_place, dim3(grid_for(n)), dim3(BLOCK), 0, h->stream, h->d_marker_origin, d_coverage, n, cov2d, maxn);
+		e = hipGetLastError();
+	}
+	uint64_t done = 0;
+	for (const ReadBatch &b : h->reads) {
+		if (b.n == 0 || e != hipSuccess) continue;
+		ProfScope ps(h, "k_markers_from_coverage");
+		const unsigned grid = (unsigned)std::min<uint64_t>((b.n + 3) / 4, 65536);
+		hipLaunchKernelGGL(k_markers_from_coverage, dim3(grid), dim3(256), 0, h->stream, b.d_len, b.n, done, h->cfg.k, cov2d, maxn, d_forward + done, d_reverse + done);
+		e = hipGetLastError();
+		done += b.n;
+	}
+	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+	pool_free(dev, cov2d);
+	pool_free(dev, h->d_marker_origin);
+	h->d_marker_origin = nullptr;
+	h->marker_counts.clear();
+	if (e != hipSuccess) return fail(h, RG_ERR_HIP, "rg_markers_apply: %s", hipGetErrorString(e));
+	return RG_OK;
+}
+
 int rg_import_vertices(rg_handle *h, const void *records, uint64_t n_pairs) {
 	if (h) h->hist_valid = false;
 	if (!h || (n_pairs && !records)) return RG_ERR_ARG;
@@ -3401,6 +3689,13 @@ int rg_release_cached_memory(void) {
 		}
 	}
 	for (void *p : drop) (void)hipFree(p);
+	return RG_OK;
+}
+
+int rg_debug_set(rg_handle *h, uint32_t flags) {
+	if (!h) return RG_ERR_ARG;
+	if (h->phase != PH_CREATED) return fail(h, RG_ERR_STATE, "rg_debug_set must come before counting starts");
+	h->dbg = flags;
 	return RG_OK;
 }
 

@@ -164,6 +164,32 @@ def purge_edges_distributed(engine, group=None, device="cuda", always=False):
     return total
 
 
+def read_markers_distributed(engine, n_reads, group=None, device="cuda"):
+    """SequencesIndexer marker selection across ranks (IndexerWorker.cpp:67-248): one all-to-all of the k-mers of this
+    rank's reads to their owners, one of 4-byte coverages back (the reference sends one
+    RAY_MPI_TAG_REQUEST_VERTEX_COVERAGE message per k-mer, :76-96).  Returns (forward, reverse) numpy arrays, -1 = none."""
+    unit = 8 * engine.kmer_words
+    counts = engine.markers_query_counts()
+    total = sum(counts)
+    keys = torch.empty(max(1, total) * unit, dtype=torch.uint8, device=device)
+    engine.markers_export_queries(keys.data_ptr(), max(1, total))
+    staged = _staged(group) and str(device) != "cpu"
+    asked, asked_counts = _all_to_all_bytes(keys, counts, unit, group, device, staged)
+    n_asked = sum(asked_counts)
+    answers = torch.zeros(max(1, n_asked) * 4, dtype=torch.uint8, device=device)
+    if str(device) != "cpu":
+        torch.cuda.current_stream().synchronize()
+    engine.markers_answer(asked.data_ptr(), n_asked, answers.data_ptr())
+    back, back_counts = _all_to_all_bytes(answers, asked_counts, 4, group, device, staged)
+    assert back_counts == counts
+    fwd = torch.empty(max(1, n_reads), dtype=torch.int32, device=device)
+    rev = torch.empty(max(1, n_reads), dtype=torch.int32, device=device)
+    if str(device) != "cpu":
+        torch.cuda.current_stream().synchronize()
+    engine.markers_apply(back.data_ptr(), total, fwd.data_ptr(), rev.data_ptr())
+    return fwd[:n_reads].cpu().numpy(), rev[:n_reads].cpu().numpy()
+
+
 HIST_DENSE = 65536
 
 

@@ -100,7 +100,7 @@ class GraphBuilder:
     def __init__(self, k, rank=0, size=1, device=0, bloom_bits=RG_BLOOM_DEFAULT, kmer_words=0, table_slots=0,
                  first_read_id=0, stream=None, sweep=0):
         self._L = _lib.load()
-        cfg = RgConfig(k=k, kmer_words=kmer_words, rank=rank, size=size, device=device, reserved0=sweep,
+        cfg = RgConfig(k=k, kmer_words=kmer_words, rank=rank, size=size, device=device, reserved0=0,
                        bloom_bits=bloom_bits, table_slots=table_slots, first_read_id=first_read_id,
                        stream=C.c_void_p(stream) if stream else None)
         self._h = C.c_void_p()
@@ -109,6 +109,8 @@ class GraphBuilder:
             msg = self._L.rg_last_error(None).decode()
             self._h = None
             raise RayGraphError(rc, msg)
+        if sweep:   # tests and experiments: force internal routes (rg_debug_set)
+            self._check(self._L.rg_debug_set(self._h, sweep))
         self.k, self.rank, self.size, self.device = k, rank, size, device
         self.kmer_words = kmer_words if kmer_words else (1 if k <= 31 else 2)
         self._keep = []
@@ -264,6 +266,21 @@ class GraphBuilder:
 
     def purge_apply(self, answers_ptr, n):
         self._check(self._L.rg_purge_apply(self._h, answers_ptr, n))
+
+    # -- markers across ranks (exchange.read_markers_distributed drives these)
+    def markers_query_counts(self):
+        out = (C.c_uint64 * self.size)()
+        self._check(self._L.rg_markers_query_counts(self._h, out))
+        return [int(x) for x in out]
+
+    def markers_export_queries(self, device_ptr, capacity_queries):
+        self._check(self._L.rg_markers_export_queries(self._h, device_ptr, capacity_queries))
+
+    def markers_answer(self, queries_ptr, n, coverage_ptr):
+        self._check(self._L.rg_markers_answer(self._h, queries_ptr, n, coverage_ptr))
+
+    def markers_apply(self, coverage_ptr, n, forward_ptr, reverse_ptr):
+        self._check(self._L.rg_markers_apply(self._h, coverage_ptr, n, forward_ptr, reverse_ptr))
 
     # -- the store
     def size_(self):

@@ -86,6 +86,7 @@ class ModelEngine:
         self.local = {}   # key -> [stamp, count, edges]
         self.table = {}
         self.final = None
+        self._reads = []
 
     def add_reads(self, packed, offsets, lengths):
         for key, stamp, em in occurrences(packed, offsets, lengths, self.k, self.first_read_id + self.n_reads):
@@ -93,6 +94,7 @@ class ModelEngine:
             e[0] = min(e[0], stamp)
             e[1] += 1
             e[2] |= em
+        self._reads.append((packed, np.asarray(offsets), np.asarray(lengths)))
         self.n_reads += len(lengths)
 
     def count_local(self):
@@ -257,6 +259,61 @@ class ModelEngine:
             if not a:
                 cov, em = self.final[key]
                 self.final[key] = (cov, em & ~(1 << bit))
+
+    # ---- markers across ranks (same surface as GraphBuilder.markers_*; host pointers) ----
+    def markers_query_counts(self):
+        self._mq = [[] for _ in range(self.size)]   # per owner: (canonical k-mer, read, position)
+        r0 = 0
+        for packed, offsets, lengths in self._reads:
+            for key, stamp, _ in occurrences(packed, offsets, lengths, self.k, r0):
+                self._mq[self._owner(key)].append((key, stamp >> 16, stamp & 0xFFFF))
+            r0 += len(lengths)
+        return [len(q) for q in self._mq]
+
+    def markers_export_queries(self, ptr, capacity):
+        flat = [q for per in self._mq for q in per]
+        assert len(flat) <= capacity
+        out = np.zeros((len(flat), self.W), dtype=np.uint64)
+        for i, (key, _, _) in enumerate(flat):
+            out[i] = to_internal(key[0], key[1], self.W)[: self.W]
+        if len(flat):
+            C.memmove(ptr, out.ctypes.data, out.nbytes)
+        self._mflat = flat
+
+    def markers_answer(self, qptr, n, aptr):
+        if n == 0:
+            return
+        buf = (C.c_uint8 * (n * 8 * self.W)).from_address(qptr)
+        q = np.frombuffer(buf, dtype=np.uint64).reshape(n, self.W)
+        ans = np.zeros(n, dtype=np.uint32)
+        for i in range(n):
+            key = from_internal(int(q[i, 0]), int(q[i, 1]) if self.W == 2 else 0, self.W)
+            ans[i] = self.final[key][0] if key in self.final else 0
+        C.memmove(aptr, ans.ctypes.data, 4 * n)
+
+    def markers_apply(self, aptr, n, fptr, rptr):
+        """IndexerWorker.cpp:97-248 on the coverages that came back"""
+        assert n == len(self._mflat)
+        ans = np.frombuffer((C.c_uint8 * max(4, 4 * n)).from_address(aptr), dtype=np.uint32)[:n] if n else []
+        lengths = np.concatenate([l for _, _, l in self._reads]) if self._reads else np.zeros(0, dtype=np.uint32)
+        cov = [dict() for _ in range(len(lengths))]
+        for a, (_, read, pos) in zip(ans, self._mflat):
+            cov[read][pos] = int(a)
+        fwd = np.full(max(1, len(lengths)), -1, dtype=np.int32)
+        rev = np.full(max(1, len(lengths)), -1, dtype=np.int32)
+        for r, L in enumerate(lengths.tolist()):
+            n_k = L - self.k + 1 if L >= self.k else 0
+            best, best_score = -1, 0
+            for value in range(10, 0, -1):
+                score = sum(1 for p in range(n_k) if cov[r][p] <= value or cov[r][p] >= 2 * value)
+                if best == -1 or score > best_score:
+                    best, best_score = value, score
+            good = [p for p in range(n_k) if cov[r][p] >= 2 * best]
+            if good:
+                fwd[r] = good[0]
+                rev[r] = L - self.k - good[-1]
+        C.memmove(fptr, fwd.ctypes.data, 4 * len(lengths))
+        C.memmove(rptr, rev.ctypes.data, 4 * len(lengths))
 
     def records(self, with_edges=True):
         dt = self.ro.record_dtype(self.W)

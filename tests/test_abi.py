@@ -94,3 +94,33 @@ def test_coverage_distribution_matches_oracle(oracle, tmp_path):
         assert open(a, "rb").read() == open(b, "rb").read()
     with pytest.raises(ray_amd.RayGraphError):
         ray_amd.coverage_distribution(np.zeros(0, np.uint32), np.zeros(0, np.uint64))
+
+
+def test_header_is_plain_c_and_the_glue_calls_type_check(tmp_path):
+    """include/raygraph.h must compile as C (the boundary has no C++ types), and the call sequence INTEGRATION.md shows
+    -- one rg_handle* member, rg_create(&cfg, &member), every later call with the member itself -- must type-check."""
+    import subprocess
+    inc = os.path.join(ROOT, "include")
+    src = tmp_path / "glue.c"
+    src.write_text("""
+#include <raygraph.h>
+#include <string.h>
+static rg_handle *m_gpuGraph;
+int glue(const uint8_t *packed, uint64_t nbytes, const uint64_t *off, const uint32_t *len, uint64_t n, void *d_buf){
+	rg_config cfg; memset(&cfg,0,sizeof cfg); cfg.k=31; cfg.size=1; cfg.bloom_bits=RG_BLOOM_DEFAULT;
+	if(rg_create(&cfg,&m_gpuGraph)!=RG_OK) return 1;
+	rg_add_reads(m_gpuGraph,packed,nbytes,off,len,n);
+	if(rg_count_kmers(m_gpuGraph)!=RG_OK) return 2;
+	uint64_t nh=0; rg_histogram(m_gpuGraph,NULL,NULL,0,&nh);
+	rg_add_edges(m_gpuGraph);
+	uint64_t pairs=0; rg_export(m_gpuGraph,NULL,0,&pairs);
+	uint64_t counts[1]; uint32_t rb; rg_records_local_part(m_gpuGraph,0,4); rg_record_counts(m_gpuGraph,counts,&rb);
+	rg_export_records(m_gpuGraph,d_buf,counts[0]); rg_count_records(m_gpuGraph,d_buf,counts[0]);
+	rg_owner_counts(m_gpuGraph,counts); rg_resolve_admission(m_gpuGraph,n);
+	return rg_destroy(m_gpuGraph);
+}
+""")
+    for compiler, std in (("gcc", "-std=c99"), ("g++", "-std=c++98")):
+        res = subprocess.run([compiler, std, "-Wall", "-Werror", "-fsyntax-only", "-x", "c" if compiler == "gcc" else "c++", "-I", inc, str(src)],
+                             capture_output=True, text=True)
+        assert res.returncode == 0, res.stderr

@@ -18,7 +18,7 @@ def _worker(rank, world, port, k, bloom, out_dir, route):
     from model import ModelEngine
     from oracle import ray_oracle as ro
     from ray_amd.exchange import (exchange_owner_buckets, exchange_records, partition_reads, purge_edges_distributed,
-                                  reduce_histogram)
+                                  read_markers_distributed, reduce_histogram)
     from ray_amd.synth import make_reads_numpy
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -39,6 +39,8 @@ def _worker(rank, world, port, k, bloom, out_dir, route):
     e.resolve_admission(last - first)
     cov, cnt = reduce_histogram(*e.histogram(), device="cpu", size=world)
     np.save(os.path.join(out_dir, "rec%d.npy" % rank), e.records())
+    fwd, rev = read_markers_distributed(e, last - first, device="cpu")   # SequencesIndexer: k-mers out, coverages back
+    np.save(os.path.join(out_dir, "markers%d.npy" % rank), np.stack([fwd, rev]))
     asked = purge_edges_distributed(e, device="cpu")   # RAY_SLAVE_MODE_PURGE_NULL_EDGES: key all-to-all, answers back
     assert asked == sum(bin(int(em)).count("1") for em in np.load(os.path.join(out_dir, "rec%d.npy" % rank))["edges"])
     np.save(os.path.join(out_dir, "purged%d.npy" % rank), e.records())
@@ -60,6 +62,9 @@ def test_two_rank_exchange_over_gloo(oracle, tmp_path, k, bloom, route):
     for r in range(2):
         got = np.load(str(tmp_path / ("rec%d.npy" % r)))
         assert_records_equal(got, want["graph"].export(r), "rank %d" % r)
+    wf, wr = want["graph"].read_markers()
+    got = np.concatenate([np.load(str(tmp_path / ("markers%d.npy" % r))) for r in range(2)], axis=1)
+    assert np.array_equal(got[0], wf) and np.array_equal(got[1], wr)
     want["graph"].purge_edges()
     changed = 0
     for r in range(2):

@@ -88,11 +88,51 @@ def test_multirank_matches_oracle(oracle, k, nranks, bloom):
                                      (1 | 16 | (10 << 8), "records", 3, False), (2 | 32, "records", 1, False)):
         builders = run_ranks(packed, offsets, lengths, k, nranks, bloom, sweep=sweep, route=route, parts=parts, one_merge=one)
         check_ranks(builders, want, route)
+    # SequencesIndexer's markers across ranks (IndexerWorker.cpp:67-248): k-mers to their owners, coverages back
+    wf, wr = want["graph"].read_markers()
+    gf, gr = markers_ranks(builders, len(lengths))
+    assert (wf >= 0).sum() > 100 and (wf < 0).sum() > 0, "both outcomes must occur in the test data"
+    assert np.array_equal(gf, wf) and np.array_equal(gr, wr)
     # RAY_SLAVE_MODE_PURGE_NULL_EDGES across ranks: keys to the owners, one-byte answers back
     want["graph"].purge_edges()
     purge_ranks(builders)
     for r, b in enumerate(builders):
         assert_records_equal(b.export(), want["graph"].export(r), "rank %d after purge" % r)
+
+
+def markers_ranks(builders, n_reads):
+    """rg_markers_*: the bytes two all-to-all(v) would move, through device buffers; returns the markers of all reads in
+    global read order (rank r holds the reads of partition_reads(n, r, R))"""
+    import torch
+    R = len(builders)
+    unit = 8 * builders[0].kmer_words
+    asked = []
+    for b in builders:
+        counts = b.markers_query_counts()
+        keys = torch.empty(max(1, sum(counts)) * unit, dtype=torch.uint8, device="cuda")
+        b.markers_export_queries(keys.data_ptr(), max(1, sum(counts)))
+        asked.append((counts, keys))
+    answers = [[None] * R for _ in range(R)]  # answers[src][dst]
+    for dst, b in enumerate(builders):
+        for src, (counts, keys) in enumerate(asked):
+            start, n = sum(counts[:dst]), counts[dst]
+            part = keys[start * unit:(start + n) * unit].clone()
+            ans = torch.full((max(1, n),), 0x7FFFFFFF, dtype=torch.int32, device="cuda")
+            b.markers_answer(part.data_ptr(), n, ans.data_ptr())
+            answers[src][dst] = ans[:n]
+    torch.cuda.synchronize()
+    fwd, rev = [], []
+    for src, b in enumerate(builders):
+        first, last = partition_reads(n_reads, src, R)
+        total = sum(asked[src][0])
+        back = torch.cat(answers[src]) if total else torch.zeros(1, dtype=torch.int32, device="cuda")
+        f = torch.full((max(1, last - first),), -7, dtype=torch.int32, device="cuda")
+        r = torch.full((max(1, last - first),), -7, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        b.markers_apply(back.data_ptr(), total, f.data_ptr(), r.data_ptr())
+        fwd.append(f[:last - first].cpu().numpy())
+        rev.append(r[:last - first].cpu().numpy())
+    return np.concatenate(fwd), np.concatenate(rev)
 
 
 def purge_ranks(builders):

@@ -34,7 +34,7 @@ def nccl_group():
 def test_exchanges_run_on_rccl(oracle, nccl_group, k, parts):
     import torch
     import ray_amd
-    from ray_amd.exchange import exchange_owner_buckets, exchange_records, purge_edges_distributed, reduce_histogram
+    from ray_amd.exchange import exchange_owner_buckets, exchange_records, purge_edges_distributed, read_markers_distributed, reduce_histogram
     assert nccl_group.get_backend() == "nccl"
     packed, offsets, lengths = make_reads_numpy(genome=30000, read_len=150, n_reads=9000, seed=70 + k, error=0.01)
     bloom = 2000000
@@ -52,6 +52,9 @@ def test_exchanges_run_on_rccl(oracle, nccl_group, k, parts):
     assert_records_equal(b.export(), want["pass1"], "after pass 1")
     b.add_edges()
     assert_records_equal(b.export(), want["pass2"], "after pass 2")
+    wf, wr = want["graph"].read_markers()                                   # markers before the purge, as SequencesIndexer runs
+    gf, gr = read_markers_distributed(b, len(lengths), device="cuda:0")   # keys out, 4-byte coverages back
+    assert np.array_equal(gf, wf) and np.array_equal(gr, wr)
     asked = purge_edges_distributed(b, device="cuda:0", always=True)      # keys out, one-byte answers back
     assert asked > 0
     assert_records_equal(b.export(), want["purged"], "after purge")
