@@ -46,6 +46,7 @@ def parse():
                          "once a rank's own reads hold most k-mers only a few times)")
     ap.add_argument("--parts", type=int, default=4, help="records route: slices of the reads whose record transfers overlap the next slice's kernels")
     ap.add_argument("--sweep", type=lambda x: int(x, 0), default=0, help="rg_debug_set flags (development: forces a sweep / bucket bits)")
+    ap.add_argument("--no-after", action="store_true", help="skip the purge and the store hand-back that are measured after the timed steps")
     ap.add_argument("--breakdown", action="store_true", help="print per-call wall times of the last step to stderr")
     return ap.parse_args()
 
@@ -95,7 +96,9 @@ def cpu_baseline(packed, offsets, lengths, k, n_sample, cores):
     rate = sum(r[0] / r[2] for r in res)
     return {"value": rate, "unit": "k-mer occurrences/s", "cores": cores, "kind": "port",
             "sample": "%d instances x %d reads of the same workload (%d occurrences, %d vertices stored in all), %.1f s per "
-                      "instance, %.1f s wall: count + histogram + edges; value = sum of the instances' rates"
+                      "instance, %.1f s wall: count + histogram + edges; no message exchange is paid (every instance is a "
+                      "whole one-rank graph whose tables fit in cache), so value = sum of the instances' rates is an upper bound "
+                      "for mpiexec -n <cores> Ray on these cores"
                       % (cores, n, occ, stored, max(r[2] for r in res), wall),
             "distinct_kmers_per_s": sum(r[1] / r[2] for r in res)}
 
@@ -149,10 +152,15 @@ def main():
     # emulated entries route: the rank's own reads cover the N-fold genome N times thinner
     genome = max(2000, int(cfg["genome"] * args.scale)) * world * (emu if route == "entries" else 1)
     n_reads = synth.n_reads_for(int(cfg["genome"] * args.scale), cfg["read_len"], cfg["coverage"])
+    species = None
+    if "species" in cfg:   # C4: the metagenome grows by whole species with N
+        sp_len, sp_cov, n_all = synth.metagenome_plan(cfg, args.scale, species_factor=world * (emu if route == "entries" else 1))
+        species, genome, n_reads = (sp_len, sp_cov), int(sp_len.sum()), n_all // (world * (emu if route == "entries" else 1))
+    error = cfg["error"] if args.error is None else args.error
     t0 = time.perf_counter()
     # same genome on every rank (same seed), different reads per rank
-    packed, offsets, lengths = synth.make_reads_torch(genome, cfg["read_len"], n_reads, cfg["seed"], cfg["error"] if args.error is None else args.error,
-                                                      device=dev, read_seed=cfg["seed"] * 1000 + rank)
+    packed, offsets, lengths = synth.make_reads_torch(genome, cfg["read_len"], n_reads, cfg["seed"], error,
+                                                      device=dev, read_seed=cfg["seed"] * 1000 + rank, species=species)
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
     gen_s = time.perf_counter() - t0
@@ -160,15 +168,20 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     marks = []
+    phases = {}   # the reference's step names (TimePrinter, MachineHelper.cpp:605,453,466,583) -> seconds over the timed steps
+
+    def phase(name, t_start):
+        phases[name] = phases.get(name, 0.0) + time.perf_counter() - t_start
 
     def mark(name):
         if args.breakdown:
             torch.cuda.synchronize()
             marks.append((name, time.perf_counter()))
 
-    def one_step(profile=False):
+    def one_step(profile=False, keep=False):
         del marks[:]
         mark("start")
+        tp = time.perf_counter()
         b = ray_amd.GraphBuilder(k, rank=rank, size=world * emu, device=local_rank, first_read_id=first_read_id, stream=stream, sweep=args.sweep)
         if profile:
             b.set_profiling(True)
@@ -229,14 +242,24 @@ def main():
             exchange_owner_buckets(b, device=dev)     # aggregated entries to the rank vertexRank names
             b.resolve_admission(n_reads)
         mark("count/resolve")
+        if profile:          # every call above returns with its stream drained, so wall time per call is the phase's time
+            phase("K-mer counting", tp)
+        tp = time.perf_counter()
         cov, cnt = b.histogram()                 # RAY_SLAVE_MODE_SEND_DISTRIBUTION
         if world > 1:
             cov, cnt = reduce_histogram(cov, cnt, device=dev, size=world)
         mark("histogram")
+        if profile:
+            phase("Coverage distribution analysis", tp)
+        tp = time.perf_counter()
         b.add_edges()                            # RAY_SLAVE_MODE_ADD_EDGES
         mark("add_edges")
+        if profile:
+            phase("Graph construction", tp)
         st = b.stats()
         sweep = b.kernel_profile() if profile else {}
+        if keep:
+            return st, sweep, b
         b.close()
         mark("destroy")
         return st, sweep, (cov, cnt)
@@ -269,6 +292,31 @@ def main():
         stored, occ, cand = [int(x) for x in tot.tolist()]
     else:
         stored, occ, cand = st["stored_pairs"], st["occurrences"], st["candidates"]
+
+    # What follows the three slave modes in a Ray run, measured once after the timed region (not part of `value`):
+    # RAY_SLAVE_MODE_PURGE_NULL_EDGES (MachineHelper.cpp:583) and the hand-back of the store to the host GridTable
+    # (rg_export: Vertex::dump records to host memory; the host's own inserts are Ray's, not timed here)
+    after = {}
+    if not args.no_after:
+        from ray_amd.exchange import purge_edges_distributed
+        _, _, b = one_step(keep=True)
+        barrier()
+        tp = time.perf_counter()
+        purge_edges_distributed(b, device=dev)
+        torch.cuda.synchronize()
+        after["Null edge purging"] = (time.perf_counter() - tp) * 1e3
+        if world == 1 and emu == 1:
+            import numpy as np
+            from ray_amd.graph import record_dtype
+            rec = np.zeros(b.stats()["stored_pairs"], dtype=record_dtype(1 if k <= 31 else 2))   # zero-filled = touched, like the glue's vector<char>
+            tp = time.perf_counter()
+            n_rec = b.export_into(rec)
+            after["store hand-back (rg_export to host memory)"] = (time.perf_counter() - tp) * 1e3
+            after["store hand-back records"] = n_rec
+            after["store hand-back bytes"] = n_rec * rec.dtype.itemsize
+            del rec
+        b.close()
+        barrier()
 
     if rank == 0 and args.breakdown:
         for (n0, t0_), (n1, t1_) in zip(marks, marks[1:]):
@@ -333,16 +381,21 @@ def main():
         # (tools/profile_c2.sh; FETCH_SIZE and WRITE_SIZE in separate runs).  FETCH_SIZE is doubled as
         # MI355X_MICROARCH.md prescribes for gfx950 (checked here on k_scatter / k_level_hist / k_init_table,
         # whose byte counts are known exactly).
-        traffic = None
+        traffic = traffic_step = None
         try:
-            if args.workload.startswith("C2") and args.scale == 1.0 and world == 1 and dom:
+            if args.workload.startswith("C2") and args.scale == 1.0 and world == 1 and dom and error == 0.0:
                 with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), PMC_SUMMARY)) as fh:
-                    pm = json.load(fh).get(dom)
+                    pmc = json.load(fh)
+                pm = pmc.get(dom)
                 if pm and pm.get("launches"):
                     traffic = (2.0 * pm.get("FETCH_SIZE_bytes", 0.0) + pm.get("WRITE_SIZE_bytes", 0.0)) / pm["launches"]
+                if pmc.get("_steps"):   # all kernels of the profiled run / its steps
+                    traffic_step = sum(2.0 * v.get("FETCH_SIZE_bytes", 0.0) + v.get("WRITE_SIZE_bytes", 0.0)
+                                       for kn, v in pmc.items() if isinstance(v, dict)) / pmc["_steps"]
         except (OSError, ValueError):
-            traffic = None
+            traffic = traffic_step = None
         launches_dom = (kprof[dom][1] / args.steps) if dom else 0
+        step_gbs = pass1_bytes_per_occ * occ0 / per_step / 1e9
         out = {
             "metric": "distinct k-mers inserted/sec (whole node)",
             "value": stored / per_step,
@@ -352,12 +405,18 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": args.workload + ("" if args.scale == 1.0 else "@scale=%g" % args.scale) + ("" if args.error is None else "@error=%g" % args.error), "k": k,
-                       "read_len": L, "reads_per_gpu": n_reads, "genome_bp": genome,
+                       "read_len": L, "reads_per_gpu": n_reads, "genome_bp": genome, "substitution_error_rate": error,
                        "parallelism": "owner-partitioned x%d" % world + ("" if nranks == 1 else ", %s route" % route) + ("" if emu == 1 else " (rank 0 of %d emulated on one GPU, no network)" % emu), "bloom": "default 16*k*reads cap 2^33"},
             "occurrences_per_s": occ / per_step,
             "kmer_occurrences": occ, "distinct_candidates": cand, "vertices_stored": stored,
+            # frac = frac_step: SURVEY 8(d)'s bytes per occurrence (stream + Bloom + table: what the path must move whatever
+            # the algorithm) x the occurrences of a step / the whole step's time.  achieved / frac_kernel: the dominant
+            # kernel's own algorithmic bytes per launch / its average launch duration (HIP events on the launch stream).
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                         "frac": step_gbs / HBM_PEAK_GBS, "frac_step": step_gbs / HBM_PEAK_GBS,
+                         "frac_kernel": (achieved / HBM_PEAK_GBS) if achieved else None,
+                         "achieved_step": step_gbs, "step_bytes_per_occurrence": pass1_bytes_per_occ,
+                         "traffic": traffic, "traffic_step": traffic_step,
                          "traffic_unit": "bytes per launch (rocprofv3 PMC, %s)" % PMC_SUMMARY,
                          "algorithmic_bytes_per_launch": (alg_bytes[dom] / launches_dom) if dom in alg_bytes and launches_dom else None,
                          "kernel": dom, "bytes_per_occurrence": bytes_per_occ,
@@ -367,6 +426,8 @@ def main():
             "pass1_algorithmic": {"bytes_per_occurrence": pass1_bytes_per_occ,
                                   "GBps_over_whole_step": pass1_bytes_per_occ * occ0 / per_step / 1e9,
                                   "frac_of_hbm_peak": pass1_bytes_per_occ * occ0 / per_step / 1e9 / HBM_PEAK_GBS},
+            "phases_ms_per_step": {name: sec / args.steps * 1e3 for name, sec in phases.items()},
+            "after_the_timed_step_ms": after,
             "setup_s": gen_s,
         }
         if not args.no_cpu_baseline and world == 1:

@@ -27,6 +27,7 @@ extern "C" {
 #define RG_ERR_NOMEM (-3)    /* device or host allocation failed */
 #define RG_ERR_STATE (-4)    /* call made in the wrong phase */
 #define RG_ERR_CAPACITY (-5) /* caller buffer too small / internal limit hit */
+#define RG_ERR_HASH (-6)     /* rg_check_hashes: the library's k-mer hashes are not the caller's */
 
 /* bloom_bits: size the filter like VerticesExtractor::getDefaultNumberOfBitsForBloomFilter
  * (VerticesExtractor/VerticesExtractor.cpp:276-320): 16*k*localReads capped at 2^33 */
@@ -56,6 +57,22 @@ int rg_create(const rg_config *cfg, rg_handle **out);
 int rg_destroy(rg_handle *h);
 /* text of the last error on this handle ("" if none); h may be NULL for rg_create failures */
 const char *rg_last_error(const rg_handle *h);
+
+/* ---- the hashes, checked against Ray's own ----------------------------------------------------------- */
+/* Owners (vertexRank = hash_function_1 % size, Kmer.cpp:165-170) and Bloom bits (hash_function_2 ^ magic,
+ * BloomFilter.cpp:124-200) rest on RayPlatform's uniform_hashing_function_1_64_64 / _2_64_64
+ * (cryptography/crypto.cpp), a file that is absent from the reference tree this library was written against: the
+ * kernels hold the published Thomas Wang mixes those functions are known as.  The rest of Ray computes owners with the
+ * real ones, so the glue proves agreement once, right after rg_create, and aborts on RG_ERR_HASH:
+ *   rg_check_hashes  hashes n_samples k-mers (fixed corners + a pseudo-random stream; 16 <= n <= 2^20) ON THE DEVICE,
+ *                    with the code the kernels use, and compares with the caller's functions.  hash1 / hash2 get the
+ *                    words of a k-mer as Kmer::getU64(0..kmer_words-1) returns them and return
+ *                    Kmer::hash_function_1() / _2() (Kmer.cpp:284-310); `user` is passed through.
+ *   rg_hash_kmers    the device's two hashes for the caller's own k-mers (host arrays; kmer_words words per k-mer),
+ *                    for a glue that prefers to compare by itself. */
+typedef uint64_t (*rg_hash_fn)(const uint64_t *kmer_words, void *user);
+int rg_check_hashes(rg_handle *h, rg_hash_fn hash1, rg_hash_fn hash2, void *user, uint32_t n_samples);
+int rg_hash_kmers(rg_handle *h, const uint64_t *kmers, uint64_t n, uint64_t *hash1_out, uint64_t *hash2_out);
 
 /* ---- input: ArrayOfReads (SequencesLoader/Read.cpp:176-204 getRawSequence()/length()) ------- */
 /* packed: the reads' 2-bit buffers back to back (base i of a read = bits 2(i%4).. of byte i/4,
@@ -259,7 +276,7 @@ int rg_release_cached_memory(void);
 
 /* ---- test and experiment switches -------------------------------------------------------------- */
 /* Forces internal routes that the library otherwise chooses by itself; results never depend on them.  No counterpart
- * in the reference; a plugin leaves it alone.  Must be called before the counting starts.  flags: bits 0-7: 0 = automatic, 1 = force the partitioned sweep, 2 = force the direct sweep; bits 8-15: log2 of the bucket count of the partitioned sweep (0 = automatic); bit 4 / bit 5: force the partitioned / the dense Bloom resolution; bit 6: start with a one-chunk log (tests of the overflow path); bit 16: cut super-k-mer records with the wavefront-per-read kernel even where the lane-per-read one applies; bit 17: produce the Bloom items straight into their first partition level even from a sparse key array; bit 18: size the log from a sample of the buckets even on small inputs (tests); bit 19: rg_merge_entries never keeps received entries as a log (tests); bit 20: the partition levels' histograms read the records instead of the digit bytes the previous level left (tests); bit 21: aggregate with a workgroup per bucket of a two-level partition (k_aggregate_wg) instead of a wavefront per bucket of a three-level one (tests); bit 22 / bit 23: always / never build the vertex table range by range from partitioned entries (tests); bit 24: resolve a power-of-two Bloom filter by key partitions whatever its fill (tests) */
+ * in the reference; a plugin leaves it alone.  Must be called before the counting starts.  flags: bits 0-7: 0 = automatic, 1 = force the partitioned sweep, 2 = force the direct sweep; bits 8-15: log2 of the bucket count of the partitioned sweep (0 = automatic); bit 4 / bit 5: force the partitioned / the dense Bloom resolution; bit 6: start with a one-chunk log (tests of the overflow path); bit 16: cut super-k-mer records with the wavefront-per-read kernel even where the lane-per-read one applies; bit 17: produce the Bloom items straight into their first partition level even from a sparse key array; bit 18: size the log from a sample of the buckets even on small inputs (tests); bit 19: rg_merge_entries never keeps received entries as a log (tests); bit 20: the partition levels' histograms read the records instead of the digit bytes the previous level left (tests); bit 21: aggregate with a workgroup per bucket of a two-level partition (k_aggregate_wg) instead of a wavefront per bucket of a three-level one (tests); bit 22 / bit 23: always / never build the vertex table range by range from partitioned entries (tests); bit 24: resolve a power-of-two Bloom filter by key partitions whatever its fill (tests); bit 25: pick the bucket count from a sample of the records even on small inputs (tests) */
 int rg_debug_set(rg_handle *h, uint32_t flags);
 
 /* ---- profiling (the reference's MACRO_COLLECT_PROFILING_INFORMATION probes,

@@ -818,6 +818,16 @@ __global__ __launch_bounds__(256) void k_markers_from_coverage(const uint32_t *_
 	}
 }
 
+// Kmer::hash_function_1 / _2 as the kernels compute them, for rg_hash_kmers (keys = the lower k-mer's words, W per key)
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_hash_kmers(const uint64_t *__restrict__ keys, uint64_t n, uint64_t *__restrict__ h1, uint64_t *__restrict__ h2) {
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const uint64_t K0 = keys[i * W], K1 = (W == 2) ? keys[i * W + 1] : 0;
+	h1[i] = hash1<W>(K0, K1);
+	h2[i] = hash2<W>(K0, K1);
+}
+
 // Vertex::load for a whole checkpoint (Vertex.cpp:422-436, MessageProcessor.cpp:596-655): records in Vertex::dump
 // layout go straight into the table with their coverage and edge byte
 template <int W>
@@ -1240,6 +1250,7 @@ struct rg_handle {
 	void *rec_buf = nullptr;             // rg_records_local .. rg_export_records: super-k-mer records of the local reads
 	uint64_t rec_slots = 0;              // slots of rec_buf in use (holes included)
 	std::vector<uint64_t> rec_counts;    // valid records per destination rank
+	const char *prof_alias = nullptr;     // set: every kernel is profiled under this name (the sample's sweep inside the sweep)
 	uint64_t *d_marker_origin = nullptr;  // rg_markers_export_queries .. rg_markers_apply: (read << 16 | position) per query
 	uint64_t marker_total = 0;
 	std::vector<uint64_t> marker_counts;
@@ -1257,7 +1268,7 @@ struct ProfScope {
 	rg_handle *h;
 	const char *name;
 	hipEvent_t e0 = nullptr, e1 = nullptr;
-	ProfScope(rg_handle *h_, const char *name_) : h(h_), name(name_) {
+	ProfScope(rg_handle *h_, const char *name_) : h(h_), name(h_->prof_alias ? h_->prof_alias : name_) {
 		if (!h->profiling) return;
 		if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
 			e0 = nullptr;
@@ -1388,13 +1399,13 @@ struct SuperkmerLaunch {
 	bool lanes(const ReadBatch &b) const { return grid_lane > 0 && b.maxlen <= SKL_MAX_READ; }
 	const char *name(const ReadBatch &b) const { return lanes(b) ? "k_superkmers_lanes" : "k_superkmers"; }
 	void launch(rg_handle *h, const ReadBatch &b, uint64_t lo, uint64_t n, int k, int m, Rec<W> *buf, uint64_t rec_cap,
-	            unsigned long long *d_hist, uint32_t modulo, uint32_t hist_shift) const {
+	            unsigned long long *d_hist, uint32_t modulo, uint32_t hist_shift, Rec<W> *sample = nullptr, uint64_t sample_cap = 0) const {
 		if (lanes(b))
 			hipLaunchKernelGGL(k_superkmers_lanes<W>, dim3(grid_lane), dim3(256), lds_lane, h->stream, b.d_packed, b.d_off + lo, b.d_len + lo, n,
-			                   b.first_id + lo, k, m, buf, rec_cap, h->d_counters, d_hist, modulo, hist_shift);
+			                   b.first_id + lo, k, m, buf, rec_cap, h->d_counters, d_hist, modulo, hist_shift, sample, sample_cap);
 		else
 			hipLaunchKernelGGL(k_superkmers<W>, dim3(grid_wave), dim3(256), 0, h->stream, b.d_packed, b.d_off + lo, b.d_len + lo, n,
-			                   b.first_id + lo, k, m, buf, rec_cap, h->d_counters, d_hist, modulo, hist_shift);
+			                   b.first_id + lo, k, m, buf, rec_cap, h->d_counters, d_hist, modulo, hist_shift, sample, sample_cap);
 	}
 };
 
@@ -1440,8 +1451,12 @@ struct AggLaunch {
 	}
 };
 
+// top / nested_bits: the sweep over the sample of the records that sizes the real one (see SAMPLE_BITS): the buckets are
+// numbered by the nested_bits bits below bit `top` of the bucket number, nothing is sampled or probed, no statistics kept.
 template <int W>
-static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bool *ok, const void *ext = nullptr, uint64_t ext_n = 0) {
+static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bool *ok, const void *ext = nullptr, uint64_t ext_n = 0,
+                               int top = BUCKET_TOP, int nested_bits = 0) {
+	const bool nested = nested_bits > 0;
 	*ok = false;
 	h->log_all_unique = false;
 	*out_log = nullptr;
@@ -1476,22 +1491,32 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	// by k_aggregate<SLOW> itself
 	AggLaunch<W> agg;
 	agg.plan((h->dbg & 0x200000) != 0);  // bit 21: a workgroup per bucket of a coarser partition (slower as it stands: DESIGN.md)
-	int bits = (h->dbg >> 8) & 0xFF;
+	int bits = nested ? nested_bits : (int)((h->dbg >> 8) & 0xFF);
+	const bool bits_forced = bits != 0;
 	if (bits == 0) {
 		bits = agg.wg ? 12 : 8;
 		while (bits < MAX_BUCKET_BITS && (occ_bound >> bits) > agg.occ_per_bucket()) bits++;
 	}
 	if (bits < 8) bits = 8;
 	if (bits > MAX_BUCKET_BITS) bits = MAX_BUCKET_BITS;
+	// The rule above assumes the redundancy of an assembly's reads (a k-mer seen ten times or more).  Reads with errors, or a
+	// metagenome's thin species, hold several times the distinct k-mers per occurrence: big inputs are sized from a sample of
+	// their records instead (below), which may raise the number of bits.
+	const bool sampling = !nested && !bits_forced && !agg.wg && (bits >= 16 || (h->dbg & 0x2000000)) && bits < MAX_BUCKET_BITS;  // bit 25: small inputs too (tests)
 	// one to three levels of at most 8 bits each, split evenly: fewer digits per level = longer runs per (tile, digit)
 	// (22 bits: 7 + 7 + 8; 8 + 7 + 7 measured 1.5-2.4 ms slower on C2, same box)
-	const int nlev = bits <= 8 ? 1 : (bits <= 16 ? 2 : 3);
-	int dbits[3] = {0, 0, 0};
-	for (int l = 0, left = bits; l < nlev; ++l) {
-		dbits[l] = left / (nlev - l);  // the odd bits go to the last levels: the earlier ones also write the digit bytes, in runs as short as their own
-		left -= dbits[l];
-	}
-	const uint64_t NBUCK = 1ull << bits;
+	int nlev = 0, dbits[3] = {0, 0, 0};
+	auto split_levels = [&]() {
+		nlev = bits <= 8 ? 1 : (bits <= 16 ? 2 : 3);
+		dbits[0] = dbits[1] = dbits[2] = 0;
+		for (int l = 0, left = bits; l < nlev; ++l) {
+			dbits[l] = left / (nlev - l);  // the odd bits go to the last levels: the earlier ones also write the digit bytes, in runs as short as their own
+			left -= dbits[l];
+		}
+	};
+	split_levels();
+	uint64_t NBUCK = 1ull << bits;
+	const uint64_t NBUCK_MAX = sampling ? (1ull << MAX_BUCKET_BITS) : NBUCK;  // what the arrays are sized for
 	// persistent grids sized to what is resident at once, so that no second, nearly empty round of
 	// workgroups runs behind the first
 	int n_cu = 256;
@@ -1503,6 +1528,8 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	for (const ReadBatch &b : h->reads)
 		if (b.maxlen >= (uint32_t)k) launches1++;
 	const uint64_t rec_cap = rec_bound + launches1 * (uint64_t)grid1 * 4 * REC_CHUNK;
+	const uint64_t sample_cap = sampling ? (rec_bound >> (SAMPLE_BITS - 2)) + 65536 : 0;  // four times its expected share
+	Rec<W> *d_sample = nullptr;
 
 	Rec<W> *buf[2] = {nullptr, nullptr};
 	unsigned long long *d_seg = nullptr, *d_hist = nullptr, *d_begin = nullptr, *d_sums = nullptr;
@@ -1512,6 +1539,7 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	Slot *log = nullptr;
 	auto cleanup = [&]() {
 		pool_free(dev, d_side);
+		pool_free(dev, d_sample);
 		pool_free(dev, buf[0]);
 		pool_free(dev, buf[1]);
 		pool_free(dev, d_seg);
@@ -1536,42 +1564,106 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	const uint64_t SEGMAX = 65536;
 	PTRY(pool_alloc(dev, (void **)&d_seg, (SEGMAX + 1) * sizeof(unsigned long long)));
 	PTRY(pool_alloc(dev, (void **)&d_tile, (SEGMAX + 1) * sizeof(uint32_t)));
-	PTRY(pool_alloc(dev, (void **)&d_hist, NBUCK * sizeof(unsigned long long)));
-	PTRY(pool_alloc(dev, (void **)&d_begin, (NBUCK + 1) * sizeof(unsigned long long)));
-	PTRY(pool_alloc(dev, (void **)&d_sums, (NBUCK / SCAN_PER_BLOCK + 2) * sizeof(unsigned long long)));
+	PTRY(pool_alloc(dev, (void **)&d_hist, std::max<uint64_t>(NBUCK_MAX, 256) * sizeof(unsigned long long)));
+	PTRY(pool_alloc(dev, (void **)&d_begin, (NBUCK_MAX + 1) * sizeof(unsigned long long)));
+	PTRY(pool_alloc(dev, (void **)&d_sums, (NBUCK_MAX / SCAN_PER_BLOCK + 2) * sizeof(unsigned long long)));
+	if (sampling && pool_alloc(dev, (void **)&d_sample, sample_cap * sizeof(Rec<W>)) != hipSuccess) {
+		(void)hipGetLastError();
+		d_sample = nullptr;  // no sample, no harm: the rule of thumb above stands
+	}
 	PTRY(hipMemsetAsync(d_hist, 0, 256 * sizeof(unsigned long long), h->stream));
-	PTRY(hipMemsetAsync(h->d_counters + PC_REC_CURSOR, 0, 8 * sizeof(unsigned long long), h->stream));
-	// 1. reads -> records (+ first-level histogram)
+	PTRY(hipMemsetAsync(h->d_counters + PC_REC_CURSOR, 0, 9 * sizeof(unsigned long long), h->stream));
+	// 1. reads -> records.  The kernel that sees every record first (the one that cuts them, or for records received from
+	// other ranks a histogram pass) counts them by the top 8 bits below `top` -- the first level's digits are the top
+	// dbits[0] <= 8 of those, its histogram a fold of this one -- and copies the sample aside.
 	uint64_t n_in = ext_n, valid = ext_n;
 	int rc = RG_OK;
+	const int hist0_shift = top - 8;
+	std::vector<unsigned long long> hist0(256);
 	if (!ext) {
 		for (const ReadBatch &b : h->reads) {
 			if (b.maxlen < (uint32_t)k) continue;
 			{
 				ProfScope ps(h, sk.name(b));
-				sk.launch(h, b, 0, b.n, k, m, buf[0], rec_cap, d_hist, 0u, (uint32_t)(24 - dbits[0]));
+				sk.launch(h, b, 0, b.n, k, m, buf[0], rec_cap, d_hist, 0u, (uint32_t)hist0_shift, d_sample, sample_cap);
 			}
 			PTRY(hipGetLastError());
 		}
-		std::vector<unsigned long long> hist(256);
-		PTRY(hipMemcpyAsync(hist.data(), d_hist, 256 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-		rc = sync_counters(h);
-		if (rc) {
-			cleanup();
-			return rc;
+	} else {
+		const unsigned long long seg1[2] = {0, n_in};
+		const uint64_t ntiles = (n_in + SCATTER_TILE - 1) / SCATTER_TILE;
+		const uint32_t tile1[2] = {0, (uint32_t)ntiles};
+		PTRY(hipMemcpyAsync(d_seg, seg1, sizeof seg1, hipMemcpyHostToDevice, h->stream));
+		PTRY(hipMemcpyAsync(d_tile, tile1, sizeof tile1, hipMemcpyHostToDevice, h->stream));
+		PTRY(hipStreamSynchronize(h->stream));  // seg1 / tile1 live on this stack frame
+		if (ntiles) {
+			ProfScope ps(h, "k_level_hist");
+			hipLaunchKernelGGL(k_level_hist<W>, dim3((unsigned)ntiles), dim3(256), 0, h->stream, (const Rec<W> *)ext, m, 1u, d_seg, d_tile, hist0_shift, 8, d_hist,
+			                   d_sample, sample_cap, h->d_counters);
 		}
+		PTRY(hipGetLastError());
+	}
+	PTRY(hipMemcpyAsync(hist0.data(), d_hist, 256 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+	rc = sync_counters(h);
+	if (rc) {
+		cleanup();
+		return rc;
+	}
+	if (!ext) {
 		if (h->h_counters[PC_REC_OVF]) {
 			cleanup();
 			return RG_OK;
 		}
 		n_in = std::min<uint64_t>(h->h_counters[PC_REC_CURSOR], rec_cap);
-		valid = 0;
-		for (auto c : hist) valid += c;
+	}
+	valid = 0;
+	for (auto c : hist0) valid += c;
+	if (ext && valid != ext_n) {
+		cleanup();
+		return fail(h, RG_ERR_STATE, "received records: %llu of %llu are valid", (unsigned long long)valid, (unsigned long long)ext_n);
 	}
 	if (valid == 0) {
 		cleanup();
 		*ok = true;
 		return RG_OK;
+	}
+	// 1b. the sample's own sweep: distinct k-mers in 1 / 2^SAMPLE_BITS of the buckets -> buckets of about AGG_TARGET k-mers
+	if (d_sample) {
+		const uint64_t n_sample = h->h_counters[PC_SAMPLE];
+		if (n_sample && n_sample <= sample_cap) {
+			Slot *slog = nullptr;
+			uint64_t sn = 0;
+			bool sok = false;
+			h->prof_alias = "sample_sweep";
+			const int src = sweep_partitioned_t<W>(h, &slog, &sn, &sok, d_sample, n_sample, BUCKET_TOP - SAMPLE_BITS, 12);
+			h->prof_alias = nullptr;
+			pool_free(dev, slog);
+			if (src != RG_OK) {
+				cleanup();
+				return src;
+			}
+			if (sok) {
+				const double distinct = (double)h->h_counters[PC_LOG_KEYS] * (double)(1u << SAMPLE_BITS);
+				int want = bits;
+				while (want < MAX_BUCKET_BITS && distinct / (double)(1ull << want) > (double)AGG_TARGET) want++;
+				if (getenv("RG_DEBUG"))
+					fprintf(stderr, "[raygraph] record sample: %llu records, %llu distinct k-mers -> %.3g in all, 2^%d buckets (rule of thumb 2^%d)\n",
+					        (unsigned long long)n_sample, (unsigned long long)h->h_counters[PC_LOG_KEYS], distinct, want, bits);
+				if (want != bits) {
+					bits = want;
+					split_levels();
+					NBUCK = 1ull << bits;
+				}
+			}
+		}
+		pool_free(dev, d_sample);
+		d_sample = nullptr;
+	}
+	{  // the first level's histogram
+		std::vector<unsigned long long> folded(256, 0);
+		for (int d8 = 0; d8 < 256; ++d8) folded[d8 >> (8 - dbits[0])] += hist0[d8];
+		hist0 = folded;
+		PTRY(hipMemcpyAsync(d_hist, hist0.data(), 256 * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
 	}
 	PTRY(pool_alloc(dev, (void **)&buf[1], valid * sizeof(Rec<W>)));
 
@@ -1584,7 +1676,7 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	for (int level = 0; level < 3 && dbits[level] > 0; ++level) {
 		const uint32_t S = (uint32_t)seg_begin.size() - 1;
 		const int db = dbits[level];
-		const int shift = 24 - used_bits - db;
+		const int shift = top - used_bits - db;
 		tile_first.assign(S + 1, 0);
 		uint64_t ntiles = 0;
 		for (uint32_t sgi = 0; sgi < S; ++sgi) {
@@ -1605,7 +1697,7 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 			ProfScope ps(h, "k_level_hist_side");
 			hipLaunchKernelGGL(k_level_hist_side<SCATTER_TILE>, dim3((unsigned)ntiles), dim3(256), 0, h->stream, d_side, S, d_seg, d_tile, db, d_hist);
 			PTRY(hipGetLastError());
-		} else if (level > 0 || ext) {  // level 0's histogram came out of k_superkmers
+		} else if (level > 0) {  // level 0's histogram is in place
 			PTRY(hipMemsetAsync(d_hist, 0, nout * sizeof(unsigned long long), h->stream));
 			ProfScope ps(h, "k_level_hist");
 			hipLaunchKernelGGL(k_level_hist<W>, dim3((unsigned)ntiles), dim3(256), 0, h->stream, level_in, m, S, d_seg, d_tile, shift, db, d_hist);
@@ -1643,10 +1735,14 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	// 3. aggregate per bucket into the log, one entry per distinct k-mer.  A quarter of the occurrences is a
 	// deterministic size (the pool reuses the block) that only inputs of little redundancy (coverage below 4, or
 	// errors in most reads) exceed; for them the aggregation is run again with a larger log.
+	// Sub-passes by whole records only help while a bucket holds several minimizers: beyond 2^24 buckets a bucket of a 100-Mbp
+	// genome is one minimizer and its error variants, and halving by records until that shows costs more than it saves
+	// (C2 with 1 % errors: k_aggregate_retry 29 ms with hash levels from the start, 55 ms behind 8 record levels)
+	const uint32_t agg_rbits = (!nested && bits < 24) ? (uint32_t)(24 - bits) : 0u;
 	const unsigned agg_grid = agg.grid_for_buckets(NBUCK, n_cu);
 	const uint64_t log_slack = agg.slack(agg_grid);
 	uint64_t log_cap = std::min<uint64_t>(occ_bound, std::max<uint64_t>(occ_bound / 4, 1ull << 20)) + log_slack;
-	if (h->dbg & 64) log_cap = LOG_CHUNK;  // tests: the first attempt overflows
+	if ((h->dbg & 64) && !nested) log_cap = LOG_CHUNK;  // tests: the first attempt overflows
 	uint32_t *d_retry = nullptr;
 	if (pool_alloc(dev, (void **)&d_retry, NBUCK * sizeof(uint32_t)) != hipSuccess) {
 		(void)hipGetLastError();
@@ -1657,7 +1753,7 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	const uint32_t flag_unique = (h->cfg.size == 1 || ext) ? 1u : 0u;
 	for (int attempt = 0;; ++attempt) {
 		const bool force_probe = (h->dbg & 0x40000) != 0;
-		const bool will_probe = attempt == 0 && !(h->dbg & 64) && (NBUCK >= (1u << 16) || force_probe);
+		const bool will_probe = !nested && attempt == 0 && !(h->dbg & 64) && (NBUCK >= (1u << 16) || force_probe);
 		const uint32_t P = force_probe ? std::max<uint32_t>((uint32_t)NBUCK / 4, 1u) : (uint32_t)NBUCK / 256;
 		// the sample runs on a small log of its own (one entry per occurrence of its share would always do; 1.5 x the average
 		// share + the chunks left open is what it gets), the real log is allocated once its size is known
@@ -1678,12 +1774,12 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 			bool fine = hipMemsetAsync(h->d_counters + PC_LOG_CURSOR, 0, 6 * sizeof(unsigned long long), h->stream) == hipSuccess;
 			if (fine) {
 				ProfScope ps(h, "k_aggregate_probe");
-				agg.fast(h, agg.grid_for_buckets(P, n_cu), level_in, d_begin, P, k, log, alloc_cap, flag_unique, d_retry, m, (uint32_t)(24 - bits));
+				agg.fast(h, agg.grid_for_buckets(P, n_cu), level_in, d_begin, P, k, log, alloc_cap, flag_unique, d_retry, m, agg_rbits);
 				fine = hipGetLastError() == hipSuccess && sync_counters(h) == RG_OK;
 				const uint64_t n_retry = fine ? h->h_counters[PC_AGG_RETRY] : 0;
 				mostly_overflowing = fine && 2 * n_retry > P;
 				if (fine && n_retry && !h->h_counters[PC_LOG_OVF] && h->h_counters[PC_LOG_CURSOR] + n_retry * agg.key_limit() <= alloc_cap) {
-					agg.slow(h, agg.grid_for_buckets(n_retry, n_cu), level_in, d_begin, (uint32_t)n_retry, k, log, alloc_cap, flag_unique, d_retry, m, (uint32_t)(24 - bits));
+					agg.slow(h, agg.grid_for_buckets(n_retry, n_cu), level_in, d_begin, (uint32_t)n_retry, k, log, alloc_cap, flag_unique, d_retry, m, agg_rbits);
 					fine = hipGetLastError() == hipSuccess && sync_counters(h) == RG_OK;
 				} else if (n_retry) {
 					fine = false;  // the sample alone does not fit: the attempt below finds out and the log doubles
@@ -1715,11 +1811,11 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 			// an attempt at whole buckets would be thrown away for most of them (C2 with 1 % errors: 47 ms): every bucket goes
 			// through the splitting kernel at once
 			ProfScope ps(h, "k_aggregate_split");
-			agg.slow(h, agg_grid, level_in, d_begin, (uint32_t)NBUCK, k, log, log_cap, flag_unique, (const uint32_t *)nullptr, m, (uint32_t)(24 - bits));
+			agg.slow(h, agg_grid, level_in, d_begin, (uint32_t)NBUCK, k, log, log_cap, flag_unique, (const uint32_t *)nullptr, m, agg_rbits);
 			e0 = hipGetLastError();
 		} else if (e0 == hipSuccess) {
 			ProfScope ps(h, "k_aggregate");
-			agg.fast(h, agg_grid, level_in, d_begin, (uint32_t)NBUCK, k, log, log_cap, flag_unique, d_retry, m, (uint32_t)(24 - bits));
+			agg.fast(h, agg_grid, level_in, d_begin, (uint32_t)NBUCK, k, log, log_cap, flag_unique, d_retry, m, agg_rbits);
 			e0 = hipGetLastError();
 		}
 		if (e0 == hipSuccess) {
@@ -1729,7 +1825,7 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 			if (!rc && n_retry && h->h_counters[PC_LOG_CURSOR] + n_retry * agg.key_limit() > log_cap) too_small = true;
 			if (n_retry && !too_small && !h->h_counters[PC_LOG_OVF]) {  // the buckets whose k-mers did not fit the LDS table: split further
 				ProfScope ps(h, "k_aggregate_retry");
-				agg.slow(h, agg.grid_for_buckets(n_retry, n_cu), level_in, d_begin, (uint32_t)n_retry, k, log, log_cap, flag_unique, d_retry, m, (uint32_t)(24 - bits));
+				agg.slow(h, agg.grid_for_buckets(n_retry, n_cu), level_in, d_begin, (uint32_t)n_retry, k, log, log_cap, flag_unique, d_retry, m, agg_rbits);
 			}
 		}
 		hipError_t e = (e0 != hipSuccess) ? e0 : hipGetLastError();
@@ -1763,6 +1859,7 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	*out_log = log;
 	*out_n = h->h_counters[PC_LOG_CURSOR];
 	*ok = true;
+	if (nested) return RG_OK;  // the caller reads PC_LOG_KEYS
 	h->log_all_unique = flag_unique && h->h_counters[PC_NONUNIQUE] == 0 && h->h_counters[PC_LDS_SPILL] == 0;
 	h->log_keys = h->h_counters[PC_LOG_KEYS];
 	h->stats.superkmer_records = valid;
@@ -2275,7 +2372,18 @@ static int bloom_xor(rg_handle *h, Table &T, uint64_t m_bits, uint64_t keys, boo
 		K.low[i] = (uint32_t)(MAGIC[i] & ((1ull << R) - 1ull));
 	}
 	XTRY(hipMemsetAsync(h->d_counters + C_SETBITS, 0, sizeof(unsigned long long), h->stream));
-	{
+	// sparse filters (a stream of a region fits the workgroup with room to spare): the pipelined kernel
+	bool distinct_bits = true;  // no two hashes of a key can name the same bit
+	for (int i = 0; i < 8; ++i)
+		for (int j = i + 1; j < 8; ++j)
+			if ((MAGIC[i] & m_mask) == (MAGIC[j] & m_mask)) distinct_bits = false;
+	const bool sparse = rmax == 14 && keys / P <= 512 && !getenv("RG_XOR_DENSE");
+	if (sparse) {
+		ProfScope ps(h, "k_xor_region");
+		hipLaunchKernelGGL((k_xor_region_sparse<14, 1024>), dim3((unsigned)std::min<uint64_t>(P, (uint64_t)n_cu)), dim3(1024), 0, h->stream, pk, d_begin, (uint32_t)P, R, K, planes,
+		                   plane_words, h->d_counters, (int)C_SETBITS, distinct_bits ? 1 : 0);
+		XTRY(hipGetLastError());
+	} else {
 		ProfScope ps(h, "k_xor_region");
 		if (rmax == 14)
 			hipLaunchKernelGGL((k_xor_region<14, 1024>), dim3((unsigned)std::min<uint64_t>(P, (uint64_t)n_cu)), dim3(1024), 0, h->stream, pk, d_begin, (uint32_t)P, R, K, planes, plane_words, h->d_counters, (int)C_SETBITS);
@@ -2559,6 +2667,28 @@ static int build_table_ranges(rg_handle *h, const Slot *log, uint64_t n_log, uin
 	return RG_OK;
 }
 
+// a temporary pool block that goes back to the pool however the scope is left (HIP_TRY returns early)
+struct PoolBlock {
+	int dev;
+	void *p = nullptr;
+	explicit PoolBlock(int d) : dev(d) {}
+	PoolBlock(const PoolBlock &) = delete;
+	PoolBlock &operator=(const PoolBlock &) = delete;
+	~PoolBlock() {
+		if (p) pool_free(dev, p);
+	}
+	hipError_t alloc(size_t bytes) { return pool_alloc(dev, &p, bytes); }
+	void *release() {
+		void *q = p;
+		p = nullptr;
+		return q;
+	}
+	template <class T>
+	T *as() const {
+		return (T *)p;
+	}
+};
+
 extern "C" {
 
 const char *rg_version(void) { return "raygraph-mi355x 0.1 (gfx950)"; }
@@ -2651,18 +2781,18 @@ int rg_add_reads(rg_handle *h, const uint8_t *packed, uint64_t packed_bytes, con
 	HIP_TRY(h, hipSetDevice(h->cfg.device));
 	ReadBatch b;
 	uint64_t padded = ((packed_bytes + 7) / 8) * 8 + 16;
-	void *dp = nullptr, *dof = nullptr, *dl = nullptr;
-	HIP_TRY(h, pool_alloc(h->cfg.device, &dp, padded));
-	HIP_TRY(h, pool_alloc(h->cfg.device, &dof, n_reads * sizeof(uint64_t)));
-	HIP_TRY(h, pool_alloc(h->cfg.device, &dl, n_reads * sizeof(uint32_t)));
-	HIP_TRY(h, hipMemsetAsync((uint8_t *)dp + (padded - 24), 0, 24, h->stream));
-	HIP_TRY(h, hipMemcpyAsync(dp, packed, packed_bytes, hipMemcpyHostToDevice, h->stream));
-	HIP_TRY(h, hipMemcpyAsync(dof, byte_offsets, n_reads * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
-	HIP_TRY(h, hipMemcpyAsync(dl, lengths, n_reads * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+	PoolBlock gp(h->cfg.device), gof(h->cfg.device), gl(h->cfg.device);
+	HIP_TRY(h, gp.alloc(padded));
+	HIP_TRY(h, gof.alloc(n_reads * sizeof(uint64_t)));
+	HIP_TRY(h, gl.alloc(n_reads * sizeof(uint32_t)));
+	HIP_TRY(h, hipMemsetAsync(gp.as<uint8_t>() + (padded - 24), 0, 24, h->stream));
+	HIP_TRY(h, hipMemcpyAsync(gp.p, packed, packed_bytes, hipMemcpyHostToDevice, h->stream));
+	HIP_TRY(h, hipMemcpyAsync(gof.p, byte_offsets, n_reads * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
+	HIP_TRY(h, hipMemcpyAsync(gl.p, lengths, n_reads * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
 	HIP_TRY(h, hipStreamSynchronize(h->stream));
-	b.d_packed = (const uint64_t *)dp;
-	b.d_off = (const uint64_t *)dof;
-	b.d_len = (const uint32_t *)dl;
+	b.d_packed = (const uint64_t *)gp.release();  // the handle owns them from here (rg_destroy frees owned batches)
+	b.d_off = (const uint64_t *)gof.release();
+	b.d_len = (const uint32_t *)gl.release();
 	b.n = n_reads;
 	b.first_id = h->cfg.first_read_id + h->n_reads;
 	b.maxlen = maxlen;
@@ -3286,11 +3416,13 @@ int rg_export(rg_handle *h, void *host_buf, uint64_t cap_records, uint64_t *n_re
 	uint64_t nchunks = std::min<uint64_t>(2048, (cap + BLOCK - 1) / BLOCK);
 	uint64_t chunk = (cap + nchunks - 1) / nchunks;
 	nchunks = (cap + chunk - 1) / chunk;
-	unsigned long long *d_chunk = nullptr;
-	uint8_t *d_out = nullptr;
-	HIP_TRY(h, pool_alloc(h->cfg.device, (void **)&d_chunk, nchunks * sizeof(unsigned long long)));
-	HIP_TRY(h, pool_alloc(h->cfg.device, (void **)&d_out, n * rec));
+	PoolBlock g_chunk(h->cfg.device), g_out(h->cfg.device);
+	HIP_TRY(h, g_chunk.alloc(nchunks * sizeof(unsigned long long)));
+	HIP_TRY(h, g_out.alloc(n * rec));
+	unsigned long long *d_chunk = g_chunk.as<unsigned long long>();
+	uint8_t *d_out = g_out.as<uint8_t>();
 	hipLaunchKernelGGL(k_export_count, dim3((int)nchunks), dim3(BLOCK), 0, h->stream, h->tab.slots, cap, chunk, d_chunk);
+	HIP_TRY(h, hipGetLastError());
 	std::vector<unsigned long long> hc(nchunks);
 	HIP_TRY(h, hipMemcpyAsync(hc.data(), d_chunk, nchunks * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
 	HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -3300,19 +3432,13 @@ int rg_export(rg_handle *h, void *host_buf, uint64_t cap_records, uint64_t *n_re
 		c = run;
 		run += t;
 	}
-	if (run != n) {
-		pool_free(h->cfg.device, d_chunk);
-		pool_free(h->cfg.device, d_out);
-		return fail(h, RG_ERR_STATE, "export found %llu stored pairs, expected %llu", run, (unsigned long long)n);
-	}
+	if (run != n) return fail(h, RG_ERR_STATE, "export found %llu stored pairs, expected %llu", run, (unsigned long long)n);
 	HIP_TRY(h, hipMemcpyAsync(d_chunk, hc.data(), nchunks * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
 	if (h->W == 1) hipLaunchKernelGGL(k_export_write<1>, dim3((int)nchunks), dim3(BLOCK), 0, h->stream, h->tab.slots, cap, chunk, d_chunk, d_out, h->phase >= PH_EDGES ? 0xFFu : 0u);
 	else hipLaunchKernelGGL(k_export_write<2>, dim3((int)nchunks), dim3(BLOCK), 0, h->stream, h->tab.slots, cap, chunk, d_chunk, d_out, h->phase >= PH_EDGES ? 0xFFu : 0u);
 	hipError_t e = hipGetLastError();
 	if (e == hipSuccess) e = hipMemcpyAsync(host_buf, d_out, n * rec, hipMemcpyDeviceToHost, h->stream);
 	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-	pool_free(h->cfg.device, d_chunk);
-	pool_free(h->cfg.device, d_out);
 	if (e != hipSuccess) return fail(h, RG_ERR_HIP, "export failed: %s", hipGetErrorString(e));
 	return RG_OK;
 }
@@ -3323,12 +3449,13 @@ int rg_find(rg_handle *h, const uint64_t *kmers, uint64_t n, uint32_t *coverage,
 	if (n == 0) return RG_OK;
 	if (!kmers || !coverage || !edges) return fail(h, RG_ERR_ARG, "null argument");
 	HIP_TRY(h, hipSetDevice(h->cfg.device));
-	uint64_t *dq = nullptr;
-	uint32_t *dc = nullptr;
-	uint8_t *de = nullptr;
-	HIP_TRY(h, pool_alloc(h->cfg.device, (void **)&dq, n * h->W * sizeof(uint64_t)));
-	HIP_TRY(h, pool_alloc(h->cfg.device, (void **)&dc, n * sizeof(uint32_t)));
-	HIP_TRY(h, pool_alloc(h->cfg.device, (void **)&de, n));
+	PoolBlock gq(h->cfg.device), gc(h->cfg.device), ge(h->cfg.device);
+	HIP_TRY(h, gq.alloc(n * h->W * sizeof(uint64_t)));
+	HIP_TRY(h, gc.alloc(n * sizeof(uint32_t)));
+	HIP_TRY(h, ge.alloc(n));
+	uint64_t *dq = gq.as<uint64_t>();
+	uint32_t *dc = gc.as<uint32_t>();
+	uint8_t *de = ge.as<uint8_t>();
 	hipError_t e = hipMemcpyAsync(dq, kmers, n * h->W * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream);
 	if (e == hipSuccess) {
 		if (h->W == 1) hipLaunchKernelGGL(k_find<1>, dim3(grid_for(n)), dim3(BLOCK), 0, h->stream, h->tab.slots, h->tab.cap, h->cfg.k, dq, n, dc, de, h->phase >= PH_EDGES ? 0xFFu : 0u);
@@ -3338,9 +3465,6 @@ int rg_find(rg_handle *h, const uint64_t *kmers, uint64_t n, uint32_t *coverage,
 	if (e == hipSuccess) e = hipMemcpyAsync(coverage, dc, n * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream);
 	if (e == hipSuccess) e = hipMemcpyAsync(edges, de, n, hipMemcpyDeviceToHost, h->stream);
 	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-	pool_free(h->cfg.device, dq);
-	pool_free(h->cfg.device, dc);
-	pool_free(h->cfg.device, de);
 	if (e != hipSuccess) return fail(h, RG_ERR_HIP, "find failed: %s", hipGetErrorString(e));
 	return RG_OK;
 }
@@ -3514,6 +3638,66 @@ int rg_read_markers(rg_handle *h, int32_t *d_forward, int32_t *d_reverse) {
 		done += b.n;
 	}
 	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	return RG_OK;
+}
+
+int rg_hash_kmers(rg_handle *h, const uint64_t *kmers, uint64_t n, uint64_t *hash1_out, uint64_t *hash2_out) {
+	if (!h) return RG_ERR_ARG;
+	if (n == 0) return RG_OK;
+	if (!kmers || !hash1_out || !hash2_out) return fail(h, RG_ERR_ARG, "null argument");
+	if (n > (1ull << 24)) return fail(h, RG_ERR_CAPACITY, "rg_hash_kmers takes at most 2^24 k-mers per call");
+	HIP_TRY(h, hipSetDevice(h->cfg.device));
+	PoolBlock gk(h->cfg.device), g1(h->cfg.device), g2(h->cfg.device);
+	HIP_TRY(h, gk.alloc(n * h->W * sizeof(uint64_t)));
+	HIP_TRY(h, g1.alloc(n * sizeof(uint64_t)));
+	HIP_TRY(h, g2.alloc(n * sizeof(uint64_t)));
+	HIP_TRY(h, hipMemcpyAsync(gk.p, kmers, n * h->W * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
+	const unsigned grid = (unsigned)((n + BLOCK - 1) / BLOCK);
+	if (h->W == 1) hipLaunchKernelGGL(k_hash_kmers<1>, dim3(grid), dim3(BLOCK), 0, h->stream, gk.as<uint64_t>(), n, g1.as<uint64_t>(), g2.as<uint64_t>());
+	else hipLaunchKernelGGL(k_hash_kmers<2>, dim3(grid), dim3(BLOCK), 0, h->stream, gk.as<uint64_t>(), n, g1.as<uint64_t>(), g2.as<uint64_t>());
+	HIP_TRY(h, hipGetLastError());
+	HIP_TRY(h, hipMemcpyAsync(hash1_out, g1.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+	HIP_TRY(h, hipMemcpyAsync(hash2_out, g2.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	return RG_OK;
+}
+
+int rg_check_hashes(rg_handle *h, rg_hash_fn hash1_fn, rg_hash_fn hash2_fn, void *user, uint32_t n_samples) {
+	if (!h) return RG_ERR_ARG;
+	if (!hash1_fn || !hash2_fn) return fail(h, RG_ERR_ARG, "rg_check_hashes needs Ray's two hash functions");
+	const uint64_t n = std::min<uint64_t>(std::max<uint32_t>(n_samples, 16), 1u << 20);
+	const int W = h->W, k = h->cfg.k;
+	// sample k-mers: the corners (all A, all T, alternating) and a splitmix64 stream, cut to 2k bits
+	const uint64_t mask0 = (2 * k >= 64) ? ~0ull : ((1ull << (2 * k)) - 1);
+	const uint64_t mask1 = (k > 32) ? ((2 * k - 64 >= 64) ? ~0ull : ((1ull << (2 * k - 64)) - 1)) : 0ull;
+	std::vector<uint64_t> keys(n * W), d1(n), d2(n);
+	uint64_t x = 0x243F6A8885A308D3ull + (uint64_t)k;
+	auto next = [&x]() {
+		uint64_t z = (x += 0x9E3779B97F4A7C15ull);
+		z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+		z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+		return z ^ (z >> 31);
+	};
+	for (uint64_t i = 0; i < n; ++i) {
+		uint64_t a = next(), b = next();
+		if (i == 0) a = b = 0;
+		if (i == 1) a = b = ~0ull;
+		if (i == 2) a = b = 0x24e4e4e4e4e4e4e4ull;
+		if (i == 3) a = b = 1;
+		keys[i * W] = a & mask0;
+		if (W == 2) keys[i * W + 1] = b & mask1;
+	}
+	int rc = rg_hash_kmers(h, keys.data(), n, d1.data(), d2.data());
+	if (rc != RG_OK) return rc;
+	for (uint64_t i = 0; i < n; ++i) {
+		const uint64_t r1 = hash1_fn(&keys[i * W], user), r2 = hash2_fn(&keys[i * W], user);
+		if (r1 != d1[i] || r2 != d2[i])
+			return fail(h, RG_ERR_HASH,
+			            "hash mismatch on k-mer words %016llx %016llx (k=%d): caller's hash_function_%d gives %016llx, the GPU path %016llx -- "
+			            "owners (vertexRank) and Bloom bits would differ from Ray's",
+			            (unsigned long long)keys[i * W], (unsigned long long)(W == 2 ? keys[i * W + 1] : 0), k, r1 != d1[i] ? 1 : 2,
+			            (unsigned long long)(r1 != d1[i] ? r1 : r2), (unsigned long long)(r1 != d1[i] ? d1[i] : d2[i]));
+	}
 	return RG_OK;
 }
 

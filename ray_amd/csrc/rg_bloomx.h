@@ -310,6 +310,129 @@ __global__ __launch_bounds__(THREADS) void k_xor_region(const unsigned long long
 	if (threadIdx.x == 0 && s_setbits) atomicAdd(&counters[c_setbits], (unsigned long long)s_setbits);
 }
 
+// Workgroup barrier for data that travels through LDS only (see rg_partition.h: __syncthreads() would also wait for the
+// global loads that are in flight for the next region)
+__device__ __forceinline__ void xor_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// k_xor_region for sparse filters: regions whose eight streams hold at most THREADS keys each (one item per stream and thread).
+// A region is a chain of two dependent loads (the bounds of its eight partitions, then their items) in front of a few LDS
+// operations; with one workgroup per CU nothing hid them (C2 error-free: 14 ms for 6.4 GB whatever the region size).  Here the
+// chain is software-pipelined over the workgroup's regions: while region r is resolved in LDS, the items of region r + G are
+// on their way and so are the bounds of region r + 2G (G = the grid).  The bounds are loaded by lanes (lane i & 7 fetches stream
+// i's) and handed round with readlane, so that they are vector loads like the items: nothing here waits on the scalar cache
+// behind the LDS barriers.  count_winners: the filter's set bits are counted as the winners (one per set bit when the eight
+// hashes of a key cannot share a bit, which the host checks), not by a sweep over the cells.
+template <int RMAX, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_xor_region_sparse(const unsigned long long *__restrict__ pk, const unsigned long long *__restrict__ part_begin,
+                                                               uint32_t P, int R, XorConsts K, unsigned long long *__restrict__ planes, uint64_t plane_words,
+                                                               unsigned long long *__restrict__ counters, int c_setbits, int count_winners) {
+	__shared__ unsigned long long s_cell[1u << RMAX];
+	__shared__ uint32_t s_setbits;
+	const uint32_t ncell = 1u << R, cmask = ncell - 1;
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t G = gridDim.x;
+	uint32_t set_total = 0;
+	if (threadIdx.x == 0) s_setbits = 0;
+	uint32_t my_c = K.c[0];  // the stream whose bounds this lane fetches
+#pragma unroll
+	for (int i = 1; i < 8; ++i)
+		if ((lane & 7u) == (uint32_t)i) my_c = K.c[i];
+	// bounds as fetched (per lane), and handed round (uniform)
+	auto fetch_bounds = [&](uint32_t r, unsigned long long &b0, unsigned long long &b1) {
+		const uint32_t q = (r < P ? r : 0u) ^ my_c;
+		b0 = part_begin[q];
+		b1 = part_begin[q + 1];
+	};
+	auto spread = [&](unsigned long long b0, unsigned long long b1, unsigned long long (&sb)[8], uint32_t (&len)[8]) -> bool {
+		bool fits = true;
+#pragma unroll
+		for (int i = 0; i < 8; ++i) {
+			const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b0, i), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b0 >> 32), i);
+			const uint32_t elo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b1, i), ehi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b1 >> 32), i);
+			sb[i] = ((unsigned long long)hi << 32) | lo;
+			len[i] = (uint32_t)((((unsigned long long)ehi << 32) | elo) - sb[i]);
+			fits = fits && len[i] <= (uint32_t)THREADS;
+		}
+		return fits;
+	};
+	uint32_t r = blockIdx.x;
+	unsigned long long sbA[8], itA[8];
+	uint32_t lenA[8];
+	unsigned long long nb0 = 0, nb1 = 0;  // raw bounds of region r + G
+	bool fitsA = false;
+	{
+		unsigned long long b0, b1;
+		fetch_bounds(r, b0, b1);
+		fitsA = spread(b0, b1, sbA, lenA);
+#pragma unroll
+		for (int i = 0; i < 8; ++i) itA[i] = (fitsA && r < P && threadIdx.x < lenA[i]) ? pk[sbA[i] + threadIdx.x] : XOR_PAD;
+		fetch_bounds(r + G, nb0, nb1);
+	}
+	for (; r < P; r += G) {
+		// the next region's items, the bounds of the one after
+		unsigned long long sbB[8], itB[8];
+		uint32_t lenB[8];
+		const bool haveB = r + G < P;
+		const bool fitsB = spread(nb0, nb1, sbB, lenB) && haveB;
+#pragma unroll
+		for (int i = 0; i < 8; ++i) itB[i] = (fitsB && threadIdx.x < lenB[i]) ? pk[sbB[i] + threadIdx.x] : XOR_PAD;
+		fetch_bounds(r + 2 * G, nb0, nb1);
+
+		for (uint32_t i = threadIdx.x; i < ncell; i += THREADS) s_cell[i] = INF_STAMP;
+		xor_lds_barrier();
+		if (fitsA) {
+#pragma unroll
+			for (int i = 0; i < 8; ++i)
+				if (itA[i] != XOR_PAD) atomicMin(&s_cell[((uint32_t)itA[i] ^ K.low[i]) & cmask], itA[i] >> 14);
+			xor_lds_barrier();
+#pragma unroll
+			for (int i = 0; i < 8; ++i) {
+				if (threadIdx.x - lane < lenA[i]) {  // wave-uniform: every stream is a whole number of wavefronts long
+					const bool win = itA[i] != XOR_PAD && s_cell[((uint32_t)itA[i] ^ K.low[i]) & cmask] == (itA[i] >> 14);
+					const unsigned long long bal = __ballot(win);
+					if (lane == 0) {
+						planes[(uint64_t)i * plane_words + ((sbA[i] + threadIdx.x) >> 6)] = bal;
+						if (count_winners) set_total += (uint32_t)__popcll(bal);
+					}
+				}
+			}
+		} else {
+			// a region with a stream longer than the workgroup: read twice
+#pragma unroll 1
+			for (int i = 0; i < 8; ++i)
+				for (uint32_t t = threadIdx.x; t < lenA[i]; t += THREADS) {
+					const unsigned long long it = pk[sbA[i] + t];
+					if (it != XOR_PAD) atomicMin(&s_cell[((uint32_t)it ^ K.low[i]) & cmask], it >> 14);
+				}
+			xor_lds_barrier();
+#pragma unroll 1
+			for (int i = 0; i < 8; ++i)
+				for (uint32_t t = threadIdx.x; t < lenA[i]; t += THREADS) {
+					const unsigned long long it = pk[sbA[i] + t];
+					const bool win = it != XOR_PAD && s_cell[((uint32_t)it ^ K.low[i]) & cmask] == (it >> 14);
+					const unsigned long long bal = __ballot(win);
+					if (lane == 0) {
+						planes[(uint64_t)i * plane_words + ((sbA[i] + t) >> 6)] = bal;
+						if (count_winners) set_total += (uint32_t)__popcll(bal);
+					}
+				}
+		}
+		if (!count_winners)
+			for (uint32_t i = threadIdx.x; i < ncell; i += THREADS) set_total += (s_cell[i] != INF_STAMP) ? 1u : 0u;
+		xor_lds_barrier();
+		fitsA = fitsB;
+#pragma unroll
+		for (int i = 0; i < 8; ++i) {
+			sbA[i] = sbB[i];
+			lenA[i] = lenB[i];
+			itA[i] = itB[i];
+		}
+	}
+	if (set_total) atomicAdd(&s_setbits, set_total);
+	__syncthreads();
+	if (threadIdx.x == 0 && s_setbits) atomicAdd(&counters[c_setbits], (unsigned long long)s_setbits);
+}
+
 // a key that won none of its eight bits is a false positive: its byte of `lost` becomes 8 (what k_admit_lost tests)
 __global__ __launch_bounds__(256) void k_xor_fp(const unsigned long long *__restrict__ pk, const uint32_t *__restrict__ ix,
                                                 const unsigned long long *__restrict__ planes, uint64_t plane_words, uint64_t npos,

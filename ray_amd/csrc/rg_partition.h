@@ -53,7 +53,10 @@ __host__ __device__ inline uint32_t fmix32(uint32_t h) {  // murmur3 finalizer: 
 }
 // bucket of a canonical minimizer; a different mix than the one that orders minimizers, whose small
 // values are exactly the ones that get picked
-__host__ __device__ inline uint32_t bucket24(uint32_t canon) { return fmix32(canon * 0x2545F491u + 0x68E31DA4u) >> 8; }
+// 32 bits: the partition levels take the top bits (up to MAX_BUCKET_BITS of them), what is left below splits a bucket whose
+// k-mers overflow the aggregation table by whole records (k_aggregate<SLOW>)
+static constexpr int BUCKET_TOP = 32;
+__host__ __device__ inline uint32_t bucket_number(uint32_t canon) { return fmix32(canon * 0x2545F491u + 0x68E31DA4u); }
 
 __host__ __device__ inline int lmax_for(int W, int k) {
 	int l = 64 * W - k - 1;
@@ -107,10 +110,24 @@ __device__ __forceinline__ uint32_t rec_bucket(const Rec<W> &r, int m) {
 	for (int i = 0; i < 2 * W; ++i) b[i] = r.w[i];
 	uint32_t moff = (uint32_t)(r.w[2 * W] >> 24) & 127u;
 	uint64_t f = rec_ext<W>(b, moff) & ((1ull << (2 * m)) - 1);
-	return bucket24(canon_mmer(f, m));
+	return bucket_number(canon_mmer(f, m));
 }
 
-enum PartCounter { PC_REC_CURSOR = 16, PC_REC_OVF, PC_LOG_CURSOR, PC_LOG_OVF, PC_LDS_SPILL, PC_AGG_RETRY, PC_NONUNIQUE, PC_LOG_KEYS };
+enum PartCounter { PC_REC_CURSOR = 16, PC_REC_OVF, PC_LOG_CURSOR, PC_LOG_OVF, PC_LDS_SPILL, PC_AGG_RETRY, PC_NONUNIQUE, PC_LOG_KEYS, PC_SAMPLE };
+
+// The sample of the records that sizes the partition: the records whose bucket number has its top SAMPLE_BITS bits clear,
+// i.e. the first 2^(b - SAMPLE_BITS) buckets of a partition into 2^b, whole (the bucket number is a hash: 1 / 4096 of the
+// input, whatever it is).  The kernels that see every record anyway copy them aside (sample != nullptr); the host counts the
+// distinct k-mers in them with a small sweep of its own and picks the number of buckets from that.
+static constexpr int SAMPLE_BITS = 12;
+template <int W>
+__device__ __forceinline__ void sample_record(const Rec<W> &rec, uint32_t bucket, Rec<W> *__restrict__ sample, uint64_t sample_cap,
+                                              unsigned long long *__restrict__ counters) {
+	if (sample && (bucket >> (BUCKET_TOP - SAMPLE_BITS)) == 0) {
+		const unsigned long long pos = atomicAdd(&counters[PC_SAMPLE], 1ull);
+		if (pos < sample_cap) sample[pos] = rec;
+	}
+}
 
 // ------------------------------------------------------------------------------------------------
 // reads -> super-k-mer records.  A wavefront takes 64 consecutive reads at a time (their lengths and
@@ -142,7 +159,8 @@ __global__ __launch_bounds__(256) void k_superkmers(const uint64_t *__restrict__
                                                     const uint32_t *__restrict__ lengths, uint64_t nreads, uint64_t read_id_base,
                                                     int k, int m, Rec<W> *__restrict__ recs, uint64_t rec_cap,
                                                     unsigned long long *__restrict__ counters,
-                                                    unsigned long long *__restrict__ coarse_hist, uint32_t modulo, uint32_t hist_shift) {
+                                                    unsigned long long *__restrict__ coarse_hist, uint32_t modulo, uint32_t hist_shift,
+                                                    Rec<W> *__restrict__ sample, uint64_t sample_cap) {
 	// coarse_hist[256]: records per first-level digit (bucket >> hist_shift, at most 8 bits), or, with modulo != 0, per
 	// destination rank bucket % modulo (record exchange between ranks, modulo <= 256)
 	constexpr int NB = 2 * W;
@@ -320,8 +338,9 @@ __global__ __launch_bounds__(256) void k_superkmers(const uint64_t *__restrict__
 							rec.w[NB] = (uint64_t)p | ((uint64_t)(len - 1) << 16) | ((uint64_t)hasL << 22) | ((uint64_t)hasR << 23) |
 							            ((uint64_t)moff << 24) | rid;
 							recs[chunk_base + chunk_used + idx] = rec;
-							const uint32_t bk = bucket24(cn[jm]);
+							const uint32_t bk = bucket_number(cn[jm]);
 							atomicAdd(&s_hist[modulo ? bk % modulo : bk >> hist_shift], 1u);
+							sample_record<W>(rec, bk, sample, sample_cap, counters);
 						}
 					}
 				chunk_used += c;
@@ -370,7 +389,8 @@ __global__ __launch_bounds__(256) void k_superkmers_lanes(const uint64_t *__rest
                                                           const uint32_t *__restrict__ lengths, uint64_t nreads, uint64_t read_id_base,
                                                           int k, int m, Rec<W> *__restrict__ recs, uint64_t rec_cap,
                                                           unsigned long long *__restrict__ counters,
-                                                          unsigned long long *__restrict__ coarse_hist, uint32_t modulo, uint32_t hist_shift) {
+                                                          unsigned long long *__restrict__ coarse_hist, uint32_t modulo, uint32_t hist_shift,
+                                                          Rec<W> *__restrict__ sample, uint64_t sample_cap) {
 	constexpr int NB = 2 * W;
 	extern __shared__ unsigned long long s_win_all[];  // [4 wavefronts][w entries][64 lanes]
 	__shared__ unsigned long long s_q[4][SKL_RING];
@@ -553,8 +573,9 @@ __global__ __launch_bounds__(256) void k_superkmers_lanes(const uint64_t *__rest
 						rec.w[NB] = (uint64_t)pr | ((uint64_t)(len - 1) << 16) | ((uint64_t)hasL << 22) | ((uint64_t)hasR << 23) |
 						            ((uint64_t)moff << 24) | ((read_id_base + rb + src) << 31);
 						recs[chunk_base + chunk_used + lane] = rec;
-						const uint32_t bk = bucket24(order_unmix((uint32_t)(d >> 32)));
+						const uint32_t bk = bucket_number(order_unmix((uint32_t)(d >> 32)));
 						atomicAdd(&s_hist[modulo ? bk % modulo : bk >> hist_shift], 1u);
+						sample_record<W>(rec, bk, sample, sample_cap, counters);
 					}
 					chunk_used += cnt;
 					qhead += cnt;
@@ -576,7 +597,7 @@ __global__ __launch_bounds__(256) void k_superkmers_lanes(const uint64_t *__rest
 // ------------------------------------------------------------------------------------------------
 // One partition level.  The input is cut into S segments (seg_begin[S+1]; level 1: the single segment
 // [0, n_in) of k_superkmers output, holes included).  A tile of SCATTER_TILE records never crosses a
-// segment (tile_first[s] = first tile of segment s).  digit = (bucket24 >> shift) & (2^dbits - 1);
+// segment (tile_first[s] = first tile of segment s).  digit = (bucket number >> shift) & (2^dbits - 1);
 // the records of segment s with digit d go to the range that starts at cursors[(s << dbits) + d].
 // 2560 records of 24 bytes + digits = 72 KB: still two workgroups per CU, runs a quarter longer than with 2048 (k_scatter x3
 // 21.9-23.1 -> 21.0-22.3 ms on C2, same box; 3072 would leave one workgroup per CU)
@@ -713,7 +734,8 @@ template <int W>
 __global__ __launch_bounds__(256) void k_level_hist(const Rec<W> *__restrict__ in, int m, uint32_t S,
                                                     const unsigned long long *__restrict__ seg_begin,
                                                     const uint32_t *__restrict__ tile_first, int shift, int dbits,
-                                                    unsigned long long *__restrict__ hist) {
+                                                    unsigned long long *__restrict__ hist, Rec<W> *__restrict__ sample = nullptr,
+                                                    uint64_t sample_cap = 0, unsigned long long *__restrict__ counters = nullptr) {
 	__shared__ uint32_t s_cnt[256];
 	const uint32_t seg = find_segment(tile_first, S, blockIdx.x);
 	const uint64_t begin = seg_begin[seg] + (uint64_t)(blockIdx.x - tile_first[seg]) * SCATTER_TILE;
@@ -723,7 +745,11 @@ __global__ __launch_bounds__(256) void k_level_hist(const Rec<W> *__restrict__ i
 	__syncthreads();
 	for (uint64_t i = begin + threadIdx.x; i < end; i += 256) {
 		Rec<W> r = in[i];
-		if (r.w[2 * W] != REC_INVALID) atomicAdd(&s_cnt[(rec_bucket<W>(r, m) >> shift) & dmask], 1u);
+		if (r.w[2 * W] != REC_INVALID) {
+			const uint32_t bk = rec_bucket<W>(r, m);
+			atomicAdd(&s_cnt[(bk >> shift) & dmask], 1u);
+			sample_record<W>(r, bk, sample, sample_cap, counters);
+		}
 	}
 	__syncthreads();
 	if (threadIdx.x <= dmask && s_cnt[threadIdx.x])
@@ -807,6 +833,7 @@ static constexpr uint32_t AGG_SLOTS = 256;
 // is dropped like an overfull one (only the last-resort mode of partial flushes writes such a k-mer to the log on
 // its own: a k-mer written before the attempt is dropped would be counted again by the retry).
 static constexpr uint32_t AGG_LIMIT = 190;
+static constexpr uint32_t AGG_TARGET = 64;  // distinct k-mers per bucket the partition is sized for from the sample (C2 at 2^22 buckets: 24; the tail must stay below AGG_LIMIT)
 static constexpr uint32_t AGG_FLUSH = 190;
 static constexpr uint32_t RT_SLOTS = 128;
 static constexpr uint32_t RT_FLUSH = RT_SLOTS * 3 / 4 - 64;

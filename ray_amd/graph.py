@@ -267,6 +267,24 @@ class GraphBuilder:
     def purge_apply(self, answers_ptr, n):
         self._check(self._L.rg_purge_apply(self._h, answers_ptr, n))
 
+    # -- the hashes against the caller's (rg_check_hashes / rg_hash_kmers)
+    def check_hashes(self, hash1, hash2, n_samples=4096):
+        """hash1 / hash2: callables taking a tuple of kmer_words uint64 words, returning Ray's hash_function_1 / _2.
+        Raises RayGraphError (RG_ERR_HASH) when the device's hashes differ."""
+        from ._lib import HASH_FN
+        W = self.kmer_words
+        f1 = HASH_FN(lambda words, user: int(hash1(tuple(int(words[j]) for j in range(W)))) & 0xFFFFFFFFFFFFFFFF)
+        f2 = HASH_FN(lambda words, user: int(hash2(tuple(int(words[j]) for j in range(W)))) & 0xFFFFFFFFFFFFFFFF)
+        self._check(self._L.rg_check_hashes(self._h, f1, f2, None, n_samples))
+
+    def hash_kmers(self, kmers):
+        q = np.ascontiguousarray(kmers, dtype=np.uint64).reshape(-1, self.kmer_words)
+        h1 = np.zeros(len(q), dtype=np.uint64)
+        h2 = np.zeros(len(q), dtype=np.uint64)
+        u64p = C.POINTER(C.c_uint64)
+        self._check(self._L.rg_hash_kmers(self._h, q.ctypes.data_as(u64p), len(q), h1.ctypes.data_as(u64p), h2.ctypes.data_as(u64p)))
+        return h1, h2
+
     # -- markers across ranks (exchange.read_markers_distributed drives these)
     def markers_query_counts(self):
         out = (C.c_uint64 * self.size)()
@@ -287,6 +305,12 @@ class GraphBuilder:
         n = C.c_uint64()
         self._check(self._L.rg_size(self._h, C.byref(n)))
         return n.value
+
+    def export_into(self, buf):
+        """rg_export into the caller's record array (record_dtype(kmer_words)); returns the number of records written"""
+        m = C.c_uint64()
+        self._check(self._L.rg_export(self._h, buf.ctypes.data, len(buf), C.byref(m)))
+        return int(m.value)
 
     def export(self, sort=True):
         """stored vertices as a structured array (key, coverage, edges); sorted by key if asked."""

@@ -13,11 +13,37 @@ CONFIGS = {
     "C2_100Mbp_60x_150bp_k31": dict(genome=100_000_000, read_len=150, coverage=60, k=31, error=0.0, seed=2),
     "C3_500Mbp_40x_150bp_k63": dict(genome=500_000_000, read_len=150, coverage=40, k=63, error=0.0, seed=3),
     "C5_3.1Gbp_30x_150bp_k31_1pct": dict(genome=3_100_000_000, read_len=150, coverage=30, k=31, error=0.01, seed=5),
+    # Ray Meta: 200 genomes of 2-6 Mbp, abundance lognormal(0, 1) normalised to a mean coverage of 30x; `genome`
+    # is the nominal total (200 x 4 Mbp), the generated one is the sum of the drawn lengths
+    "C4_meta_200sp_lognormal_30x_150bp_k31": dict(genome=800_000_000, read_len=150, coverage=30, k=31, error=0.0, seed=4,
+                                                   species=200, genome_min=2_000_000, genome_max=6_000_000, sigma=1.0),
 }
 
 
 def n_reads_for(genome, read_len, coverage):
     return int(genome * coverage // read_len)
+
+
+def metagenome_plan(cfg, scale=1.0, species_factor=1):
+    """C4: -> (lengths int64 [S], coverage float64 [S], n_reads).  Species i has a genome of lengths[i] bases (uniform in
+    [genome_min, genome_max] x scale) and is sequenced coverage[i] deep: lognormal(0, sigma) abundances scaled so that their
+    mean is cfg["coverage"].  A read comes from species i with probability ~ coverage[i] * lengths[i]."""
+    rng = np.random.default_rng(cfg["seed"])
+    S = cfg["species"] * species_factor
+    lo = max(cfg["read_len"] + 1, int(cfg["genome_min"] * scale))
+    hi = max(lo + 1, int(cfg["genome_max"] * scale))
+    lengths = rng.integers(lo, hi + 1, size=S, dtype=np.int64)
+    a = rng.lognormal(mean=0.0, sigma=cfg["sigma"], size=S)
+    coverage = cfg["coverage"] * a / a.mean()
+    n_reads = int((coverage * lengths).sum() // cfg["read_len"])
+    return lengths, coverage, n_reads
+
+
+def metagenome_numpy(cfg, scale):
+    """C4 for make_reads_numpy(genomes=...): -> ([(codes, weight)], n_reads)"""
+    lengths, coverage, n_reads = metagenome_plan(cfg, scale)
+    rng = np.random.default_rng(cfg["seed"] + 1000)
+    return [(rng.integers(0, 4, size=int(n), dtype=np.uint8), float(c * n)) for n, c in zip(lengths, coverage)], n_reads
 
 
 def make_reads_numpy(genome, read_len, n_reads, seed, error=0.0, ragged=False, genomes=None):
@@ -69,12 +95,19 @@ def pack_codes(codes, lengths):
     return np.ascontiguousarray(packed), offsets, lengths.astype(np.uint32)
 
 
-def make_reads_torch(genome, read_len, n_reads, seed, error=0.0, device="cuda", chunk=2_000_000, read_seed=None):
+def make_reads_torch(genome, read_len, n_reads, seed, error=0.0, device="cuda", chunk=2_000_000, read_seed=None, species=None):
     """same distribution, generated directly in HBM with torch (plumbing only): fixed-length reads.
+    species: (lengths, coverage) of metagenome_plan -- the genomes lie back to back in one array of sum(lengths) bases and a
+    read starts inside the genome of a species drawn with probability ~ coverage * length.
     -> (packed u8 tensor padded by 32 bytes, offsets u64-as-int64 tensor, lengths int32 tensor)"""
     import torch
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
+    if species is not None:
+        sp_len = torch.as_tensor(species[0], dtype=torch.int64, device=device)
+        sp_off = torch.cumsum(sp_len, 0) - sp_len
+        sp_w = torch.as_tensor(species[1] * species[0], dtype=torch.float64, device=device)
+        genome = int(species[0].sum())
     g = torch.randint(0, 4, (genome,), dtype=torch.uint8, device=device, generator=gen)
     if read_seed is not None:  # same genome on every rank, different reads
         gen.manual_seed(read_seed)
@@ -84,7 +117,13 @@ def make_reads_torch(genome, read_len, n_reads, seed, error=0.0, device="cuda", 
     Lp = bpr * 4
     for c0 in range(0, n_reads, chunk):
         m = min(chunk, n_reads - c0)
-        starts = torch.randint(0, genome - read_len + 1, (m,), device=device, generator=gen, dtype=torch.int64)
+        if species is None:
+            starts = torch.randint(0, genome - read_len + 1, (m,), device=device, generator=gen, dtype=torch.int64)
+        else:
+            which = torch.multinomial(sp_w.float(), m, replacement=True, generator=gen)
+            room = (sp_len[which] - read_len + 1).double()
+            starts = sp_off[which] + (torch.rand(m, device=device, generator=gen, dtype=torch.float64) * room).long()
+            starts = torch.minimum(starts, sp_off[which] + sp_len[which] - read_len)
         codes = g[starts[:, None] + ar[None, :]]
         rev = torch.rand(m, device=device, generator=gen) < 0.5
         codes = torch.where(rev[:, None], 3 - codes.flip(1), codes)

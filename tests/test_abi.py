@@ -106,9 +106,12 @@ def test_header_is_plain_c_and_the_glue_calls_type_check(tmp_path):
 #include <raygraph.h>
 #include <string.h>
 static rg_handle *m_gpuGraph;
+static uint64_t rayHash1(const uint64_t *w, void *user){ (void)user; return w[0]; }   /* stands for Kmer::hash_function_1 */
+static uint64_t rayHash2(const uint64_t *w, void *user){ (void)user; return w[0]; }
 int glue(const uint8_t *packed, uint64_t nbytes, const uint64_t *off, const uint32_t *len, uint64_t n, void *d_buf){
 	rg_config cfg; memset(&cfg,0,sizeof cfg); cfg.k=31; cfg.size=1; cfg.bloom_bits=RG_BLOOM_DEFAULT;
 	if(rg_create(&cfg,&m_gpuGraph)!=RG_OK) return 1;
+	if(rg_check_hashes(m_gpuGraph,rayHash1,rayHash2,NULL,4096)==RG_ERR_HASH) return 3;
 	rg_add_reads(m_gpuGraph,packed,nbytes,off,len,n);
 	if(rg_count_kmers(m_gpuGraph)!=RG_OK) return 2;
 	uint64_t nh=0; rg_histogram(m_gpuGraph,NULL,NULL,0,&nh);
@@ -117,6 +120,8 @@ int glue(const uint8_t *packed, uint64_t nbytes, const uint64_t *off, const uint
 	uint64_t counts[1]; uint32_t rb; rg_records_local_part(m_gpuGraph,0,4); rg_record_counts(m_gpuGraph,counts,&rb);
 	rg_export_records(m_gpuGraph,d_buf,counts[0]); rg_count_records(m_gpuGraph,d_buf,counts[0]);
 	rg_owner_counts(m_gpuGraph,counts); rg_resolve_admission(m_gpuGraph,n);
+	rg_markers_query_counts(m_gpuGraph,counts); rg_markers_export_queries(m_gpuGraph,d_buf,counts[0]);
+	rg_markers_answer(m_gpuGraph,d_buf,counts[0],(uint32_t*)d_buf); rg_markers_apply(m_gpuGraph,(const uint32_t*)d_buf,counts[0],(int32_t*)d_buf,(int32_t*)d_buf);
 	return rg_destroy(m_gpuGraph);
 }
 """)

@@ -57,13 +57,28 @@ def test_eight_rank_configs(oracle, name, genome, nranks):
 
 
 def test_c4_metagenome(oracle, tmp_path):
-    """configs[3]: 200 species, log-normal abundance: coverage from below 1x to hundreds, so singletons, false
-    positives and deep vertices all occur in one run"""
-    rng = np.random.default_rng(4)
-    genomes = [(rng.integers(0, 4, size=int(rng.integers(400, 1600)), dtype=np.uint8), float(w))
-               for w in rng.lognormal(mean=0.0, sigma=1.5, size=200)]
-    reads = make_reads_numpy(0, 100, 30_000, seed=40, error=0.005, genomes=genomes)
-    want = gpu_vs_oracle(oracle, *reads, 31, tmpdir=str(tmp_path), sweeps=(1 | 16 | (13 << 8), 2 | 32))
+    """configs[3]: 200 species, log-normal abundance (synth.CONFIGS' C4, genomes scaled 1:5000 to 400-1200 bases): coverage from
+    below 1x to hundreds, so singletons, false positives and deep vertices all occur in one run"""
+    from ray_amd.synth import metagenome_numpy
+    c = CONFIGS["C4_meta_200sp_lognormal_30x_150bp_k31"]
+    genomes, n_reads = metagenome_numpy(c, 1 / 5000)
+    assert len(genomes) == 200 and 25_000 <= n_reads <= 40_000
+    reads = make_reads_numpy(0, c["read_len"], n_reads, seed=40, error=0.005, genomes=genomes)
+    want = gpu_vs_oracle(oracle, *reads, c["k"], tmpdir=str(tmp_path), sweeps=(1 | 16 | (13 << 8), 2 | 32))
+    cov = want["pass1"]["coverage"]
+    assert cov.min() <= 2 and cov.max() >= 50
+
+
+def test_c4_reads_made_on_the_device(oracle):
+    """the bench's generator for C4 (genomes back to back in HBM, species drawn by coverage x length): parity on what it makes"""
+    import torch
+    from ray_amd.synth import make_reads_torch, metagenome_plan
+    c = CONFIGS["C4_meta_200sp_lognormal_30x_150bp_k31"]
+    lengths, coverage, n_reads = metagenome_plan(c, 1 / 5000)
+    packed, offsets, rl = make_reads_torch(0, c["read_len"], n_reads, c["seed"], 0.003, species=(lengths, coverage))
+    torch.cuda.synchronize()
+    reads = (packed.cpu().numpy(), offsets.cpu().numpy().astype(np.uint64), rl.cpu().numpy().astype(np.uint32))
+    want = gpu_vs_oracle(oracle, *reads, c["k"], sweeps=(1 | 16 | (12 << 8),))
     cov = want["pass1"]["coverage"]
     assert cov.min() <= 2 and cov.max() >= 50
 

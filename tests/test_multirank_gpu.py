@@ -85,7 +85,7 @@ def test_multirank_matches_oracle(oracle, k, nranks, bloom):
     want = oracle_run(oracle, packed, offsets, lengths, k, nranks, bloom)
     for sweep, route, parts, one in ((1 | 16 | (17 << 8), "entries", 1, False), (2 | 32, "entries", 1, True), (1 | 16 | (10 << 8), "records", 1, True),
                                      (1 | 32 | (10 << 8), "records", 1, True), (1 | 16 | (10 << 8) | 0x80000, "records", 1, True),
-                                     (1 | 16 | (10 << 8), "records", 3, False), (2 | 32, "records", 1, False)):
+                                     (1 | 16 | (10 << 8), "records", 3, False), (1 | 16 | 0x2000000, "records", 1, True), (2 | 32, "records", 1, False)):
         builders = run_ranks(packed, offsets, lengths, k, nranks, bloom, sweep=sweep, route=route, parts=parts, one_merge=one)
         check_ranks(builders, want, route)
     # SequencesIndexer's markers across ranks (IndexerWorker.cpp:67-248): k-mers to their owners, coverages back

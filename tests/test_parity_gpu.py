@@ -239,3 +239,34 @@ def test_power_of_two_filters_by_key_partitions(oracle, k, log2_bits):
     want = gpu_vs_oracle(oracle, packed, offsets, lengths, k, bloom_bits=1 << log2_bits, purge=False,
                          sweeps=(1 | (10 << 8) | 0x1000000, 2 | 0x1000000))
     assert want["builder"].stats()["bloom_partitioned"] == 2
+
+
+@pytest.mark.parametrize("k", [21, 31, 47, 63])
+def test_hashes_are_checked_against_the_callers(oracle, k):
+    """rg_check_hashes / rg_hash_kmers: the device's hash_function_1 / _2 against the caller's own (here the oracle's, the
+    stand-in for Ray's Kmer::hash_function_1/2); a caller whose hash differs in one bit gets RG_ERR_HASH"""
+    import ray_amd
+    from ray_amd._lib import RG_ERR_HASH
+    b = ray_amd.GraphBuilder(k)
+    W = b.kmer_words
+    b.check_hashes(lambda w: oracle.hash1(w, W), lambda w: oracle.hash2(w, W), n_samples=512)
+    with pytest.raises(ray_amd.RayGraphError) as err:
+        b.check_hashes(lambda w: oracle.hash1(w, W) ^ (1 << 40), lambda w: oracle.hash2(w, W), n_samples=64)
+    assert err.value.code == RG_ERR_HASH and "hash_function_1" in str(err.value)
+    with pytest.raises(ray_amd.RayGraphError) as err:
+        b.check_hashes(lambda w: oracle.hash1(w, W), lambda w: oracle.hash2(w, W) + (1 if w[0] == 1 else 0), n_samples=64)
+    assert err.value.code == RG_ERR_HASH and "hash_function_2" in str(err.value)
+    rng = np.random.default_rng(k)
+    kmers = rng.integers(0, 1 << 62, size=(100, W), dtype=np.uint64)
+    if W == 2:
+        kmers[:, 1] &= np.uint64((1 << (2 * k - 64)) - 1)
+    else:
+        kmers &= np.uint64((1 << (2 * k)) - 1)
+    h1, h2 = b.hash_kmers(kmers)
+    assert [int(x) for x in h1] == [oracle.hash1(tuple(int(v) for v in row), W) for row in kmers]
+    assert [int(x) for x in h2] == [oracle.hash2(tuple(int(v) for v in row), W) for row in kmers]
+    # the survey's known answers (SURVEY.md 8c) through the device code
+    if k == 31:
+        h1, h2 = b.hash_kmers(np.array([[0x24e4e4e4e4e4e4e4]], dtype=np.uint64))
+        assert (int(h1[0]), int(h2[0])) == (0x14605c73bf1f7ba9, 0x2a0e90af81ed09a8)
+    b.close()
