@@ -3165,7 +3165,10 @@ int rg_resolve_admission(rg_handle *h, uint64_t local_reads_for_bloom) {
 		// filters of 2^B bits too full for the regions (or rg_debug_set bit 24: tests): one item per key, partitioned by the
 		// key's origin, eight streams per region (rg_bloomx.h)
 		const bool regions_cheap = contested <= 0.4 * REGION_MULTI_CAP;  // beyond: stamp gathers and several rounds per region (C2 with 0.2 % errors: 125 ms against 45)
-		if (!(flags & 32u) && !(flags & 16u) && ((h->dbg & 0x1000000) || (!regions_cheap && keys >= (1ull << 20)))) {
+		// ... and, since its regions are software-pipelined (k_xor_region_sparse), for sparse ones too: C2 error-free 12.1 ms
+		// against the regions' 15.4.  The (bit, key) items of rg_bloom.h remain for filters whose size is not a power of two.
+		(void)regions_cheap;
+		if (!(flags & 32u) && !(flags & 16u) && ((h->dbg & 0x1000000) || keys >= (1ull << 20))) {
 			rc0 = bloom_xor(h, T, m_bits, keys, &resolved);
 			if (rc0) return rc0;
 			if (resolved) h->stats.bloom_partitioned = 2;
