@@ -1381,6 +1381,7 @@ template <int W>
 struct SuperkmerLaunch {
 	int grid_wave = 1, grid_lane = 0;
 	size_t lds_lane = 0;
+	bool wide = false;  // k_superkmers_lanes<W, true>: 6-byte window slots, windows of up to 64 m-mers
 	int grid_max() const { return grid_wave > grid_lane ? grid_wave : grid_lane; }
 	void plan(rg_handle *h, int n_cu, int k, int m, uint64_t total_reads) {
 		const int w = k - m + 1;
@@ -1391,8 +1392,16 @@ struct SuperkmerLaunch {
 		if (w <= SKL_HOST_MAX_W && w <= SKL_MAX_W && !(h->dbg & 0x10000)) {
 			lds_lane = (size_t)4 * w * 64 * sizeof(unsigned long long);
 			int occl = 0;
-			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occl, k_superkmers_lanes<W>, 256, lds_lane) == hipSuccess && occl >= 1)
+			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occl, k_superkmers_lanes<W, false>, 256, lds_lane) == hipSuccess && occl >= 1)
 				grid_lane = (int)std::min<uint64_t>((uint64_t)n_cu * occl, std::max<uint64_t>(1, (total_reads + 255) / 256));
+		} else if (w <= SKL_MAX_W_WIDE && !(h->dbg & 0x10000)) {
+			lds_lane = (size_t)4 * w * 64 * 6;
+			int occl = 0;
+			if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_superkmers_lanes<W, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lane) == hipSuccess &&
+			    hipOccupancyMaxActiveBlocksPerMultiprocessor(&occl, k_superkmers_lanes<W, true>, 256, lds_lane) == hipSuccess && occl >= 1) {
+				grid_lane = (int)std::min<uint64_t>((uint64_t)n_cu * occl, std::max<uint64_t>(1, (total_reads + 255) / 256));
+				wide = true;
+			}
 		}
 		(void)hipGetLastError();
 	}
@@ -1400,8 +1409,11 @@ struct SuperkmerLaunch {
 	const char *name(const ReadBatch &b) const { return lanes(b) ? "k_superkmers_lanes" : "k_superkmers"; }
 	void launch(rg_handle *h, const ReadBatch &b, uint64_t lo, uint64_t n, int k, int m, Rec<W> *buf, uint64_t rec_cap,
 	            unsigned long long *d_hist, uint32_t modulo, uint32_t hist_shift, Rec<W> *sample = nullptr, uint64_t sample_cap = 0) const {
-		if (lanes(b))
-			hipLaunchKernelGGL(k_superkmers_lanes<W>, dim3(grid_lane), dim3(256), lds_lane, h->stream, b.d_packed, b.d_off + lo, b.d_len + lo, n,
+		if (lanes(b) && wide)
+			hipLaunchKernelGGL((k_superkmers_lanes<W, true>), dim3(grid_lane), dim3(256), lds_lane, h->stream, b.d_packed, b.d_off + lo, b.d_len + lo, n,
+			                   b.first_id + lo, k, m, buf, rec_cap, h->d_counters, d_hist, modulo, hist_shift, sample, sample_cap);
+		else if (lanes(b))
+			hipLaunchKernelGGL((k_superkmers_lanes<W, false>), dim3(grid_lane), dim3(256), lds_lane, h->stream, b.d_packed, b.d_off + lo, b.d_len + lo, n,
 			                   b.first_id + lo, k, m, buf, rec_cap, h->d_counters, d_hist, modulo, hist_shift, sample, sample_cap);
 		else
 			hipLaunchKernelGGL(k_superkmers<W>, dim3(grid_wave), dim3(256), 0, h->stream, b.d_packed, b.d_off + lo, b.d_len + lo, n,

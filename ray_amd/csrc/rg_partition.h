@@ -371,8 +371,13 @@ __global__ __launch_bounds__(256) void k_superkmers(const uint64_t *__restrict__
 //      + rank into a ring in LDS); whenever 64 are queued, the wavefront assembles 64 records at once, lane per
 //      record, bases fetched from the read (cache hits), stores to consecutive slots.
 // x orders (mix, position) exactly like k_superkmers, so every k-mer still has one bucket whatever kernel cut it.
+// WIDE (windows of more than 24 m-mers: k >= 39, C3's k = 63): the window slots are split into a 32-bit mix and a 16-bit
+// position (6 bytes per slot and lane instead of 8: w = 49 then takes 75 KB per workgroup, two workgroups per CU, where
+// 8-byte slots would leave one), the position of an entry of the current block is implied by its index and only stored for
+// the suffix minima; the descriptor gives 6 bits to the record length and the minimizer offset and 11 to the start.
 static constexpr uint32_t SKL_RING = 128;
-static constexpr int SKL_MAX_W = 32;  // descriptor fields: 5 bits each for the record length - 1 and the minimizer offset
+static constexpr int SKL_MAX_W = 32;       // narrow descriptor: 5 bits each for the record length - 1 and the minimizer offset
+static constexpr int SKL_MAX_W_WIDE = 64;  // wide descriptor: 6 bits each, start position below 2048
 
 constexpr uint32_t inv32(uint32_t a) {  // inverse of an odd number modulo 2^32 (Newton)
 	uint32_t x = a;
@@ -384,7 +389,7 @@ __device__ __forceinline__ uint32_t order_unmix(uint32_t h) {  // order_mix is a
 	return (h * inv32(0x9E3779B1u)) ^ 0x5bd1e995u;
 }
 
-template <int W>
+template <int W, bool WIDE>
 __global__ __launch_bounds__(256) void k_superkmers_lanes(const uint64_t *__restrict__ P, const uint64_t *__restrict__ offsets,
                                                           const uint32_t *__restrict__ lengths, uint64_t nreads, uint64_t read_id_base,
                                                           int k, int m, Rec<W> *__restrict__ recs, uint64_t rec_cap,
@@ -399,6 +404,11 @@ __global__ __launch_bounds__(256) void k_superkmers_lanes(const uint64_t *__rest
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	const uint32_t w = (uint32_t)(k - m + 1);
 	unsigned long long *const win = s_win_all + (size_t)wave * w * 64 + lane;  // entry i of this lane: win[i * 64]
+	uint32_t *const winm = reinterpret_cast<uint32_t *>(s_win_all) + (size_t)wave * w * 64 + lane;  // WIDE: the mixes ...
+	uint16_t *const winj = reinterpret_cast<uint16_t *>(reinterpret_cast<uint32_t *>(s_win_all) + (size_t)4 * w * 64) + (size_t)wave * w * 64 + lane;  // ... and the positions
+	constexpr uint32_t SB = WIDE ? 11u : 16u;  // descriptor: start | (length - 1) << SB | lane << LANE_SH | (minimizer - start) << MO_SH
+	constexpr uint32_t LNB = WIDE ? 6u : 5u;
+	constexpr uint32_t LANE_SH = SB + LNB, MO_SH = LANE_SH + 6u;
 	unsigned long long *const ring = s_q[wave];
 	s_hist[threadIdx.x] = 0;
 	__syncthreads();
@@ -438,7 +448,7 @@ __global__ __launch_bounds__(256) void k_superkmers_lanes(const uint64_t *__rest
 		uint32_t pend = (L && 1u <= lastw) ? rp[1] : 0u;
 		uint32_t widx = 2, f = 0, r = 0;
 		uint32_t pre_hi = ~0u, pre_lo = 0, cur_hi = 0, cur_lo = ~0u, dbase = 0, i = 0;
-		const uint32_t lane_term = lane << 21;
+		const uint32_t lane_term = lane << LANE_SH;
 		const uint32_t nsteps = maxn + w;  // m-mers 0 .. max(nm): k-mer p is complete at j = p + w - 1, and p = n closes the last record
 		const uint32_t nbase = nsteps + (uint32_t)m - 1;  // bases walked: m-mer j is complete with base j + m - 1
 		for (uint32_t t0 = 0; t0 < nbase; t0 += 16) {
@@ -458,10 +468,14 @@ __global__ __launch_bounds__(256) void k_superkmers_lanes(const uint64_t *__rest
 				if (t + 1 < (uint32_t)m) continue;  // wave-uniform
 				const uint32_t j = t + 1 - (uint32_t)m;
 				unsigned long long sfx = ~0ull;
-				if (i + 1 < w) sfx = win[(i + 1) * 64];  // S[i+1] of the previous block (garbage in the first block: not used there)
+				if (i + 1 < w) {  // S[i+1] of the previous block (garbage in the first block: not used there)
+					if (WIDE) sfx = ((unsigned long long)winm[(i + 1) * 64] << 32) | winj[(i + 1) * 64];
+					else sfx = win[(i + 1) * 64];
+				}
 				const uint32_t cm = f < r ? f : r;
 				const uint32_t mix = order_mix(cm);
-				win[i * 64] = ((unsigned long long)mix << 32) | j;
+				if (WIDE) winm[i * 64] = mix;  // its position is j - (w - 1 - i) seen from the end of the block
+				else win[i * 64] = ((unsigned long long)mix << 32) | j;
 				// (mix, position) pairs are ordered by mix, the earlier position winning ties: positions only grow, so
 				// 32-bit compares of the mixes do, < where the newcomer is the later one, <= where it is the earlier one
 				const bool newpre = i == 0 || mix < pre_hi;
@@ -478,14 +492,14 @@ __global__ __launch_bounds__(256) void k_superkmers_lanes(const uint64_t *__rest
 					if (bal) {
 						if (push) {
 							// dbase + ((p - 1) << 16) = start | (p - start - 1) << 16 | lane << 21 | (minimizer position - start) << 27
-							const uint32_t d = dbase + ((p - 1u) << 16);
+							const uint32_t d = dbase + ((p - 1u) << SB);
 							const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
 							ring[(qtail + rk) & (SKL_RING - 1)] = ((unsigned long long)cur_hi << 32) | d;
 						}
 						qtail += (uint32_t)__popcll(bal);
 					}
 					if (p < n && changed) {  // a record starts at p
-						dbase = (res_lo << 27) + (lane_term + p * (1u - (1u << 16) - (1u << 27)));
+						dbase = (res_lo << MO_SH) + (lane_term + p * (1u - (1u << SB) - (1u << MO_SH)));
 						cur_lo = res_lo;
 						cur_hi = res_hi;
 					}
@@ -494,6 +508,34 @@ __global__ __launch_bounds__(256) void k_superkmers_lanes(const uint64_t *__rest
 				if (i == w) {  // block complete: slot t becomes the minimum of entries t .. w-1
 					// four entries per round so that their LDS latencies overlap; slot 0 is nobody's S (indices are clamped to it)
 					uint32_t run_hi = mix, run_lo = j;
+					if (WIDE) {
+						if (w >= 2) winj[(w - 1) * 64] = (uint16_t)j;  // S[w-1] is the last entry itself (slot 0 is nobody's S)
+						const uint32_t j0 = j + 1u - w;  // position of entry 0 of this block
+						for (int q = (int)w - 2; q >= 0; q -= 4) {
+							const int q1 = q > 0 ? q - 1 : 0, q2 = q > 1 ? q - 2 : 0, q3 = q > 2 ? q - 3 : 0;
+							const uint32_t m0 = winm[q * 64], m1 = winm[q1 * 64], m2 = winm[q2 * 64], m3 = winm[q3 * 64];
+							const bool t0 = m0 <= run_hi;
+							run_hi = t0 ? m0 : run_hi;
+							run_lo = t0 ? j0 + (uint32_t)q : run_lo;
+							winm[q * 64] = run_hi;
+							winj[q * 64] = (uint16_t)run_lo;
+							const bool t1 = m1 <= run_hi;
+							run_hi = t1 ? m1 : run_hi;
+							run_lo = t1 ? j0 + (uint32_t)q1 : run_lo;
+							winm[q1 * 64] = run_hi;
+							winj[q1 * 64] = (uint16_t)run_lo;
+							const bool t2 = m2 <= run_hi;
+							run_hi = t2 ? m2 : run_hi;
+							run_lo = t2 ? j0 + (uint32_t)q2 : run_lo;
+							winm[q2 * 64] = run_hi;
+							winj[q2 * 64] = (uint16_t)run_lo;
+							const bool t3 = m3 <= run_hi;
+							run_hi = t3 ? m3 : run_hi;
+							run_lo = t3 ? j0 + (uint32_t)q3 : run_lo;
+							winm[q3 * 64] = run_hi;
+							winj[q3 * 64] = (uint16_t)run_lo;
+						}
+					} else
 					for (int q = (int)w - 2; q >= 0; q -= 4) {
 						const int q1 = q > 0 ? q - 1 : 0, q2 = q > 1 ? q - 2 : 0, q3 = q > 2 ? q - 3 : 0;
 						const unsigned long long v0 = win[q * 64], v1 = win[q1 * 64], v2 = win[q2 * 64], v3 = win[q3 * 64];
@@ -541,7 +583,7 @@ __global__ __launch_bounds__(256) void k_superkmers_lanes(const uint64_t *__rest
 					// cost the kernel its fourth workgroup per CU
 					const unsigned long long d = ring[(qhead + lane) & (SKL_RING - 1)];
 					const uint32_t dl = (uint32_t)d;
-					const uint32_t pr = dl & 0xFFFFu, len = ((dl >> 16) & 31u) + 1u, src = (dl >> 21) & 63u, jrel = dl >> 27;
+					const uint32_t pr = dl & ((1u << SB) - 1u), len = ((dl >> SB) & ((1u << LNB) - 1u)) + 1u, src = (dl >> LANE_SH) & 63u, jrel = (dl >> MO_SH) & ((1u << LNB) - 1u);
 					const uint32_t Ls = (uint32_t)__shfl((int)L, (int)src);
 					const uint64_t b0 = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(bit0 >> 32), (int)src) << 32) | (uint32_t)__shfl((int)(uint32_t)bit0, (int)src);
 					if (!dead && lane < cnt) {
