@@ -1434,12 +1434,12 @@ struct AggLaunch {
 		occ = wg ? 1 : 4;
 		if (wg) {
 			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_aggregate_wg<W, THREADS, KS, RS, false>, THREADS, 0) != hipSuccess || occ < 1) occ = 1;
-		} else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_aggregate<W, false>, 64 * AGG_WAVES, 0) != hipSuccess || occ < 1) occ = 4;
+		} else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_aggregate<W, false>, 64 * agg_waves<W>(), 0) != hipSuccess || occ < 1) occ = 4;
 		(void)hipGetLastError();
 	}
-	uint32_t per_group() const { return wg ? 1u : AGG_WAVES; }           // buckets a workgroup works on at a time
+	uint32_t per_group() const { return wg ? 1u : agg_waves<W>(); }           // buckets a workgroup works on at a time
 	uint64_t key_limit() const { return wg ? KLIMIT : AGG_LIMIT; }       // keys a bucket attempt can hold
-	uint64_t slack(unsigned grid) const { return wg ? 0 : (uint64_t)grid * AGG_WAVES * LOG_CHUNK; }  // log entries lost to open chunks
+	uint64_t slack(unsigned grid) const { return wg ? 0 : (uint64_t)grid * agg_waves<W>() * LOG_CHUNK; }  // log entries lost to open chunks
 	// occurrences a bucket should hold at most: its distinct k-mers must fit the LDS table at the coverage assemblies are run at
 	uint64_t occ_per_bucket() const { return wg ? (uint64_t)KS * 24 : 2048; }
 	unsigned grid_for_buckets(uint64_t n, int n_cu) const { return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n + per_group() - 1) / per_group(), (uint64_t)n_cu * occ)); }
@@ -1449,7 +1449,7 @@ struct AggLaunch {
 			hipLaunchKernelGGL((k_aggregate_wg<W, THREADS, KS, RS, false>), dim3(grid), dim3(THREADS), 0, h->stream, recs, begin, nb, k, log, log_cap, h->d_counters,
 			                   flag_unique, (const uint32_t *)nullptr, retry, m, rbits);
 		else
-			hipLaunchKernelGGL((k_aggregate<W, false>), dim3(grid), dim3(64 * AGG_WAVES), 0, h->stream, recs, begin, nb, k, log, log_cap, h->d_counters, flag_unique,
+			hipLaunchKernelGGL((k_aggregate<W, false>), dim3(grid), dim3(64 * agg_waves<W>()), 0, h->stream, recs, begin, nb, k, log, log_cap, h->d_counters, flag_unique,
 			                   (const uint32_t *)nullptr, retry, m, rbits);
 	}
 	void slow(rg_handle *h, unsigned grid, const Rec<W> *recs, const unsigned long long *begin, uint32_t nlist, int k, Slot *log, uint64_t log_cap,
@@ -1458,7 +1458,7 @@ struct AggLaunch {
 			hipLaunchKernelGGL((k_aggregate_wg<W, THREADS, KS, RS, true>), dim3(grid), dim3(THREADS), 0, h->stream, recs, begin, nlist, k, log, log_cap, h->d_counters,
 			                   flag_unique, list, (uint32_t *)nullptr, m, rbits);
 		else
-			hipLaunchKernelGGL((k_aggregate<W, true>), dim3(grid), dim3(64 * AGG_WAVES), 0, h->stream, recs, begin, nlist, k, log, log_cap, h->d_counters, flag_unique,
+			hipLaunchKernelGGL((k_aggregate<W, true>), dim3(grid), dim3(64 * agg_waves<W>()), 0, h->stream, recs, begin, nlist, k, log, log_cap, h->d_counters, flag_unique,
 			                   list, (uint32_t *)nullptr, m, rbits);
 	}
 };

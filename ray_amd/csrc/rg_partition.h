@@ -880,7 +880,11 @@ static constexpr uint32_t AGG_FLUSH = 190;
 static constexpr uint32_t RT_SLOTS = 128;
 static constexpr uint32_t RT_FLUSH = RT_SLOTS * 3 / 4 - 64;
 static constexpr uint32_t LOG_CHUNK = 512;
-static constexpr uint32_t AGG_WAVES = 4;  // wavefronts per workgroup (one per workgroup: 26 ms instead of 17)
+// wavefronts per workgroup (one per workgroup: 26 ms instead of 17).  Two-word keys have 16.1 KB of tables per wavefront,
+// 8 wavefronts per CU with four per workgroup; three per workgroup (9 per CU) changed nothing (C3 shape: 25.4 ms both), five
+// (80.7 KB: only one workgroup fits) 40.9 ms
+template <int W>
+constexpr uint32_t agg_waves() { return 4u; }
 
 template <int W>
 struct AggTable {
@@ -963,7 +967,7 @@ __device__ __forceinline__ bool lds_upsert(AggTable<W> &t, uint32_t hash, uint64
 // and its number appended to retry_list (counters[PC_AGG_RETRY] of them).  SLOW == true: the buckets of
 // bucket_list, with sub-passes.  Two instantiations so that the common path carries none of the retry machinery.
 template <int W, bool SLOW>
-__global__ __launch_bounds__(64 * AGG_WAVES) void k_aggregate(const Rec<W> *__restrict__ recs,
+__global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const Rec<W> *__restrict__ recs,
                                                               const unsigned long long *__restrict__ bucket_begin, uint32_t nbuckets,
                                                               int k, Slot *__restrict__ log, uint64_t log_cap,
                                                               unsigned long long *__restrict__ counters, uint32_t flag_unique,
@@ -979,8 +983,8 @@ __global__ __launch_bounds__(64 * AGG_WAVES) void k_aggregate(const Rec<W> *__re
 	// minimizer's bucket number that the partition levels left unused (m = minimizer length): a record that is not
 	// of the pass costs its load and nothing else; further levels take k-mers by bits of their hash.
 	constexpr int NB = 2 * W;
-	__shared__ AggTable<W> s_tables[AGG_WAVES];
-	__shared__ RecTable<W> s_rtables[AGG_WAVES];
+	__shared__ AggTable<W> s_tables[agg_waves<W>()];
+	__shared__ RecTable<W> s_rtables[agg_waves<W>()];
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	AggTable<W> &T = s_tables[wave];
 	RecTable<W> &R = s_rtables[wave];
@@ -1197,9 +1201,9 @@ __global__ __launch_bounds__(64 * AGG_WAVES) void k_aggregate(const Rec<W> *__re
 	}
 	wave_sync();
 
-	const uint32_t stride = gridDim.x * AGG_WAVES;
+	const uint32_t stride = gridDim.x * agg_waves<W>();
 	// nbuckets = number of buckets to visit: all of them, or (SLOW) the length of bucket_list
-	uint32_t b = blockIdx.x * AGG_WAVES + wave;
+	uint32_t b = blockIdx.x * agg_waves<W>() + wave;
 	uint64_t cb = 0, ce = 0;
 	if (b < nbuckets) {
 		const uint32_t bb = (SLOW && bucket_list) ? bucket_list[b] : b;  // no list: every bucket
