@@ -19,7 +19,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PMC_SUMMARY = "profiles/r02_v4_c2_pmc.json"
+PMC_SUMMARY = "profiles/r02_v6_c2_pmc.json"
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
@@ -35,7 +35,7 @@ def parse():
                     help="development: run what one of N ranks does on ONE GPU (records exported by destination, as many "
                          "full-coverage records counted as N ranks would send here, entries exported by owner and merged; "
                          "no network).  Not a bench line.")
-    ap.add_argument("--cpu-sample-reads", type=int, default=60000, help="reads per CPU baseline instance")
+    ap.add_argument("--cpu-sample-reads", type=int, default=150000, help="reads per CPU baseline instance")
     ap.add_argument("--cpu-cores", type=int, default=0, help="CPU baseline instances; 0 = min(16, host cores): the GPU box's share")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--route", choices=("auto", "records", "entries"), default="auto",
@@ -217,6 +217,7 @@ def main():
             mark("records_local + export")
             b.count_records(rsend.data_ptr(), n_rec)
             del rsend
+            torch.cuda.empty_cache()   # a rank gives its exchange buffers back once they are consumed; torch's cache would keep them
             mark("count_records")
             counts = b.owner_counts()
             send = torch.empty(max(1, sum(counts)) * RG_ENTRY_BYTES, dtype=torch.uint8, device=dev)
@@ -225,6 +226,7 @@ def main():
             b.merge_entries(send.data_ptr(), sum(counts))   # as many entries, all distinct, as N ranks would send here
             mark("merge")
             del send
+            torch.cuda.empty_cache()
             b.resolve_admission(n_reads)
         elif world == 1:
             if args.breakdown:
@@ -387,8 +389,8 @@ def main():
                 with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), PMC_SUMMARY)) as fh:
                     pmc = json.load(fh)
                 pm = pmc.get(dom)
-                if pm and pm.get("launches"):
-                    traffic = (2.0 * pm.get("FETCH_SIZE_bytes", 0.0) + pm.get("WRITE_SIZE_bytes", 0.0)) / pm["launches"]
+                if pm and pm.get("launches"):   # per launch of this run's count: the profiled step's extra launches (the record sample's) move next to nothing
+                    traffic = (2.0 * pm.get("FETCH_SIZE_bytes", 0.0) + pm.get("WRITE_SIZE_bytes", 0.0)) / max(1.0, kprof[dom][1] / args.steps)
                 if pmc.get("_steps"):   # all kernels of the profiled run / its steps
                     traffic_step = sum(2.0 * v.get("FETCH_SIZE_bytes", 0.0) + v.get("WRITE_SIZE_bytes", 0.0)
                                        for kn, v in pmc.items() if isinstance(v, dict)) / pmc["_steps"]

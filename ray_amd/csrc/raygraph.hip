@@ -1126,15 +1126,16 @@ hipError_t pool_alloc(int device, void **out, uint64_t bytes) {
 	}
 	hipError_t e = hipMalloc(out, bytes);
 	if (e != hipSuccess) {
-		// The device is full.  A cached block of any larger size is better than releasing memory (hipFree of a touched
-		// multi-GiB block costs hundreds of milliseconds); failing that, cached blocks go back to the driver, largest first,
-		// until the request fits.
+		// The device is full.  A cached block of up to twice the size is better than releasing memory (hipFree of a touched
+		// multi-GiB block costs hundreds of milliseconds; a block many times the size is kept for the request it fits --
+		// C5's share per GPU: 26 GB of records that sat in the 99 GB block left the log without room); failing that, cached
+		// blocks go back to the driver, largest first, until the request fits.
 		(void)hipGetLastError();
 		{
 			std::lock_guard<std::mutex> lk(g_pool.mu);
 			auto &fb = g_pool.free_blocks[device];
 			auto it = fb.lower_bound(bytes);
-			if (it != fb.end()) {
+			if (it != fb.end() && it->first <= 2 * bytes) {
 				*out = it->second;
 				g_pool.live[device][*out] = it->first;
 				fb.erase(it);
@@ -1156,7 +1157,20 @@ hipError_t pool_alloc(int device, void **out, uint64_t bytes) {
 			if (e == hipSuccess) break;
 			(void)hipGetLastError();
 		}
-		if (e != hipSuccess) return e;
+		if (e != hipSuccess) {
+			if (getenv("RG_DEBUG")) {
+				size_t fr = 0, tot = 0;
+				(void)hipMemGetInfo(&fr, &tot);
+				uint64_t live = 0;
+				std::lock_guard<std::mutex> lk(g_pool.mu);
+				for (auto &kv : g_pool.live[device]) live += kv.second;
+				fprintf(stderr, "[raygraph] pool: %.2f GB asked, %.2f GB live in %zu blocks, nothing cached, device reports %.2f of %.2f GB free\n", bytes / 1e9,
+				        live / 1e9, g_pool.live[device].size(), fr / 1e9, tot / 1e9);
+				for (auto &kv : g_pool.live[device])
+					if (kv.second > (1ull << 30)) fprintf(stderr, "[raygraph] pool:   live block of %.2f GB\n", kv.second / 1e9);
+			}
+			return e;
+		}
 	}
 	std::lock_guard<std::mutex> lk(g_pool.mu);
 	g_pool.live[device][*out] = bytes;
@@ -1428,17 +1442,21 @@ struct AggLaunch {
 	static constexpr int THREADS = 1024, KS = 4096, RS = (W == 1 ? 1024 : 512);  // 132 / 152 KB of LDS: one workgroup of 16 wavefronts per CU
 	static constexpr uint32_t KLIMIT = KS * 5 / 8;
 	bool wg = true;
+	bool big = false;  // k_aggregate with tables of AGG_SLOTS_BIG k-mers per wavefront (diverse inputs)
 	int occ = 1;
-	void plan(bool use_wg) {
+	void plan(bool use_wg, bool use_big = false) {
 		wg = use_wg;
+		big = use_big && !use_wg;
 		occ = wg ? 1 : 4;
 		if (wg) {
 			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_aggregate_wg<W, THREADS, KS, RS, false>, THREADS, 0) != hipSuccess || occ < 1) occ = 1;
+		} else if (big) {
+			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_aggregate<W, false, AGG_SLOTS_BIG>, 64 * agg_waves<W>(), 0) != hipSuccess || occ < 1) occ = 2;
 		} else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_aggregate<W, false>, 64 * agg_waves<W>(), 0) != hipSuccess || occ < 1) occ = 4;
 		(void)hipGetLastError();
 	}
 	uint32_t per_group() const { return wg ? 1u : agg_waves<W>(); }           // buckets a workgroup works on at a time
-	uint64_t key_limit() const { return wg ? KLIMIT : AGG_LIMIT; }       // keys a bucket attempt can hold
+	uint64_t key_limit() const { return wg ? KLIMIT : (big ? agg_limit<AGG_SLOTS_BIG>() : AGG_LIMIT); }       // keys a bucket attempt can hold
 	uint64_t slack(unsigned grid) const { return wg ? 0 : (uint64_t)grid * agg_waves<W>() * LOG_CHUNK; }  // log entries lost to open chunks
 	// occurrences a bucket should hold at most: its distinct k-mers must fit the LDS table at the coverage assemblies are run at
 	uint64_t occ_per_bucket() const { return wg ? (uint64_t)KS * 24 : 2048; }
@@ -1448,6 +1466,9 @@ struct AggLaunch {
 		if (wg)
 			hipLaunchKernelGGL((k_aggregate_wg<W, THREADS, KS, RS, false>), dim3(grid), dim3(THREADS), 0, h->stream, recs, begin, nb, k, log, log_cap, h->d_counters,
 			                   flag_unique, (const uint32_t *)nullptr, retry, m, rbits);
+		else if (big)
+			hipLaunchKernelGGL((k_aggregate<W, false, AGG_SLOTS_BIG>), dim3(grid), dim3(64 * agg_waves<W>()), 0, h->stream, recs, begin, nb, k, log, log_cap, h->d_counters,
+			                   flag_unique, (const uint32_t *)nullptr, retry, m, rbits);
 		else
 			hipLaunchKernelGGL((k_aggregate<W, false>), dim3(grid), dim3(64 * agg_waves<W>()), 0, h->stream, recs, begin, nb, k, log, log_cap, h->d_counters, flag_unique,
 			                   (const uint32_t *)nullptr, retry, m, rbits);
@@ -1456,6 +1477,9 @@ struct AggLaunch {
 	          uint32_t flag_unique, const uint32_t *list, int m, uint32_t rbits) const {
 		if (wg)
 			hipLaunchKernelGGL((k_aggregate_wg<W, THREADS, KS, RS, true>), dim3(grid), dim3(THREADS), 0, h->stream, recs, begin, nlist, k, log, log_cap, h->d_counters,
+			                   flag_unique, list, (uint32_t *)nullptr, m, rbits);
+		else if (big)
+			hipLaunchKernelGGL((k_aggregate<W, true, AGG_SLOTS_BIG>), dim3(grid), dim3(64 * agg_waves<W>()), 0, h->stream, recs, begin, nlist, k, log, log_cap, h->d_counters,
 			                   flag_unique, list, (uint32_t *)nullptr, m, rbits);
 		else
 			hipLaunchKernelGGL((k_aggregate<W, true>), dim3(grid), dim3(64 * agg_waves<W>()), 0, h->stream, recs, begin, nlist, k, log, log_cap, h->d_counters, flag_unique,
@@ -1502,7 +1526,7 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	// a bucket's distinct k-mers fit the LDS table of k_aggregate; buckets of more diverse inputs are split further
 	// by k_aggregate<SLOW> itself
 	AggLaunch<W> agg;
-	agg.plan((h->dbg & 0x200000) != 0);  // bit 21: a workgroup per bucket of a coarser partition (slower as it stands: DESIGN.md)
+	agg.plan((h->dbg & 0x200000) != 0, (h->dbg & 0x4000000) != 0);  // bit 21: a workgroup per bucket of a coarser partition (slower as it stands: DESIGN.md); bit 26: the 512-slot tables (tests)
 	int bits = nested ? nested_bits : (int)((h->dbg >> 8) & 0xFF);
 	const bool bits_forced = bits != 0;
 	if (bits == 0) {
@@ -1571,7 +1595,7 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	} while (0)
 	if (!ext && pool_alloc(dev, (void **)&buf[0], rec_cap * sizeof(Rec<W>)) != hipSuccess) {  // not enough memory: direct sweep
 		(void)hipGetLastError();
-		return RG_OK;
+		{ if (getenv("RG_DEBUG")) fprintf(stderr, "[raygraph] partitioned sweep gives up at line %d (no memory)\n", __LINE__); return RG_OK; }
 	}
 	const uint64_t SEGMAX = 65536;
 	PTRY(pool_alloc(dev, (void **)&d_seg, (SEGMAX + 1) * sizeof(unsigned long long)));
@@ -1666,6 +1690,9 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 					split_levels();
 					NBUCK = 1ull << bits;
 				}
+				// even the finest partition leaves buckets of about a hundred k-mers or more: the larger tables (C5's share per GPU
+				// at 2^24 buckets holds 168 per bucket and a third of the buckets overflowed the 190 of the small ones)
+				if (distinct / (double)NBUCK > (double)AGG_BIG_ABOVE && !(h->dbg & 0x200000)) agg.plan(false, true);
 			}
 		}
 		pool_free(dev, d_sample);
@@ -1759,7 +1786,7 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	if (pool_alloc(dev, (void **)&d_retry, NBUCK * sizeof(uint32_t)) != hipSuccess) {
 		(void)hipGetLastError();
 		cleanup();
-		return RG_OK;
+		{ if (getenv("RG_DEBUG")) fprintf(stderr, "[raygraph] partitioned sweep gives up at line %d (no memory)\n", __LINE__); return RG_OK; }
 	}
 	// entries may be marked unique unless other ranks aggregate the same keys (entry route, size > 1)
 	const uint32_t flag_unique = (h->cfg.size == 1 || ext) ? 1u : 0u;
@@ -1775,7 +1802,7 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 			log = nullptr;
 			pool_free(dev, d_retry);
 			cleanup();
-			return RG_OK;
+			{ if (getenv("RG_DEBUG")) fprintf(stderr, "[raygraph] partitioned sweep gives up at line %d (no memory)\n", __LINE__); return RG_OK; }
 		}
 		// Before the first attempt a sample of the buckets (the bucket number is a hash: any range is a fair sample) is
 		// aggregated alone, overflowing buckets included, and the log sized from what it produced: an input of little
@@ -1814,7 +1841,7 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 				(void)hipGetLastError();
 				pool_free(dev, d_retry);
 				cleanup();
-				return RG_OK;
+				{ if (getenv("RG_DEBUG")) fprintf(stderr, "[raygraph] partitioned sweep gives up at line %d (no memory)\n", __LINE__); return RG_OK; }
 			}
 		}
 		bool too_small = false;

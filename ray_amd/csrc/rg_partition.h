@@ -867,16 +867,21 @@ __global__ __launch_bounds__(256) void k_scan_add(unsigned long long *__restrict
 // Neither table can overfill: their fill is checked at points between which at most 64 keys arrive
 // (the spill path of the k-mer table is for safety only).  The records of the next round (or of the
 // next bucket's first round) are loaded before the current round is processed.
-static constexpr uint32_t AGG_SLOTS = 256;
+static constexpr uint32_t AGG_SLOTS = 256;      // the k-mer table of a wavefront ...
+static constexpr uint32_t AGG_SLOTS_BIG = 512;  // ... and of the variant for diverse inputs (the sample says a bucket holds about 100 k-mers or more even at 2^24 buckets:
+                                                // reads with 1 % errors at 30x and beyond), two workgroups per CU instead of three, no bucket retried in two halves
 // The k-mer table takes up to 64 new keys per round of the expansion (one lane per k-mer), so a round may only start
 // with AGG_SLOTS - 64 slots claimed at most: a batch of records whose k-mers fit below AGG_LIMIT all together runs
 // unchecked, otherwise the fill is looked at after every round and the table is declared too small for the (sub-pass
 // of the) bucket above AGG_FLUSH.  With that no k-mer can fail to find a slot; should one all the same, the attempt
 // is dropped like an overfull one (only the last-resort mode of partial flushes writes such a k-mer to the log on
 // its own: a k-mer written before the attempt is dropped would be counted again by the retry).
-static constexpr uint32_t AGG_LIMIT = 190;
+static constexpr uint32_t AGG_LIMIT = 190;      // of 256 slots; scaled with the table (agg_limit<SLOTS>())
+template <int SLOTS>
+constexpr uint32_t agg_limit() { return AGG_LIMIT * (uint32_t)SLOTS / AGG_SLOTS; }
 static constexpr uint32_t AGG_TARGET = 64;  // distinct k-mers per bucket the partition is sized for from the sample (C2 at 2^22 buckets: 24; the tail must stay below AGG_LIMIT)
 static constexpr uint32_t AGG_FLUSH = 190;
+static constexpr uint32_t AGG_BIG_ABOVE = 80;   // expected k-mers per bucket above which the sweep takes the AGG_SLOTS_BIG tables
 static constexpr uint32_t RT_SLOTS = 128;
 static constexpr uint32_t RT_FLUSH = RT_SLOTS * 3 / 4 - 64;
 static constexpr uint32_t LOG_CHUNK = 512;
@@ -886,14 +891,14 @@ static constexpr uint32_t LOG_CHUNK = 512;
 template <int W>
 constexpr uint32_t agg_waves() { return 4u; }
 
-template <int W>
+template <int W, int SLOTS = AGG_SLOTS>
 struct AggTable {
-	uint64_t k0[AGG_SLOTS];
-	uint64_t k1[W == 2 ? AGG_SLOTS : 1];
-	uint64_t stamp[AGG_SLOTS];
-	uint32_t cnt[AGG_SLOTS];
-	uint32_t edges[AGG_SLOTS];
-	uint16_t list[AGG_SLOTS];
+	uint64_t k0[SLOTS];
+	uint64_t k1[W == 2 ? SLOTS : 1];
+	uint64_t stamp[SLOTS];
+	uint32_t cnt[SLOTS];
+	uint32_t edges[SLOTS];
+	uint16_t list[SLOTS];
 	uint32_t fill;
 	uint32_t spilled;  // a k-mer of the current bucket went to the log on its own (table full)
 };
@@ -922,14 +927,14 @@ __device__ __forceinline__ uint32_t agg_hash(uint64_t i0, uint64_t i1) {
 	x ^= x >> 15;
 	return x * 0x9E3779B1u;  // top 8 bits: slot of the LDS table; the 12 bits below: sub-pass of the bucket
 }
-static_assert(AGG_SLOTS == 256, "the slot is the top 8 bits of agg_hash");
+static_assert(AGG_SLOTS == 256 && AGG_SLOTS_BIG == 512, "the slot is the top 8 or 9 bits of agg_hash");
 static constexpr uint32_t AGG_MAX_SUBPASSES = 4096;
 
-template <int W>
-__device__ __forceinline__ bool lds_upsert(AggTable<W> &t, uint32_t hash, uint64_t i0, uint64_t i1, uint64_t stamp, uint32_t emask,
+template <int W, int SLOTS>
+__device__ __forceinline__ bool lds_upsert(AggTable<W, SLOTS> &t, uint32_t hash, uint64_t i0, uint64_t i1, uint64_t stamp, uint32_t emask,
                                            uint32_t weight) {
-	uint32_t s = hash >> 24;
-	for (uint32_t probe = 0; probe < AGG_SLOTS; ++probe) {
+	uint32_t s = hash >> (SLOTS == 512 ? 23 : 24);
+	for (uint32_t probe = 0; probe < (uint32_t)SLOTS; ++probe) {
 		uint64_t c0 = t.k0[s];
 		if (c0 == EMPTY) {
 			uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long *>(&t.k0[s]), EMPTY, i0);
@@ -958,7 +963,7 @@ __device__ __forceinline__ bool lds_upsert(AggTable<W> &t, uint32_t hash, uint64
 				return true;
 			}
 		}
-		s = (s + 1) & (AGG_SLOTS - 1);
+		s = (s + 1) & ((uint32_t)SLOTS - 1);
 	}
 	return false;
 }
@@ -966,7 +971,7 @@ __device__ __forceinline__ bool lds_upsert(AggTable<W> &t, uint32_t hash, uint64
 // SLOW == false: every bucket once, no sub-passes; a bucket whose k-mers do not fit the table is dropped unwritten
 // and its number appended to retry_list (counters[PC_AGG_RETRY] of them).  SLOW == true: the buckets of
 // bucket_list, with sub-passes.  Two instantiations so that the common path carries none of the retry machinery.
-template <int W, bool SLOW>
+template <int W, bool SLOW, int SLOTS = AGG_SLOTS>
 __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const Rec<W> *__restrict__ recs,
                                                               const unsigned long long *__restrict__ bucket_begin, uint32_t nbuckets,
                                                               int k, Slot *__restrict__ log, uint64_t log_cap,
@@ -983,10 +988,11 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const Rec<W> 
 	// minimizer's bucket number that the partition levels left unused (m = minimizer length): a record that is not
 	// of the pass costs its load and nothing else; further levels take k-mers by bits of their hash.
 	constexpr int NB = 2 * W;
-	__shared__ AggTable<W> s_tables[agg_waves<W>()];
+	__shared__ AggTable<W, SLOTS> s_tables[agg_waves<W>()];
+	constexpr uint32_t LIMIT = agg_limit<SLOTS>();
 	__shared__ RecTable<W> s_rtables[agg_waves<W>()];
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-	AggTable<W> &T = s_tables[wave];
+	AggTable<W, SLOTS> &T = s_tables[wave];
 	RecTable<W> &R = s_rtables[wave];
 	const uint64_t mask0 = (2 * k >= 64) ? ~0ull : ((1ull << (2 * k)) - 1);
 	const uint64_t mask1 = (k > 32) ? ((1ull << (2 * k - 64)) - 1) : 0ull;
@@ -1104,7 +1110,7 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const Rec<W> 
 			}
 			const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
 			const uint32_t rpre = incl - rlen;
-			const bool checked = (uint32_t)__builtin_amdgcn_readfirstlane((int)T.fill) + total > AGG_LIMIT;  // else no overfill possible
+			const bool checked = (uint32_t)__builtin_amdgcn_readfirstlane((int)T.fill) + total > LIMIT;  // else no overfill possible
 			for (uint32_t t0 = 0; t0 < total; t0 += 64) {
 				const uint32_t t = t0 + lane;
 				// owner = number of records whose prefix sum is <= t (all lanes take part in the shuffles)
@@ -1143,9 +1149,9 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const Rec<W> 
 					uint64_t i0, i1;
 					to_internal<W>(use_rc ? r0 : f0, use_rc ? r1 : f1, i0, i1);
 					const uint32_t hx = agg_hash<W>(i0, i1);
-					if (SLOW && ((hx >> 12) & (nsub - 1)) != sub) {
+					if (SLOW && ((hx >> (SLOTS == 512 ? 11 : 12)) & (nsub - 1)) != sub) {
 						// another sub-pass owns this k-mer
-					} else if (!lds_upsert<W>(T, hx, i0, i1, stamp0 + i, em, weight)) {
+					} else if (!lds_upsert<W, SLOTS>(T, hx, i0, i1, stamp0 + i, em, weight)) {
 						if (!partial_flushes) {
 							T.spilled = 2;  // no slot left: the attempt is void
 						} else {
@@ -1169,7 +1175,7 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const Rec<W> 
 				if (checked) {
 					wave_sync();
 					if (!partial_flushes && (uint32_t)__builtin_amdgcn_readfirstlane((int)T.spilled) == 2) return false;
-					if ((uint32_t)__builtin_amdgcn_readfirstlane((int)T.fill) > AGG_FLUSH) {
+					if ((uint32_t)__builtin_amdgcn_readfirstlane((int)T.fill) > LIMIT) {
 						if (!partial_flushes) return false;
 						flush();
 					}
@@ -1182,7 +1188,7 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const Rec<W> 
 		return true;
 	};
 
-	for (uint32_t i = lane; i < AGG_SLOTS; i += 64) {
+	for (uint32_t i = lane; i < (uint32_t)SLOTS; i += 64) {
 		T.k0[i] = EMPTY;
 		if (W == 2) T.k1[i] = EMPTY;
 		T.stamp[i] = INF_STAMP;
