@@ -361,6 +361,8 @@ def main():
             "k_xor_region": 8 * cand0 * 8 + cand0,                                                   # every packed word once per hash, 8 win bits per key out
             "k_xor_fp": cand0 * (8 + 4 + 1),
         }
+        if "k_build_ranges" in kprof:
+            del alg_bytes["k_insert_admitted"]   # only the few entries that left their range go through it: no byte model
         if kprof.get("k_scatter_entries", (0, 0))[1] > args.steps:
             alg_bytes["k_scatter_entries"] += (kprof["k_scatter_entries"][1] / args.steps - 1) * 2 * st["stored_pairs"] * 32
         if kprof.get("k_scatter16", (0, 0))[1] > args.steps:
