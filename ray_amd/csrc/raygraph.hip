@@ -2252,6 +2252,16 @@ static int bloom_xor(rg_handle *h, Table &T, uint64_t m_bits, uint64_t keys, boo
 	// workgroups of 512: 73 ms; 2^12 x 4 of 256: 77 ms -- RG_XOR_R selects them for experiments)
 	int rmax = 14;
 	if (const char *ev = getenv("RG_XOR_R")) rmax = std::max(12, std::min(XOR_REGION_LOG2_MAX, atoi(ev)));
+	// Dense filters: a region's eight streams stay in registers between the two passes while each holds at most
+	// 1024 x XOR_SPER keys; beyond that the streams would be read twice (C5's share per GPU: 5370 keys per stream at 2^14
+	// bits), so the regions are halved instead -- the workgroup stays at 1024 threads, one per CU
+	bool dense_small = false;
+	if (!getenv("RG_XOR_R")) {
+		while (rmax > 12 && B > rmax && (double)keys / (double)(1ull << (B - rmax)) > 0.85 * 1024 * XOR_SPER) {
+			rmax--;
+			dense_small = true;
+		}
+	}
 	const int R = std::min(B, rmax);
 	const int PB = B - R;  // partition bits
 	if (PB > 24) return RG_OK;
@@ -2417,6 +2427,14 @@ static int bloom_xor(rg_handle *h, Table &T, uint64_t m_bits, uint64_t keys, boo
 		for (int j = i + 1; j < 8; ++j)
 			if ((MAGIC[i] & m_mask) == (MAGIC[j] & m_mask)) distinct_bits = false;
 	const bool sparse = rmax == 14 && keys / P <= 512 && !getenv("RG_XOR_DENSE");
+	if (!sparse && dense_small) {
+		ProfScope ps(h, "k_xor_region");
+		if (rmax == 13)
+			hipLaunchKernelGGL((k_xor_region<13, 1024>), dim3((unsigned)std::min<uint64_t>(P, (uint64_t)n_cu)), dim3(1024), 0, h->stream, pk, d_begin, (uint32_t)P, R, K, planes, plane_words, h->d_counters, (int)C_SETBITS);
+		else
+			hipLaunchKernelGGL((k_xor_region<12, 1024>), dim3((unsigned)std::min<uint64_t>(P, (uint64_t)n_cu)), dim3(1024), 0, h->stream, pk, d_begin, (uint32_t)P, R, K, planes, plane_words, h->d_counters, (int)C_SETBITS);
+		XTRY(hipGetLastError());
+	} else
 	if (sparse) {
 		ProfScope ps(h, "k_xor_region");
 		hipLaunchKernelGGL((k_xor_region_sparse<14, 1024>), dim3((unsigned)std::min<uint64_t>(P, (uint64_t)n_cu)), dim3(1024), 0, h->stream, pk, d_begin, (uint32_t)P, R, K, planes,
