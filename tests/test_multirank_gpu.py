@@ -172,3 +172,20 @@ def check_ranks(builders, want, route=""):
             merged[int(c)] = merged.get(int(c), 0) + int(n)
     assert sorted(merged) == want["hist"][0].tolist()
     assert [merged[c] for c in sorted(merged)] == want["hist"][1].tolist()
+
+
+def test_ranks_without_reads(oracle):
+    """fewer reads than ranks: SequencesLoader gives them all to the last rank (SequencesLoader.cpp:287-297); the others
+    still take part in every exchange -- records, entries, markers, purge -- with nothing to send"""
+    packed, offsets, lengths = make_reads_numpy(genome=300, read_len=80, n_reads=3, seed=5, error=0.0)
+    want = oracle_run(oracle, packed, offsets, lengths, 21, 4, 0)
+    for route in ("records", "entries"):
+        builders = run_ranks(packed, offsets, lengths, 21, 4, 0, route=route, one_merge=True)
+        check_ranks(builders, want, route)
+    wf, wr = want["graph"].read_markers()
+    gf, gr = markers_ranks(builders, len(lengths))
+    assert np.array_equal(gf, wf) and np.array_equal(gr, wr)
+    want["graph"].purge_edges()
+    purge_ranks(builders)
+    for r, b in enumerate(builders):
+        assert_records_equal(b.export(), want["graph"].export(r), "rank %d after purge" % r)
