@@ -216,17 +216,16 @@ def main():
                 n_rec += sum(rcounts)
             mark("records_local + export")
             b.count_records(rsend.data_ptr(), n_rec)
-            del rsend
-            torch.cuda.empty_cache()   # a rank gives its exchange buffers back once they are consumed; torch's cache would keep them
+            del rsend   # (torch keeps the block cached: the exchange buffers of a rank are as good as persistent)
             mark("count_records")
             counts = b.owner_counts()
             send = torch.empty(max(1, sum(counts)) * RG_ENTRY_BYTES, dtype=torch.uint8, device=dev)
             b.export_owner_buckets(send.data_ptr(), max(1, sum(counts)))
+            b.release_local()                        # as exchange_owner_buckets does: the aggregation goes before the exchange
             mark("owner buckets")
-            b.merge_entries(send.data_ptr(), sum(counts))   # as many entries, all distinct, as N ranks would send here
-            mark("merge")
+            b.adopt_entries(send.data_ptr(), sum(counts), keepalive=send)   # as many entries, all distinct, as N ranks would send here; admitted in place
+            mark("adopt")
             del send
-            torch.cuda.empty_cache()
             b.resolve_admission(n_reads)
         elif world == 1:
             if args.breakdown:

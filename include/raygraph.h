@@ -135,6 +135,16 @@ int rg_owner_counts(rg_handle *h, uint64_t *counts /* [size] */);
 #define RG_ENTRY_BYTES 32
 int rg_export_owner_buckets(rg_handle *h, void *d_out, uint64_t capacity_entries);
 int rg_merge_entries(rg_handle *h, const void *d_entries, uint64_t n_entries);
+/* Two calls that keep big partitions (tens of GB of entries per rank) from sitting in memory three times; same results,
+ * no counterpart in the reference (its messages are 4 KB and its table grows in place, GridTable.cpp:111-134):
+ *   rg_release_local   after rg_export_owner_buckets: frees this rank's aggregation before the exchange instead of at the
+ *                      first rg_merge_entries (the buckets hold everything it knew)
+ *   rg_adopt_entries   rg_merge_entries for a partition that arrives whole, without the copy: admission runs in the
+ *                      caller's device buffer, which must stay valid and untouched until rg_resolve_admission has
+ *                      returned (its contents are undefined afterwards).  Where rg_merge_entries would not keep the entries as a
+ *                      log (a second delivery, entries of the entry route) it behaves exactly like rg_merge_entries. */
+int rg_release_local(rg_handle *h);
+int rg_adopt_entries(rg_handle *h, void *d_entries, uint64_t n_entries);
 /* local_reads_for_bloom: this rank's read count for RG_BLOOM_DEFAULT sizing
  * (VerticesExtractor.cpp:298-300); pass UINT64_MAX to use the reads added to this handle */
 int rg_resolve_admission(rg_handle *h, uint64_t local_reads_for_bloom);

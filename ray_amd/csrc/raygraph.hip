@@ -1259,6 +1259,7 @@ struct rg_handle {
 	bool log_all_unique = false;         // the last sweep's log holds every key once
 	uint64_t log_keys = 0;               // entries of the last sweep's log
 	Slot *pending_log = nullptr;         // size == 1: the sweep's log of distinct k-mers, admitted before it is inserted
+	bool pending_borrowed = false;       // the pending log is the caller's buffer (rg_adopt_entries): never freed here
 	uint64_t pending_n = 0, pending_keys = 0;
 	bool merge_started = false;          // rg_merge_entries has been called with entries
 	void *rec_buf = nullptr;             // rg_records_local .. rg_export_records: super-k-mer records of the local reads
@@ -1704,7 +1705,12 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 		hist0 = folded;
 		PTRY(hipMemcpyAsync(d_hist, hist0.data(), 256 * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
 	}
-	PTRY(pool_alloc(dev, (void **)&buf[1], valid * sizeof(Rec<W>)));
+	if (ext && nlev > 1) {  // received records: both level buffers are ours; one block (see build_table_ranges)
+		PTRY(pool_alloc(dev, (void **)&buf[1], 2 * valid * sizeof(Rec<W>)));
+		buf[0] = buf[1] + valid;  // (pool_free ignores it: not a block of its own)
+	} else {
+		PTRY(pool_alloc(dev, (void **)&buf[1], valid * sizeof(Rec<W>)));
+	}
 
 	// 2. partition levels
 	int cur = 0;                                      // buf[cur] holds the level's input (level 0 of received records: ext)
@@ -2284,8 +2290,7 @@ static int bloom_xor(rg_handle *h, Table &T, uint64_t m_bits, uint64_t keys, boo
 	uint32_t *ix = nullptr, *d_tile = nullptr;
 	uint8_t *d_side = nullptr, *d_lost = nullptr;
 	auto cleanup = [&]() {
-		pool_free(dev, A);
-		pool_free(dev, Bb);
+		pool_free(dev, A);  // Bb is its second half
 		if ((void *)pk != (void *)A) {
 			pool_free(dev, pk);
 			pool_free(dev, ix);
@@ -2305,8 +2310,8 @@ static int bloom_xor(rg_handle *h, Table &T, uint64_t m_bits, uint64_t keys, boo
 	// with a middle level the last one reads Bb and A is free by then: the packed words and slot indices (12 B per position)
 	// take its place (16 B per key) when they fit -- at C5's share per GPU (3.5e9 keys) that is 42 GB less at the peak
 	const bool alias = c2 && npos_cap * 12 + 256 <= keys * sizeof(Item16);
-	hipError_t e = pool_alloc(dev, (void **)&A, keys * sizeof(Item16));
-	if (e == hipSuccess && c2) e = pool_alloc(dev, (void **)&Bb, keys * sizeof(Item16));
+	hipError_t e = pool_alloc(dev, (void **)&A, (c2 ? 2 : 1) * keys * sizeof(Item16));  // both item buffers in one block (see build_table_ranges)
+	if (e == hipSuccess && c2) Bb = A + keys;
 	if (alias) {
 		pk = (unsigned long long *)A;
 		ix = (uint32_t *)((uint8_t *)A + ((npos_cap * 8 + 255) & ~255ull));
@@ -2482,8 +2487,10 @@ __global__ __launch_bounds__(256) void k_adopt_entries(const Slot *__restrict__ 
 	for (; i < n; i += stride) {
 		const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(&in[i].k0), b = *reinterpret_cast<const ulonglong2 *>(&in[i].stamp);
 		if (a.x == EMPTY || !(b.y & LOG_UNIQUE)) bad++;
-		*reinterpret_cast<ulonglong2 *>(&out[i].k0) = a;
-		*reinterpret_cast<ulonglong2 *>(&out[i].stamp) = b;
+		if (out) {  // no copy: the caller's buffer itself becomes the log (rg_adopt_entries)
+			*reinterpret_cast<ulonglong2 *>(&out[i].k0) = a;
+			*reinterpret_cast<ulonglong2 *>(&out[i].stamp) = b;
+		}
 	}
 	if (bad) atomicAdd(&counters[C_ADOPT_BAD], (unsigned long long)bad);
 }
@@ -2502,8 +2509,9 @@ static int materialize_pending_log(rg_handle *h) {
 	}
 	if (hipGetLastError() != hipSuccess) return fail(h, RG_ERR_HIP, "k_merge launch failed");
 	rc = sync_counters(h);
-	pool_free(h->cfg.device, h->pending_log);
+	pool_free(h->cfg.device, h->pending_log);  // (a borrowed buffer is not the pool's: nothing happens)
 	h->pending_log = nullptr;
+	h->pending_borrowed = false;
 	h->pending_n = 0;
 	if (rc) return rc;
 	T.fill_known = h->h_counters[C_FILL];
@@ -2570,8 +2578,7 @@ static int build_table_ranges(rg_handle *h, const Slot *log, uint64_t n_log, uin
 	uint8_t *d_side = nullptr;
 	const uint64_t ovf_cap = retained / 16 + 4096;
 	auto cleanup = [&]() {
-		pool_free(dev, buf[0]);
-		pool_free(dev, buf[1]);
+		pool_free(dev, buf[0]);  // buf[1] is its second half
 		pool_free(dev, ovf);
 		pool_free(dev, d_seg);
 		pool_free(dev, d_hist);
@@ -2582,8 +2589,10 @@ static int build_table_ranges(rg_handle *h, const Slot *log, uint64_t n_log, uin
 	};
 	const uint64_t SEGMAX = 65536;
 	hipError_t e = pool_alloc(dev, (void **)&tab, cap * sizeof(Slot));
-	if (e == hipSuccess) e = pool_alloc(dev, (void **)&buf[0], retained * sizeof(Slot));
-	if (e == hipSuccess && nlev > 1) e = pool_alloc(dev, (void **)&buf[1], retained * sizeof(Slot));
+	// the two entry buffers are one block: a few large blocks of the same sizes every time are what the pool can hand out
+	// again when the device is nearly full (C5's share per GPU), where many middling ones go back to the driver and return
+	if (e == hipSuccess) e = pool_alloc(dev, (void **)&buf[0], (nlev > 1 ? 2 : 1) * retained * sizeof(Slot));
+	if (e == hipSuccess && nlev > 1) buf[1] = buf[0] + retained;
 	if (e == hipSuccess) e = pool_alloc(dev, (void **)&ovf, ovf_cap * sizeof(Slot));
 	if (e == hipSuccess) e = pool_alloc(dev, (void **)&d_seg, (SEGMAX + 1) * sizeof(unsigned long long));
 	if (e == hipSuccess) e = pool_alloc(dev, (void **)&d_tile, (SEGMAX + 1) * sizeof(uint32_t));
@@ -3157,6 +3166,53 @@ int rg_merge_entries(rg_handle *h, const void *d_entries, uint64_t n_entries) {
 	return RG_OK;
 }
 
+int rg_release_local(rg_handle *h) {
+	if (!h) return RG_ERR_ARG;
+	if (h->phase == PH_MERGING) return RG_OK;  // already released (by this call or by the first rg_merge_entries)
+	if (h->phase != PH_COUNTED_LOCAL) return fail(h, RG_ERR_STATE, "rg_release_local needs rg_count_local / rg_count_records first");
+	if (h->cfg.size == 1 && !h->local.slots) return fail(h, RG_ERR_STATE, "rg_release_local: on one rank the local table is the partition");
+	HIP_TRY(h, hipSetDevice(h->cfg.device));
+	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	h->owner_counts_valid = false;
+	table_free(h, h->local);
+	h->phase = PH_MERGING;
+	return RG_OK;
+}
+
+int rg_adopt_entries(rg_handle *h, void *d_entries, uint64_t n_entries) {
+	if (h) h->hist_valid = false;
+	if (!h) return RG_ERR_ARG;
+	if (h->phase != PH_COUNTED_LOCAL && h->phase != PH_MERGING) return fail(h, RG_ERR_STATE, "rg_adopt_entries needs rg_count_local first");
+	if (n_entries && !d_entries) return fail(h, RG_ERR_ARG, "null entries");
+	HIP_TRY(h, hipSetDevice(h->cfg.device));
+	// in place only where rg_merge_entries would keep a copy as the log: first and only delivery, every entry a distinct key
+	bool in_place = n_entries > 0 && !h->tab.slots && !h->pending_log && !h->merge_started && n_entries < (1ull << 32) && !(h->dbg & 0x80000) &&
+	                (h->cfg.size > 1 || h->local.slots || h->phase == PH_MERGING);
+	if (in_place) {
+		hipError_t e = hipMemsetAsync(h->d_counters + C_ADOPT_BAD, 0, sizeof(unsigned long long), h->stream);
+		if (e == hipSuccess) {
+			ProfScope ps(h, "k_adopt_entries");
+			hipLaunchKernelGGL(k_adopt_entries, dim3(grid_for(n_entries)), dim3(BLOCK), 0, h->stream, (const Slot *)d_entries, n_entries, (Slot *)nullptr, h->d_counters);
+			e = hipGetLastError();
+		}
+		const int rc0 = e == hipSuccess ? sync_counters(h) : fail(h, RG_ERR_HIP, "k_adopt_entries: %s", hipGetErrorString(e));
+		if (rc0) return rc0;
+		in_place = h->h_counters[C_ADOPT_BAD] == 0;
+	}
+	if (!in_place) return rg_merge_entries(h, d_entries, n_entries);  // copies what it needs: the buffer is the caller's again on return
+	h->owner_counts_valid = false;
+	if (h->phase == PH_COUNTED_LOCAL) {
+		table_free(h, h->local);
+		h->phase = PH_MERGING;
+	}
+	h->merge_started = true;
+	h->pending_log = (Slot *)d_entries;  // pool_free ignores pointers the pool did not hand out: the buffer stays the caller's
+	h->pending_borrowed = true;
+	h->pending_n = h->pending_keys = n_entries;
+	if (getenv("RG_DEBUG")) fprintf(stderr, "[raygraph] rank %d: %llu received entries admitted in the caller's buffer\n", h->cfg.rank, (unsigned long long)n_entries);
+	return RG_OK;
+}
+
 int rg_resolve_admission(rg_handle *h, uint64_t local_reads_for_bloom) {
 	if (h) h->hist_valid = false;
 	if (!h) return RG_ERR_ARG;
@@ -3284,8 +3340,9 @@ int rg_resolve_admission(rg_handle *h, uint64_t local_reads_for_bloom) {
 			if (hipGetLastError() != hipSuccess) rc = fail(h, RG_ERR_HIP, "k_insert_admitted launch failed");
 		}
 		if (rc == RG_OK) rc = sync_counters(h);
-		pool_free(h->cfg.device, h->pending_log);
+		pool_free(h->cfg.device, h->pending_log);  // (a borrowed buffer is not the pool's: nothing happens)
 		h->pending_log = nullptr;
+		h->pending_borrowed = false;
 		h->pending_n = 0;
 		if (rc) return rc;
 		if (h->h_counters[C_FILL] != retained) return fail(h, RG_ERR_STATE, "inserted %llu of %llu admitted vertices", (unsigned long long)h->h_counters[C_FILL], (unsigned long long)retained);

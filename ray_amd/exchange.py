@@ -50,6 +50,8 @@ def exchange_owner_buckets(engine, group=None, device="cuda", always=False):
     total = sum(counts)
     send = torch.empty(max(1, total) * RG_ENTRY_BYTES, dtype=torch.uint8, device=device)
     engine.export_owner_buckets(send.data_ptr(), max(1, total))
+    if hasattr(engine, "release_local"):
+        engine.release_local()   # the buckets hold everything the local aggregation knew: its memory is free for the receive buffer
     staged = _staged(group) and str(device) != "cpu"
     xdev = "cpu" if staged else device
     send_counts = torch.tensor(counts, dtype=torch.int64, device=xdev)
@@ -64,7 +66,11 @@ def exchange_owner_buckets(engine, group=None, device="cuda", always=False):
         recv = recv.to(device)
     if str(device) != "cpu":
         torch.cuda.current_stream().synchronize()
-    engine.merge_entries(recv.data_ptr(), n_recv)
+    del send, src
+    if hasattr(engine, "adopt_entries"):
+        engine.adopt_entries(recv.data_ptr(), n_recv, keepalive=recv)   # no copy: admission runs in the receive buffer
+    else:
+        engine.merge_entries(recv.data_ptr(), n_recv)
     return total, n_recv
 
 

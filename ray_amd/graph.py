@@ -232,8 +232,18 @@ class GraphBuilder:
     def merge_entries(self, device_ptr, n_entries):
         self._check(self._L.rg_merge_entries(self._h, device_ptr, n_entries))
 
+    def release_local(self):
+        self._check(self._L.rg_release_local(self._h))
+
+    def adopt_entries(self, device_ptr, n_entries, keepalive=None):
+        """rg_adopt_entries: admission runs in the caller's buffer; `keepalive` (the tensor that owns it) is held until
+        resolve_admission has returned"""
+        self._check(self._L.rg_adopt_entries(self._h, device_ptr, n_entries))
+        self._borrowed = keepalive
+
     def resolve_admission(self, local_reads=UINT64_MAX):
         self._check(self._L.rg_resolve_admission(self._h, local_reads))
+        self._borrowed = None
 
     # -- histogram / pass 2 / purge
     def histogram(self):

@@ -16,7 +16,8 @@ def run_ranks(packed, offsets, lengths, k, nranks, bloom, W=0, sweep=0, route="e
     """route "entries": every rank aggregates its own reads, then the entries go to their owners;
     route "records": the super-k-mer records go to the rank that aggregates their bucket first (the preferred
     multi-GPU route), then the entries go to their owners.
-    one_merge: an owner gets everything it receives in ONE rg_merge_entries call, as exchange_owner_buckets delivers it
+    one_merge: an owner gets everything it receives in ONE rg_merge_entries call ("adopt": one rg_adopt_entries call after
+    rg_release_local, as exchange_owner_buckets delivers it: no copy, admission runs in the receive buffer)
     (record route: the entries are unique and are kept as a log that is admitted before anything is inserted);
     otherwise one call per source rank (the first is kept as a log, the second sends it to the table: classic merge)"""
     import torch
@@ -57,6 +58,8 @@ def run_ranks(packed, offsets, lengths, k, nranks, bloom, W=0, sweep=0, route="e
         buf = torch.empty(max(1, sum(counts)) * RG_ENTRY_BYTES, dtype=torch.uint8, device="cuda")
         b.export_owner_buckets(buf.data_ptr(), max(1, sum(counts)))
         torch.cuda.synchronize()
+        if one_merge == "adopt":
+            b.release_local()   # the aggregation goes before the exchange, not at the first delivery
         sends.append((counts, buf))
     for dst, b in enumerate(builders):
         got = []
@@ -70,7 +73,10 @@ def run_ranks(packed, offsets, lengths, k, nranks, bloom, W=0, sweep=0, route="e
         if one_merge:
             allgot = torch.cat(got)
             torch.cuda.synchronize()
-            b.merge_entries(allgot.data_ptr() if allgot.numel() else 0, allgot.numel() // RG_ENTRY_BYTES)
+            if one_merge == "adopt":   # admission in the receive buffer itself
+                b.adopt_entries(allgot.data_ptr() if allgot.numel() else 0, allgot.numel() // RG_ENTRY_BYTES, keepalive=allgot)
+            else:
+                b.merge_entries(allgot.data_ptr() if allgot.numel() else 0, allgot.numel() // RG_ENTRY_BYTES)
     for r, b in enumerate(builders):
         first, last = partition_reads(n, r, nranks)
         b.resolve_admission(last - first)
@@ -85,7 +91,8 @@ def test_multirank_matches_oracle(oracle, k, nranks, bloom):
     want = oracle_run(oracle, packed, offsets, lengths, k, nranks, bloom)
     for sweep, route, parts, one in ((1 | 16 | (17 << 8), "entries", 1, False), (2 | 32, "entries", 1, True), (1 | 16 | (10 << 8), "records", 1, True),
                                      (1 | 32 | (10 << 8), "records", 1, True), (1 | 16 | (10 << 8) | 0x80000, "records", 1, True),
-                                     (1 | 16 | (10 << 8), "records", 3, False), (1 | 16 | 0x2000000, "records", 1, True), (2 | 32, "records", 1, False)):
+                                     (1 | 16 | (10 << 8), "records", 3, False), (1 | 16 | 0x2000000, "records", 1, True), (1 | 16 | (11 << 8), "records", 2, "adopt"),
+                                     (1 | 32 | (9 << 8), "entries", 1, "adopt"), (2 | 32, "records", 1, False)):
         builders = run_ranks(packed, offsets, lengths, k, nranks, bloom, sweep=sweep, route=route, parts=parts, one_merge=one)
         check_ranks(builders, want, route)
     # SequencesIndexer's markers across ranks (IndexerWorker.cpp:67-248): k-mers to their owners, coverages back
