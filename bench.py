@@ -352,6 +352,7 @@ def main():
             "bloom_stamp_fill": st["bloom_bits"] * 8,
             "k_histogram": st["table_slots"] * 32,
             "k_entry_hist": st["log_entries"] * 32,                                                  # log scan
+            "k_admit_count": st["log_entries"] * 33,                                                 # log scan + one mark byte per entry, nothing written
             "k_scatter_entries": st["log_entries"] * 32 + st["stored_pairs"] * 32,                   # first level: log in, admitted entries out (further levels added below)
             "k_build_ranges": st["stored_pairs"] * 32 + st["table_slots"] * 32,                      # entries in, every slot of the table written once
             "k_xor_hist": (st["log_entries"] if "k_build_ranges" in kprof or "k_insert_admitted" in kprof else st["table_slots"]) * 32,

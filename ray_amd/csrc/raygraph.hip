@@ -324,12 +324,6 @@ __device__ __forceinline__ void hist_add(uint32_t *s_h, uint64_t cov, unsigned l
 		if (pos < HIST_OVF_CAP) ovf[pos] = (uint32_t)cov;
 	}
 }
-// final state of a slot after admission: coverage in the count field, the edge bits gathered during the sweep moved
-// to the published field (rg_add_edges only makes them visible: the bits themselves are final once pass 1 ends)
-__device__ __forceinline__ uint64_t admitted_meta(uint64_t meta, uint64_t cov) {
-	const uint64_t pend = (meta >> PEND_SHIFT) & 0xFFull;
-	return (meta & ~COUNT_MASK & ~(0xFFull << PUB_SHIFT)) | cov | (pend << PUB_SHIFT);
-}
 
 template <int W, bool BLOOM>
 __global__ __launch_bounds__(BLOCK) void k_admit(Slot *__restrict__ tab, uint64_t cap, uint64_t m_bits,
@@ -384,12 +378,18 @@ __global__ __launch_bounds__(BLOCK) void k_admit(Slot *__restrict__ tab, uint64_
 
 // A7 with the "lost" marks of rg_bloom.h: a key whose 8 bit checks all found the bit set earlier is a
 // false positive
-template <int W>
+// WRITE: the coverage goes into the slot (admission in place); otherwise the pass only counts -- vertices stored, Bloom
+// insertions, the coverage histogram and, per top byte of the slot hash, the admitted entries (first_hist: the first
+// level of the table partition, rg_table.h) -- and the kernels that read the log next apply the rule again.
+// STATS == false: only the write (the fallback after a counting pass).
+template <int W, bool WRITE = true, bool STATS = true>
 __global__ __launch_bounds__(BLOCK) void k_admit_lost(Slot *__restrict__ tab, uint64_t cap, const uint32_t *__restrict__ lost,
                                                       unsigned long long *__restrict__ counters, unsigned long long *__restrict__ hist_dense,
-                                                      uint32_t *__restrict__ hist_ovf) {
+                                                      uint32_t *__restrict__ hist_ovf, unsigned long long *__restrict__ first_hist = nullptr) {
 	__shared__ uint32_t s_h[HIST_LDS];
+	__shared__ uint32_t s_first[256];
 	for (uint32_t j = threadIdx.x; j < HIST_LDS; j += blockDim.x) s_h[j] = 0;
+	if (threadIdx.x < 256) s_first[threadIdx.x] = 0;
 	__syncthreads();
 	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -407,9 +407,11 @@ __global__ __launch_bounds__(BLOCK) void k_admit_lost(Slot *__restrict__ tab, ui
 		}
 		if (cov > 0xFFFFFFFFull) cov = 0xFFFFFFFFull;
 		if (cov) retained++;
-		tab[i].meta = admitted_meta(v.meta, cov);
-		hist_add(s_h, cov, hist_dense, hist_ovf, counters);
+		if (WRITE) tab[i].meta = admitted_meta(v.meta, cov);
+		if (STATS) hist_add(s_h, cov, hist_dense, hist_ovf, counters);
+		if (!WRITE && cov) atomicAdd(&s_first[(uint32_t)(slot_hash<W>(v.k0, W == 2 ? v.k1 : 0) >> 56)], 1u);
 	}
+	if (!STATS) return;
 	for (int d = 32; d > 0; d >>= 1) {
 		retained += __shfl_down(retained, d);
 		inserted += __shfl_down(inserted, d);
@@ -421,6 +423,7 @@ __global__ __launch_bounds__(BLOCK) void k_admit_lost(Slot *__restrict__ tab, ui
 	__syncthreads();
 	for (uint32_t j = threadIdx.x; j < HIST_LDS; j += blockDim.x)
 		if (s_h[j]) atomicAdd(&hist_dense[j], (unsigned long long)s_h[j]);
+	if (!WRITE && first_hist && threadIdx.x < 256 && s_first[threadIdx.x]) atomicAdd(&first_hist[threadIdx.x], (unsigned long long)s_first[threadIdx.x]);
 }
 
 // A12: coverage histogram of the stored pairs.  Low coverages are binned in LDS per workgroup.
@@ -2248,7 +2251,9 @@ static int bloom_partitioned(rg_handle *h, Table &T, uint64_t m_bits, uint64_t k
 
 // ---- Bloom admission for power-of-two filters at any fill (rg_bloomx.h) ------------------------------------
 // *ok = false: not applicable (filter size not a power of two, no memory); the caller then uses another method.
-static int bloom_xor(rg_handle *h, Table &T, uint64_t m_bits, uint64_t keys, bool *ok) {
+// keep_lost != nullptr: the admission kernel is not run; the marks (one byte per slot of T, 8 = false positive) are handed to
+// the caller, who admits while building the table and frees them with pool_free.
+static int bloom_xor(rg_handle *h, Table &T, uint64_t m_bits, uint64_t keys, bool *ok, uint8_t **keep_lost = nullptr) {
 	*ok = false;
 	const int dev = h->cfg.device;
 	if (m_bits == 0 || (m_bits & (m_bits - 1)) || T.cap >= (1ull << 32) || keys == 0) return RG_OK;
@@ -2460,7 +2465,7 @@ static int bloom_xor(rg_handle *h, Table &T, uint64_t m_bits, uint64_t keys, boo
 		hipLaunchKernelGGL(k_xor_fp, dim3(grid_for(npos_cap)), dim3(256), 0, h->stream, pk, ix, planes, plane_words, npos_cap, d_lost);
 		XTRY(hipGetLastError());
 	}
-	{
+	if (!keep_lost) {
 		ProfScope ps(h, "k_admit");
 		const int grid = grid_for(T.cap);
 		if (h->W == 1) hipLaunchKernelGGL(k_admit_lost<1>, dim3(grid), dim3(BLOCK), 0, h->stream, T.slots, T.cap, (const uint32_t *)d_lost, h->d_counters, h->d_hist_dense, h->d_hist_ovf);
@@ -2468,6 +2473,10 @@ static int bloom_xor(rg_handle *h, Table &T, uint64_t m_bits, uint64_t keys, boo
 		XTRY(hipGetLastError());
 	}
 	XTRY(hipStreamSynchronize(h->stream));
+	if (keep_lost) {
+		*keep_lost = d_lost;
+		d_lost = nullptr;
+	}
 	if (getenv("RG_DEBUG"))
 		fprintf(stderr, "[raygraph] Bloom by key partitions: %llu keys, 2^%d bits, %llu partitions (levels %d+%d+%d bits), regions of 2^%d bits\n",
 		        (unsigned long long)keys, B, (unsigned long long)P, c1, c2, c3, R);
@@ -2550,7 +2559,11 @@ static int collect_histogram(rg_handle *h, const unsigned long long *dense, cons
 
 // ---- the vertex table from the admitted entries of a log, range by range (rg_table.h) ---------------------
 // *done = false: not applicable (too few entries, no memory, overflow list full); the caller then inserts the classic way.
-static int build_table_ranges(rg_handle *h, const Slot *log, uint64_t n_log, uint64_t retained, bool *done) {
+// lost != nullptr: the log is as the sweep wrote it, lost[i] is entry i's mark and first_hist the admitted entries per top byte
+// of the slot hash (k_admit_lost<W, false>): the first partition level applies the admission rule to what it reads.
+// lost == nullptr: the log was admitted in place.
+static int build_table_ranges(rg_handle *h, const Slot *log, uint64_t n_log, uint64_t retained, bool *done, const uint8_t *lost = nullptr,
+                              const unsigned long long *first_hist = nullptr) {
 	*done = false;
 	const int dev = h->cfg.device;
 	Table &T = h->tab;
@@ -2558,18 +2571,19 @@ static int build_table_ranges(rg_handle *h, const Slot *log, uint64_t n_log, uin
 	uint64_t cap = (uint64_t)((double)retained / 0.7) + 1;
 	if (cap < 4096) cap = 4096;
 	if (h->cfg.table_slots > cap) cap = h->cfg.table_slots;
-	// ranges of 2048 slots while two partition levels reach them, of 4096 beyond
-	int span_log2 = 11;
-	if (((cap + 2047) >> 11) > 65536) span_log2 = 12;
-	const uint64_t NR = (cap + (1ull << span_log2) - 1) >> span_log2;
-	if (NR >= (1ull << 24)) return RG_OK;
-	int bits = 1;
-	while ((1ull << bits) < NR) bits++;
-	const int nlev = bits <= 8 ? 1 : (bits <= 16 ? 2 : 3);
-	int dbits[3] = {0, 0, 0};
-	for (int l = 0, left = bits; l < nlev; ++l) {
-		dbits[l] = left / (nlev - l);
-		left -= dbits[l];
+	// 2^bits ranges of the slot hash, each at most RANGE_SPAN_MAX slots; the first level always takes the top 8 bits (what the
+	// admission pass counted before the capacity was known), the rest is split over one or two more
+	int bits = 8;
+	while (bits < 25 && (cap >> bits) >= RANGE_SPAN_MAX) bits++;
+	if (bits > 24) return RG_OK;
+	const uint64_t NR = 1ull << bits;
+	const int rem = bits - 8;
+	const int nlev = 1 + (rem > 0 ? 1 : 0) + (rem > 8 ? 1 : 0);
+	int dbits[3] = {8, 0, 0};
+	if (nlev == 2) dbits[1] = rem;
+	if (nlev == 3) {
+		dbits[1] = rem / 2;
+		dbits[2] = rem - dbits[1];
 	}
 	const uint64_t NBUCK = 1ull << bits;
 	Slot *tab = nullptr, *buf[2] = {nullptr, nullptr}, *ovf = nullptr;
@@ -2636,11 +2650,13 @@ static int build_table_ranges(rg_handle *h, const Slot *log, uint64_t n_log, uin
 		TTRY(hipMemcpyAsync(d_tile, tile_first.data(), (S + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
 		const uint64_t nout = (uint64_t)S << db;
 		TTRY(hipMemsetAsync(d_hist, 0, nout * sizeof(unsigned long long), h->stream));
-		if (level == 0) {
+		if (level == 0 && first_hist) {
+			TTRY(hipMemcpyAsync(d_hist, first_hist, 256 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, h->stream));
+		} else if (level == 0) {
 			ProfScope ps(h, "k_entry_hist");
 			const int grid = (int)std::min<uint64_t>(2048, (n_log + 255) / 256);
-			if (h->W == 1) hipLaunchKernelGGL(k_entry_hist<1>, dim3(grid), dim3(256), 0, h->stream, log, n_log, cap, span_log2, shift, (1u << db) - 1u, d_hist);
-			else hipLaunchKernelGGL(k_entry_hist<2>, dim3(grid), dim3(256), 0, h->stream, log, n_log, cap, span_log2, shift, (1u << db) - 1u, d_hist);
+			if (h->W == 1) hipLaunchKernelGGL(k_entry_hist<1>, dim3(grid), dim3(256), 0, h->stream, log, n_log, bits, shift, (1u << db) - 1u, d_hist);
+			else hipLaunchKernelGGL(k_entry_hist<2>, dim3(grid), dim3(256), 0, h->stream, log, n_log, bits, shift, (1u << db) - 1u, d_hist);
 		} else {
 			ProfScope ps(h, "k_level_hist_side");
 			hipLaunchKernelGGL(k_level_hist_side<ENT_TILE>, dim3((unsigned)ntiles), dim3(256), 0, h->stream, d_side, S, d_seg, d_tile, db, d_hist);
@@ -2658,11 +2674,11 @@ static int build_table_ranges(rg_handle *h, const Slot *log, uint64_t n_log, uin
 			uint8_t *side_out = have_next ? d_side : nullptr;
 			Slot *out = buf[cur];
 			if (h->W == 1) {
-				if (level == 0) hipLaunchKernelGGL((k_scatter_entries<1, true>), dim3((unsigned)ntiles), dim3(ENT_THREADS), 0, h->stream, level_in, S, d_seg, d_tile, cap, span_log2, shift, db, d_hist, out, side_out, shift - ndb, (1u << ndb) - 1u);
-				else hipLaunchKernelGGL((k_scatter_entries<1, false>), dim3((unsigned)ntiles), dim3(ENT_THREADS), 0, h->stream, level_in, S, d_seg, d_tile, cap, span_log2, shift, db, d_hist, out, side_out, shift - ndb, (1u << ndb) - 1u);
+				if (level == 0) hipLaunchKernelGGL((k_scatter_entries<1, true>), dim3((unsigned)ntiles), dim3(ENT_THREADS), 0, h->stream, level_in, S, d_seg, d_tile, bits, shift, db, d_hist, out, side_out, shift - ndb, (1u << ndb) - 1u, lost);
+				else hipLaunchKernelGGL((k_scatter_entries<1, false>), dim3((unsigned)ntiles), dim3(ENT_THREADS), 0, h->stream, level_in, S, d_seg, d_tile, bits, shift, db, d_hist, out, side_out, shift - ndb, (1u << ndb) - 1u, (const uint8_t *)nullptr);
 			} else {
-				if (level == 0) hipLaunchKernelGGL((k_scatter_entries<2, true>), dim3((unsigned)ntiles), dim3(ENT_THREADS), 0, h->stream, level_in, S, d_seg, d_tile, cap, span_log2, shift, db, d_hist, out, side_out, shift - ndb, (1u << ndb) - 1u);
-				else hipLaunchKernelGGL((k_scatter_entries<2, false>), dim3((unsigned)ntiles), dim3(ENT_THREADS), 0, h->stream, level_in, S, d_seg, d_tile, cap, span_log2, shift, db, d_hist, out, side_out, shift - ndb, (1u << ndb) - 1u);
+				if (level == 0) hipLaunchKernelGGL((k_scatter_entries<2, true>), dim3((unsigned)ntiles), dim3(ENT_THREADS), 0, h->stream, level_in, S, d_seg, d_tile, bits, shift, db, d_hist, out, side_out, shift - ndb, (1u << ndb) - 1u, lost);
+				else hipLaunchKernelGGL((k_scatter_entries<2, false>), dim3((unsigned)ntiles), dim3(ENT_THREADS), 0, h->stream, level_in, S, d_seg, d_tile, bits, shift, db, d_hist, out, side_out, shift - ndb, (1u << ndb) - 1u, (const uint8_t *)nullptr);
 			}
 		}
 		TTRY(hipGetLastError());
@@ -2684,15 +2700,16 @@ static int build_table_ranges(rg_handle *h, const Slot *log, uint64_t n_log, uin
 		ProfScope ps(h, "k_build_ranges");
 		int n_cu = 256;
 		(void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-		if (span_log2 == 11) {
-			const unsigned grid = (unsigned)std::min<uint64_t>(NR, (uint64_t)n_cu * 2);
-			if (h->W == 1) hipLaunchKernelGGL((k_build_ranges<1, 11>), dim3(grid), dim3(1024), 0, h->stream, level_in, d_begin, (uint32_t)NR, tab, cap, ovf, ovf_cap, h->d_counters);
-			else hipLaunchKernelGGL((k_build_ranges<2, 11>), dim3(grid), dim3(1024), 0, h->stream, level_in, d_begin, (uint32_t)NR, tab, cap, ovf, ovf_cap, h->d_counters);
-		} else {
-			const unsigned grid = (unsigned)std::min<uint64_t>(NR, (uint64_t)n_cu);
-			if (h->W == 1) hipLaunchKernelGGL((k_build_ranges<1, 12>), dim3(grid), dim3(1024), 0, h->stream, level_in, d_begin, (uint32_t)NR, tab, cap, ovf, ovf_cap, h->d_counters);
-			else hipLaunchKernelGGL((k_build_ranges<2, 12>), dim3(grid), dim3(1024), 0, h->stream, level_in, d_begin, (uint32_t)NR, tab, cap, ovf, ovf_cap, h->d_counters);
-		}
+		const size_t lds = (size_t)((cap >> bits) + 2) * sizeof(Slot);
+		const void *fn = h->W == 1 ? reinterpret_cast<const void *>(&k_build_ranges<1>) : reinterpret_cast<const void *>(&k_build_ranges<2>);
+		TTRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		int occ = 1;
+		if ((h->W == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_build_ranges<1>, 1024, lds)
+		               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_build_ranges<2>, 1024, lds)) != hipSuccess || occ < 1)
+			occ = 1;
+		const unsigned grid = (unsigned)std::min<uint64_t>(NR, (uint64_t)n_cu * occ);
+		if (h->W == 1) hipLaunchKernelGGL(k_build_ranges<1>, dim3(grid), dim3(1024), lds, h->stream, level_in, d_begin, (uint32_t)NR, bits, tab, cap, ovf, ovf_cap, h->d_counters);
+		else hipLaunchKernelGGL(k_build_ranges<2>, dim3(grid), dim3(1024), lds, h->stream, level_in, d_begin, (uint32_t)NR, bits, tab, cap, ovf, ovf_cap, h->d_counters);
 	}
 	TTRY(hipGetLastError());
 	int rc = sync_counters(h);
@@ -2721,8 +2738,8 @@ static int build_table_ranges(rg_handle *h, const Slot *log, uint64_t n_log, uin
 		}
 	}
 	if (getenv("RG_DEBUG"))
-		fprintf(stderr, "[raygraph] table of %llu slots built from %llu admitted entries in %llu ranges of %u slots (%d partition levels), %llu entries left their range\n",
-		        (unsigned long long)cap, (unsigned long long)retained, (unsigned long long)NR, 1u << span_log2, nlev, (unsigned long long)n_ovf);
+		fprintf(stderr, "[raygraph] table of %llu slots built from %llu admitted entries in %llu ranges of up to %u slots (%d partition levels), %llu entries left their range\n",
+		        (unsigned long long)cap, (unsigned long long)retained, (unsigned long long)NR, (unsigned)(cap >> bits) + 1u, nlev, (unsigned long long)n_ovf);
 	cleanup();
 	T.slots = tab;
 	T.cap = cap;
@@ -3263,6 +3280,8 @@ int rg_resolve_admission(rg_handle *h, uint64_t local_reads_for_bloom) {
 	h->stats.bloom_bits = m_bits;
 	const int grid = grid_for(T.cap);
 	bool resolved = false;
+	uint8_t *lost_kept = nullptr;             // marks of a Bloom resolution whose admission is deferred to the table build
+	unsigned long long *d_first_hist = nullptr;
 	if (m_bits > 0) {
 		// keys in the table decide the method: region partitioning when the filter stays sparse
 		// (8 touches per key), dense first-touch stamps otherwise.  rg_debug_set bit 4 forces the
@@ -3282,7 +3301,9 @@ int rg_resolve_admission(rg_handle *h, uint64_t local_reads_for_bloom) {
 		// against the regions' 15.4.  The (bit, key) items of rg_bloom.h remain for filters whose size is not a power of two.
 		(void)regions_cheap;
 		if (!(flags & 32u) && !(flags & 16u) && ((h->dbg & 0x1000000) || keys >= (1ull << 20))) {
-			rc0 = bloom_xor(h, T, m_bits, keys, &resolved);
+			// admission on a log whose table will be built range by range: the marks are kept, nothing is written into the log
+			const bool defer = from_log && !(h->dbg & 0x800000) && (keys >= (1ull << 20) || (h->dbg & 0x400000));
+			rc0 = bloom_xor(h, T, m_bits, keys, &resolved, defer ? &lost_kept : nullptr);
 			if (rc0) return rc0;
 			if (resolved) h->stats.bloom_partitioned = 2;
 		}
@@ -3322,8 +3343,27 @@ int rg_resolve_admission(rg_handle *h, uint64_t local_reads_for_bloom) {
 		else hipLaunchKernelGGL((k_admit<2, false>), dim3(grid), dim3(BLOCK), 0, h->stream, T.slots, T.cap, 0ull, (const unsigned long long *)nullptr, h->d_counters, h->d_hist_dense, h->d_hist_ovf);
 		HIP_TRY(h, hipGetLastError());
 	}
+	if (lost_kept) {  // the counting pass of the admission: statistics, histogram, first level of the table partition; the log stays as it is
+		hipError_t e = pool_alloc(h->cfg.device, (void **)&d_first_hist, 256 * sizeof(unsigned long long));
+		if (e == hipSuccess) e = hipMemsetAsync(d_first_hist, 0, 256 * sizeof(unsigned long long), h->stream);
+		if (e == hipSuccess) {
+			ProfScope ps(h, "k_admit_count");
+			if (h->W == 1) hipLaunchKernelGGL((k_admit_lost<1, false>), dim3(grid), dim3(BLOCK), 0, h->stream, T.slots, T.cap, (const uint32_t *)lost_kept, h->d_counters, h->d_hist_dense, h->d_hist_ovf, d_first_hist);
+			else hipLaunchKernelGGL((k_admit_lost<2, false>), dim3(grid), dim3(BLOCK), 0, h->stream, T.slots, T.cap, (const uint32_t *)lost_kept, h->d_counters, h->d_hist_dense, h->d_hist_ovf, d_first_hist);
+			e = hipGetLastError();
+		}
+		if (e != hipSuccess) {
+			pool_free(h->cfg.device, lost_kept);
+			pool_free(h->cfg.device, d_first_hist);
+			return fail(h, RG_ERR_HIP, "admission: %s", hipGetErrorString(e));
+		}
+	}
 	int rc = collect_histogram(h, h->d_hist_dense, h->d_hist_ovf);
-	if (rc) return rc;
+	if (rc) {
+		pool_free(h->cfg.device, lost_kept);
+		pool_free(h->cfg.device, d_first_hist);
+		return rc;
+	}
 	uint64_t candidates = h->h_counters[C_FILL];
 	if (from_log) {
 		candidates = h->pending_keys;
@@ -3331,7 +3371,20 @@ int rg_resolve_admission(rg_handle *h, uint64_t local_reads_for_bloom) {
 		// the table range by range, without global atomics (rg_debug_set bit 22 forces it on small inputs, bit 23 never: tests)
 		bool built = false;
 		if (!(h->dbg & 0x800000) && (retained >= (1ull << 20) || (h->dbg & 0x400000)))
-			rc = build_table_ranges(h, h->pending_log, h->pending_n, retained, &built);
+			rc = build_table_ranges(h, h->pending_log, h->pending_n, retained, &built, lost_kept, d_first_hist);
+		if (rc == RG_OK && !built && lost_kept) {  // the classic insert wants the log admitted in place: write what the counting pass left out
+			ProfScope ps(h, "k_admit");
+			if (h->W == 1) hipLaunchKernelGGL((k_admit_lost<1, true, false>), dim3(grid), dim3(BLOCK), 0, h->stream, T.slots, T.cap, (const uint32_t *)lost_kept, h->d_counters, (unsigned long long *)nullptr, (uint32_t *)nullptr);
+			else hipLaunchKernelGGL((k_admit_lost<2, true, false>), dim3(grid), dim3(BLOCK), 0, h->stream, T.slots, T.cap, (const uint32_t *)lost_kept, h->d_counters, (unsigned long long *)nullptr, (uint32_t *)nullptr);
+			if (hipGetLastError() != hipSuccess) rc = fail(h, RG_ERR_HIP, "k_admit_lost launch failed");
+		}
+		if (lost_kept) {
+			(void)hipStreamSynchronize(h->stream);
+			pool_free(h->cfg.device, lost_kept);
+			pool_free(h->cfg.device, d_first_hist);
+			lost_kept = nullptr;
+			d_first_hist = nullptr;
+		}
 		if (rc == RG_OK && !built) rc = table_reserve(h, h->tab, std::max<uint64_t>(1, retained), C_FILL);
 		if (rc == RG_OK && !built) {
 			ProfScope ps(h, "k_insert_admitted");

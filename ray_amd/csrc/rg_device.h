@@ -30,6 +30,13 @@ struct __attribute__((aligned(32))) Slot {
 };
 static_assert(sizeof(Slot) == 32, "slot must be one 32-byte sector");
 
+// final state of a slot after admission: coverage in the count field, the edge bits gathered during the sweep moved
+// to the published field (rg_add_edges only makes them visible: the bits themselves are final once pass 1 ends)
+__device__ __forceinline__ uint64_t admitted_meta(uint64_t meta, uint64_t cov) {
+	const uint64_t pend = (meta >> PEND_SHIFT) & 0xFFull;
+	return (meta & ~COUNT_MASK & ~(0xFFull << PUB_SHIFT)) | cov | (pend << PUB_SHIFT);
+}
+
 // ---- the reference's hashes, kept in one place (RayPlatform's crypto.cpp is absent,
 // these are the published Thomas Wang mixes it is recalled to use -- parity unpinned) ------------
 __host__ __device__ inline uint64_t mix1(uint64_t key) {  // uniform_hashing_function_1_64_64

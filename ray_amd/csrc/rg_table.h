@@ -6,8 +6,13 @@
 // keys, so nothing has to be atomic if one workgroup owns a whole stretch of the table:
 //
 //   k_entry_hist + k_scatter_entries   the admitted entries are partitioned by the table range their home slot
-//                   lies in (range = home slot >> SPAN_LOG2; one to three levels of at most 8 bits, tile-local
-//                   counting sort in LDS, runs out -- the scheme of k_scatter, on 32-byte entries)
+//                   lies in.  A range is a stretch of the *hash*: range = top `bits` bits of slot_hash, whose slots are
+//                   [umulhi(r << (64 - bits), cap), umulhi((r + 1) << (64 - bits), cap)) -- at most 4096 of them -- so
+//                   the partition (two or three levels of at most 8 bits, tile-local counting sort in LDS, runs out: the
+//                   scheme of k_scatter on 32-byte entries) does not depend on the capacity, and its first level can be
+//                   counted before the number of admitted vertices, hence the capacity, is known: by the admission pass
+//                   itself (k_admit_hist, raygraph.hip), which then need not write the log at all -- the first level
+//                   applies the admission rule again to what it reads (`lost` != nullptr)
 //   k_build_ranges  one workgroup per range: the range's slots are filled in LDS (linear probing inside the
 //                   range, LDS compare-and-swap), then written out once, free slots included -- no k_init_table,
 //                   every byte of the table is written exactly once, coalesced
@@ -25,36 +30,50 @@ static constexpr int ENT_THREADS = 512;
 
 enum TableCounter { TC_OVF_CURSOR = 27, TC_OVF_LOST = 28 };
 
-// range index of an entry: the bits above SPAN_LOG2 of its home slot
+// range index of an entry: the top `bits` bits of its slot hash
 template <int W>
-__device__ __forceinline__ uint32_t entry_range(const Slot &v, uint64_t cap, int span_log2) {
-	return (uint32_t)(slot_home(slot_hash<W>(v.k0, W == 2 ? v.k1 : 0), cap) >> span_log2);
+__device__ __forceinline__ uint32_t entry_range(const Slot &v, int bits) {
+	return (uint32_t)(slot_hash<W>(v.k0, W == 2 ? v.k1 : 0) >> (64 - bits));
 }
 
 __device__ __forceinline__ bool entry_admitted(const Slot &v) { return v.k0 != EMPTY && (v.meta & COUNT_MASK) != 0; }
 
-// first level's digit histogram: admitted entries of the log per top digit
+// an entry of the log as admission leaves it, from the entry as the sweep wrote it and its "lost" mark (the rule of
+// k_admit_lost: MessageProcessor.cpp:741-804); false = not stored
+__device__ __forceinline__ bool admit_entry(Slot &v, const uint8_t *__restrict__ lost, uint64_t i) {
+	if (v.k0 == EMPTY) return false;
+	const uint64_t N = v.meta & COUNT_MASK & ~LOG_UNIQUE;
+	uint64_t cov = (lost[i] == 8) ? N + 1 : (N >= 2 ? N : 0);
+	if (cov > 0xFFFFFFFFull) cov = 0xFFFFFFFFull;
+	if (cov == 0) return false;
+	v.meta = admitted_meta(v.meta, cov);
+	return true;
+}
+
+// first level's digit histogram: admitted entries of the log (admitted in place) per top digit
 template <int W>
-__global__ __launch_bounds__(256) void k_entry_hist(const Slot *__restrict__ in, uint64_t n, uint64_t cap, int span_log2, int shift, uint32_t dmask,
+__global__ __launch_bounds__(256) void k_entry_hist(const Slot *__restrict__ in, uint64_t n, int bits, int shift, uint32_t dmask,
                                                     unsigned long long *__restrict__ hist) {
 	__shared__ uint32_t s_cnt[256];
 	s_cnt[threadIdx.x] = 0;
 	__syncthreads();
 	for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
 		const Slot v = in[i];
-		if (entry_admitted(v)) atomicAdd(&s_cnt[(entry_range<W>(v, cap, span_log2) >> shift) & dmask], 1u);
+		if (entry_admitted(v)) atomicAdd(&s_cnt[(entry_range<W>(v, bits) >> shift) & dmask], 1u);
 	}
 	__syncthreads();
 	if (s_cnt[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
 }
 
-// One partition level of 32-byte entries (see k_scatter for the scheme).  FIRST: the input is the log of the sweep after
-// admission -- unused chunk entries and entries that were not admitted are dropped here.
+// One partition level of 32-byte entries (see k_scatter for the scheme).  FIRST: the input is the log of the sweep --
+// unused chunk entries and entries that are not admitted are dropped here; lost != nullptr: the log is as the sweep wrote
+// it and the admission rule is applied on the way (lost[i] = the mark of entry i), lost == nullptr: admitted in place.
 template <int W, bool FIRST>
 __global__ __launch_bounds__(ENT_THREADS) void k_scatter_entries(const Slot *__restrict__ in, uint32_t S, const unsigned long long *__restrict__ seg_begin,
-                                                                 const uint32_t *__restrict__ tile_first, uint64_t cap, int span_log2, int shift, int dbits,
+                                                                 const uint32_t *__restrict__ tile_first, int bits, int shift, int dbits,
                                                                  unsigned long long *__restrict__ cursors, Slot *__restrict__ out,
-                                                                 uint8_t *__restrict__ side, int next_shift, uint32_t next_mask) {
+                                                                 uint8_t *__restrict__ side, int next_shift, uint32_t next_mask,
+                                                                 const uint8_t *__restrict__ lost) {
 	constexpr int PER = ENT_TILE / ENT_THREADS;
 	__shared__ Slot s_ent[ENT_TILE];
 	__shared__ uint8_t s_dig[ENT_TILE], s_next[ENT_TILE];
@@ -86,8 +105,10 @@ __global__ __launch_bounds__(ENT_THREADS) void k_scatter_entries(const Slot *__r
 			mine[j].k1 = a.y;
 			mine[j].stamp = b.x;
 			mine[j].meta = b.y;
-			if (!FIRST || entry_admitted(mine[j])) {
-				const uint32_t r = entry_range<W>(mine[j], cap, span_log2);
+			bool keep = true;
+			if (FIRST) keep = lost ? admit_entry(mine[j], lost, i) : entry_admitted(mine[j]);
+			if (keep) {
+				const uint32_t r = entry_range<W>(mine[j], bits);
 				dig[j] = (r >> shift) & dmask;
 				nxt[j] = (r >> next_shift) & next_mask;
 				rank[j] = atomicAdd(&s_cnt[dig[j]], 1u);
@@ -142,20 +163,23 @@ __global__ __launch_bounds__(ENT_THREADS) void k_scatter_entries(const Slot *__r
 	}
 }
 
-// One workgroup per table range of SPAN slots: fill it in LDS, write it out whole.  range_begin[r] .. range_begin[r+1] are
-// the entries whose home slot lies in range r.  An entry that finds no free slot between its home and the end of the range
-// goes to the overflow list (ovf, at most ovf_cap entries; beyond that TC_OVF_LOST counts and the host rebuilds the
-// classic way).
-template <int W, int SPAN_LOG2>
+// One workgroup per table range (at most SPAN_MAX slots): fill it in LDS, write it out whole.  range_begin[r] ..
+// range_begin[r+1] are the entries whose slot hash has r in its top `bits` bits; their home slots lie in
+// [lo(r), lo(r+1)] with lo(r) = umulhi(r << (64 - bits), cap) -- the slot lo(r+1) itself belongs to the next range (a slot
+// that the boundary between two ranges cuts).  An entry that finds no free slot between its home and the end of the range
+// goes to the overflow list (ovf, at most ovf_cap entries; beyond that TC_OVF_LOST counts and the host rebuilds the classic
+// way).
+static constexpr uint32_t RANGE_SPAN_MAX = 4096;
+template <int W>
 __global__ __launch_bounds__(1024) void k_build_ranges(const Slot *__restrict__ entries, const unsigned long long *__restrict__ range_begin,
-                                                       uint32_t nranges, Slot *__restrict__ tab, uint64_t cap, Slot *__restrict__ ovf,
+                                                       uint32_t nranges, int bits, Slot *__restrict__ tab, uint64_t cap, Slot *__restrict__ ovf,
                                                        uint64_t ovf_cap, unsigned long long *__restrict__ counters) {
-	constexpr uint32_t SPAN = 1u << SPAN_LOG2;
-	__shared__ Slot s_tab[SPAN];
+	extern __shared__ Slot s_tab[];  // the largest span of this table: (cap >> bits) + 1 slots (two workgroups per CU up to 2560)
 	uint32_t placed = 0;
 	for (uint32_t r = blockIdx.x; r < nranges; r += gridDim.x) {
-		const uint64_t lo = (uint64_t)r << SPAN_LOG2;
-		const uint32_t span = (cap - lo < SPAN) ? (uint32_t)(cap - lo) : SPAN;
+		const uint64_t lo = slot_home((uint64_t)r << (64 - bits), cap);
+		const uint64_t hi = (r + 1 == nranges) ? cap : slot_home((uint64_t)(r + 1) << (64 - bits), cap);
+		const uint32_t span = (uint32_t)(hi - lo);  // <= RANGE_SPAN_MAX: the host picks `bits` for that
 		for (uint32_t i = threadIdx.x; i < span; i += blockDim.x) {
 			*reinterpret_cast<ulonglong2 *>(&s_tab[i].k0) = make_ulonglong2(EMPTY, EMPTY);
 			*reinterpret_cast<ulonglong2 *>(&s_tab[i].stamp) = make_ulonglong2(INF_STAMP, 0);
@@ -165,7 +189,7 @@ __global__ __launch_bounds__(1024) void k_build_ranges(const Slot *__restrict__ 
 		for (uint64_t e = begin + threadIdx.x; e < end; e += blockDim.x) {
 			const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(&entries[e].k0), b = *reinterpret_cast<const ulonglong2 *>(&entries[e].stamp);
 			const uint64_t home = slot_home(slot_hash<W>(a.x, W == 2 ? a.y : 0), cap);
-			uint32_t s = (uint32_t)(home - lo);  // the partition guarantees lo <= home < lo + span
+			uint32_t s = (uint32_t)(home - lo);  // the partition guarantees lo <= home <= hi
 			bool done = false;
 			for (; s < span; ++s) {
 				// the keys are distinct: whoever sets word 0 owns the slot, nobody else looks at the rest of it

@@ -237,7 +237,7 @@ def test_power_of_two_filters_by_key_partitions(oracle, k, log2_bits):
     partition levels below the one that makes the items; log and vertex table as the key array"""
     packed, offsets, lengths = make_reads_numpy(genome=20000, read_len=150 if k < 63 else 200, n_reads=6000, seed=90 + log2_bits, error=0.02)
     want = gpu_vs_oracle(oracle, packed, offsets, lengths, k, bloom_bits=1 << log2_bits, purge=False,
-                         sweeps=(1 | (10 << 8) | 0x1000000, 2 | 0x1000000))
+                         sweeps=(1 | (10 << 8) | 0x1000000, 1 | (9 << 8) | 0x1000000 | 0x400000, 2 | 0x1000000))
     assert want["builder"].stats()["bloom_partitioned"] == 2
 
 
