@@ -2253,8 +2253,10 @@ static int bloom_partitioned(rg_handle *h, Table &T, uint64_t m_bits, uint64_t k
 // *ok = false: not applicable (filter size not a power of two, no memory); the caller then uses another method.
 // keep_lost != nullptr: the admission kernel is not run; the marks (one byte per slot of T, 8 = false positive) are handed to
 // the caller, who admits while building the table and frees them with pool_free.
-static int bloom_xor(rg_handle *h, Table &T, uint64_t m_bits, uint64_t keys, bool *ok, uint8_t **keep_lost = nullptr) {
+// counted: the first level's ranges come from a histogram pass (k_xor_hist) instead of being sized in advance.
+static int bloom_xor(rg_handle *h, Table &T, uint64_t m_bits, uint64_t keys, bool *ok, uint8_t **keep_lost = nullptr, bool counted = false) {
 	*ok = false;
+	if (getenv("RG_XOR_COUNTED")) counted = true;
 	const int dev = h->cfg.device;
 	if (m_bits == 0 || (m_bits & (m_bits - 1)) || T.cap >= (1ull << 32) || keys == 0) return RG_OK;
 	int B = 0;
@@ -2294,7 +2296,15 @@ static int bloom_xor(rg_handle *h, Table &T, uint64_t m_bits, uint64_t keys, boo
 	unsigned long long *pk = nullptr, *planes = nullptr, *d_seg = nullptr, *d_hist = nullptr, *d_begin = nullptr, *d_sums = nullptr;
 	uint32_t *ix = nullptr, *d_tile = nullptr;
 	uint8_t *d_side = nullptr, *d_lost = nullptr;
+	unsigned long long *d_lim = nullptr;  // ranges sized in advance: their ends for k_xor_keys, then what was filled of each
+	// The first level's digit is the top c1 bits of a hash of distinct keys: every range gets its share of the keys plus eight
+	// standard deviations and a little, and the histogram pass over the key array is not needed (C5's share per GPU: 14.5 ms).
+	// A range that overflows all the same is noticed and the counted way taken.
+	const uint64_t S1 = 1ull << c1;
+	const uint64_t slot1 = (keys / S1 + (uint64_t)(8.0 * std::sqrt((double)keys / (double)S1)) + 4096 + 63) & ~63ull;
+	const uint64_t cap1 = counted ? keys : S1 * slot1;  // items the first level's output holds
 	auto cleanup = [&]() {
+		pool_free(dev, d_lim);
 		pool_free(dev, A);  // Bb is its second half
 		if ((void *)pk != (void *)A) {
 			pool_free(dev, pk);
@@ -2315,8 +2325,9 @@ static int bloom_xor(rg_handle *h, Table &T, uint64_t m_bits, uint64_t keys, boo
 	// with a middle level the last one reads Bb and A is free by then: the packed words and slot indices (12 B per position)
 	// take its place (16 B per key) when they fit -- at C5's share per GPU (3.5e9 keys) that is 42 GB less at the peak
 	const bool alias = c2 && npos_cap * 12 + 256 <= keys * sizeof(Item16);
-	hipError_t e = pool_alloc(dev, (void **)&A, (c2 ? 2 : 1) * keys * sizeof(Item16));  // both item buffers in one block (see build_table_ranges)
-	if (e == hipSuccess && c2) Bb = A + keys;
+	hipError_t e = pool_alloc(dev, (void **)&A, (cap1 + (c2 ? keys : 0)) * sizeof(Item16));  // both item buffers in one block (see build_table_ranges)
+	if (e == hipSuccess && c2) Bb = A + cap1;
+	if (e == hipSuccess) e = pool_alloc(dev, (void **)&d_lim, 256 * sizeof(unsigned long long));
 	if (alias) {
 		pk = (unsigned long long *)A;
 		ix = (uint32_t *)((uint8_t *)A + ((npos_cap * 8 + 255) & ~255ull));
@@ -2325,7 +2336,7 @@ static int bloom_xor(rg_handle *h, Table &T, uint64_t m_bits, uint64_t keys, boo
 		if (e == hipSuccess) e = pool_alloc(dev, (void **)&ix, npos_cap * 4);
 	}
 	if (e == hipSuccess) e = pool_alloc(dev, (void **)&planes, 8 * plane_words * 8);
-	if (e == hipSuccess) e = pool_alloc(dev, (void **)&d_side, keys);
+	if (e == hipSuccess) e = pool_alloc(dev, (void **)&d_side, cap1);
 	if (e == hipSuccess) e = pool_alloc(dev, (void **)&d_lost, T.cap + 4);
 	if (e == hipSuccess) e = pool_alloc(dev, (void **)&d_seg, (SEGMAX + 1) * sizeof(unsigned long long));
 	if (e == hipSuccess) e = pool_alloc(dev, (void **)&d_tile, (SEGMAX + 1) * sizeof(uint32_t));
@@ -2354,25 +2365,46 @@ static int bloom_xor(rg_handle *h, Table &T, uint64_t m_bits, uint64_t keys, boo
 	if (!alias) XTRY(hipMemsetAsync(pk, 0xFF, npos_cap * 8, h->stream));
 	XTRY(hipMemsetAsync(d_lost, 0, T.cap + 4, h->stream));
 	XTRY(hipMemsetAsync(d_hist, 0, 256 * sizeof(unsigned long long), h->stream));
-	// level 1: histogram of the top c1 bits, items produced straight into their ranges
-	const int grid_scan = (int)std::min<uint64_t>((uint64_t)n_cu * 8, (T.cap + 255) / 256);
-	{
+	// level 1: items produced straight into the ranges of the top c1 bits -- ranges sized in advance, or (counted) from a histogram pass
+	std::vector<unsigned long long> seg_begin, seg_fill;  // seg_fill: where the filling of the level-1 ranges ended (sized in advance only)
+	if (counted) {
+		const int grid_scan = (int)std::min<uint64_t>((uint64_t)n_cu * 8, (T.cap + 255) / 256);
 		ProfScope ps(h, "k_xor_hist");
 		if (h->W == 1) hipLaunchKernelGGL(k_xor_hist<1>, dim3(grid_scan), dim3(256), 0, h->stream, T.slots, T.cap, m_mask, B - c1, (1u << c1) - 1u, d_hist);
 		else hipLaunchKernelGGL(k_xor_hist<2>, dim3(grid_scan), dim3(256), 0, h->stream, T.slots, T.cap, m_mask, B - c1, (1u << c1) - 1u, d_hist);
 		XTRY(hipGetLastError());
+		scan(S1);
+	} else {
+		seg_begin.resize(S1 + 1);
+		seg_fill.resize(S1);
+		for (uint64_t d = 0; d <= S1; ++d) seg_begin[d] = d * slot1;
+		XTRY(hipMemcpyAsync(d_hist, seg_begin.data(), S1 * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));      // the cursors
+		XTRY(hipMemcpyAsync(d_lim, seg_begin.data() + 1, S1 * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));  // the ends
+		XTRY(hipMemsetAsync(h->d_counters + XC_PRESIZE_OVF, 0, sizeof(unsigned long long), h->stream));
 	}
-	scan(1ull << c1);
 	const int nd = c2 ? c2 : c3;                 // bits of the level after the first
 	const int nshift = B - c1 - nd;
 	{
 		ProfScope ps(h, "k_xor_keys");
 		const unsigned grid = (unsigned)((T.cap + XOR_TILE - 1) / XOR_TILE);
-		if (h->W == 1) hipLaunchKernelGGL(k_xor_keys<1>, dim3(grid), dim3(XOR_THREADS), 0, h->stream, T.slots, T.cap, m_mask, B - c1, (1u << c1) - 1u, d_hist, A, d_side, nshift, (1u << nd) - 1u);
-		else hipLaunchKernelGGL(k_xor_keys<2>, dim3(grid), dim3(XOR_THREADS), 0, h->stream, T.slots, T.cap, m_mask, B - c1, (1u << c1) - 1u, d_hist, A, d_side, nshift, (1u << nd) - 1u);
+		const unsigned long long *lim = counted ? nullptr : d_lim;
+		if (h->W == 1) hipLaunchKernelGGL(k_xor_keys<1>, dim3(grid), dim3(XOR_THREADS), 0, h->stream, T.slots, T.cap, m_mask, B - c1, (1u << c1) - 1u, d_hist, A, d_side, nshift, (1u << nd) - 1u, lim, h->d_counters);
+		else hipLaunchKernelGGL(k_xor_keys<2>, dim3(grid), dim3(XOR_THREADS), 0, h->stream, T.slots, T.cap, m_mask, B - c1, (1u << c1) - 1u, d_hist, A, d_side, nshift, (1u << nd) - 1u, lim, h->d_counters);
 		XTRY(hipGetLastError());
 	}
-	std::vector<unsigned long long> seg_begin;
+	if (!counted) {
+		XTRY(hipMemcpyAsync(seg_fill.data(), d_hist, S1 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+		const int rcs = sync_counters(h);
+		if (rcs) {
+			cleanup();
+			return rcs;
+		}
+		if (h->h_counters[XC_PRESIZE_OVF]) {  // a range sized in advance was too small (never seen): count them
+			cleanup();
+			return bloom_xor(h, T, m_bits, keys, ok, keep_lost, true);
+		}
+		XTRY(hipMemcpyAsync(d_lim, seg_fill.data(), S1 * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
+	}
 	std::vector<uint32_t> tile_first;
 	const Item16 *level_in = A;
 	int used = c1;
@@ -2380,19 +2412,27 @@ static int bloom_xor(rg_handle *h, Table &T, uint64_t m_bits, uint64_t keys, boo
 		const bool final_level = level == (c2 ? 2 : 1);
 		const int db = final_level ? c3 : c2;
 		const uint64_t S64 = 1ull << used;
-		seg_begin.resize(S64 + 1);
-		XTRY(hipMemcpyAsync(seg_begin.data(), d_begin, (S64 + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-		XTRY(hipStreamSynchronize(h->stream));
-		if (seg_begin[S64] != keys) {
+		const bool gaps = level == 1 && !counted;  // the segments are the ranges sized in advance: [seg_begin[s], seg_fill[s])
+		uint64_t held = 0;
+		if (!gaps) {
+			seg_begin.resize(S64 + 1);
+			XTRY(hipMemcpyAsync(seg_begin.data(), d_begin, (S64 + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+			XTRY(hipStreamSynchronize(h->stream));
+			held = seg_begin[S64];
+		} else {
+			for (uint64_t d = 0; d < S64; ++d) held += seg_fill[d] - seg_begin[d];
+		}
+		if (held != keys) {
 			cleanup();
-			return fail(h, RG_ERR_STATE, "Bloom key partition holds %llu of %llu keys", seg_begin[S64], (unsigned long long)keys);
+			return fail(h, RG_ERR_STATE, "Bloom key partition holds %llu of %llu keys", (unsigned long long)held, (unsigned long long)keys);
 		}
 		const uint32_t S = (uint32_t)S64;
+		const unsigned long long *d_segend = gaps ? d_lim : nullptr;
 		tile_first.assign(S + 1, 0);
 		uint64_t ntiles = 0;
 		for (uint32_t sgi = 0; sgi < S; ++sgi) {
 			tile_first[sgi] = (uint32_t)ntiles;
-			ntiles += (seg_begin[sgi + 1] - seg_begin[sgi] + XOR_TILE - 1) / XOR_TILE;
+			ntiles += ((gaps ? seg_fill[sgi] : seg_begin[sgi + 1]) - seg_begin[sgi] + XOR_TILE - 1) / XOR_TILE;
 		}
 		tile_first[S] = (uint32_t)ntiles;
 		XTRY(hipMemcpyAsync(d_seg, seg_begin.data(), (S + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
@@ -2401,7 +2441,7 @@ static int bloom_xor(rg_handle *h, Table &T, uint64_t m_bits, uint64_t keys, boo
 		XTRY(hipMemsetAsync(d_hist, 0, nout * sizeof(unsigned long long), h->stream));
 		{
 			ProfScope ps(h, "k_level_hist_side");
-			hipLaunchKernelGGL(k_level_hist_side<XOR_TILE>, dim3((unsigned)ntiles), dim3(256), 0, h->stream, d_side, S, d_seg, d_tile, db, d_hist);
+			hipLaunchKernelGGL(k_level_hist_side<XOR_TILE>, dim3((unsigned)ntiles), dim3(256), 0, h->stream, d_side, S, d_seg, d_tile, db, d_hist, d_segend);
 			XTRY(hipGetLastError());
 		}
 		if (final_level) hipLaunchKernelGGL(k_round64, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, h->stream, d_hist, nout);
@@ -2413,10 +2453,10 @@ static int bloom_xor(rg_handle *h, Table &T, uint64_t m_bits, uint64_t keys, boo
 			const int shift = B - used - db;
 			if (final_level)
 				hipLaunchKernelGGL((k_scatter16<true>), dim3((unsigned)ntiles), dim3(XOR_THREADS), 0, h->stream, level_in, S, d_seg, d_tile, shift, db, d_hist, (Item16 *)nullptr,
-				                   (uint8_t *)nullptr, 0, 0u, pk, ix, (1ull << R) - 1ull);
+				                   (uint8_t *)nullptr, 0, 0u, pk, ix, (1ull << R) - 1ull, d_segend);
 			else
 				hipLaunchKernelGGL((k_scatter16<false>), dim3((unsigned)ntiles), dim3(XOR_THREADS), 0, h->stream, level_in, S, d_seg, d_tile, shift, db, d_hist, Bb, d_side,
-				                   shift - c3, (1u << c3) - 1u, (unsigned long long *)nullptr, (uint32_t *)nullptr, 0ull);
+				                   shift - c3, (1u << c3) - 1u, (unsigned long long *)nullptr, (uint32_t *)nullptr, 0ull, d_segend);
 			XTRY(hipGetLastError());
 		}
 		used += db;

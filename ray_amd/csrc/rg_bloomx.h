@@ -93,10 +93,16 @@ __device__ __forceinline__ uint32_t xor_claim(uint32_t *s_cnt, uint32_t *s_off, 
 }
 
 // keys -> items, sorted by the first-level digit inside a tile of XOR_TILE slots and written as runs
+// limits != nullptr: the digits' ranges were sized in advance (o is a hash: a share of the keys each, plus slack) instead of
+// counted by k_xor_hist; limits[d] is the end of range d, an item that would land beyond it is dropped and counted in
+// counters[XC_PRESIZE_OVF] (the host then falls back to counted ranges).
+enum XorCounter { XC_PRESIZE_OVF = 29 };
 template <int W>
 __global__ __launch_bounds__(XOR_THREADS) void k_xor_keys(const Slot *__restrict__ tab, uint64_t cap, uint64_t m_mask, int shift, uint32_t dmask,
                                                           unsigned long long *__restrict__ cursors, Item16 *__restrict__ out,
-                                                          uint8_t *__restrict__ side, int next_shift, uint32_t next_mask) {
+                                                          uint8_t *__restrict__ side, int next_shift, uint32_t next_mask,
+                                                          const unsigned long long *__restrict__ limits = nullptr,
+                                                          unsigned long long *__restrict__ counters = nullptr) {
 	constexpr int PER = XOR_TILE / XOR_THREADS;
 	__shared__ Item16 s_item[XOR_TILE];
 	__shared__ uint8_t s_dig[XOR_TILE];
@@ -136,6 +142,10 @@ __global__ __launch_bounds__(XOR_THREADS) void k_xor_keys(const Slot *__restrict
 		const uint32_t d = s_dig[i];
 		const Item16 it = s_item[i];
 		const unsigned long long dst = s_gbase[d] + (i - s_off[d]);
+		if (limits && dst >= limits[d]) {
+			atomicAdd(&counters[XC_PRESIZE_OVF], 1ull);
+			continue;
+		}
 		*reinterpret_cast<ulonglong2 *>(&out[dst]) = make_ulonglong2(it.a, it.b);
 		if (side) side[dst] = (uint8_t)((uint32_t)(it.a >> (31 + next_shift)) & next_mask);
 	}
@@ -149,7 +159,8 @@ __global__ __launch_bounds__(XOR_THREADS) void k_scatter16(const Item16 *__restr
                                                            const uint32_t *__restrict__ tile_first, int shift, int dbits,
                                                            unsigned long long *__restrict__ cursors, Item16 *__restrict__ out, uint8_t *__restrict__ side,
                                                            int next_shift, uint32_t next_mask, unsigned long long *__restrict__ pk,
-                                                           uint32_t *__restrict__ ix, uint64_t low_mask) {
+                                                           uint32_t *__restrict__ ix, uint64_t low_mask,
+                                                           const unsigned long long *__restrict__ seg_end = nullptr) {
 	constexpr int PER = XOR_TILE / XOR_THREADS;
 	__shared__ Item16 s_item[XOR_TILE];
 	__shared__ uint8_t s_dig[XOR_TILE];
@@ -163,7 +174,8 @@ __global__ __launch_bounds__(XOR_THREADS) void k_scatter16(const Item16 *__restr
 	}
 	const uint32_t seg = lo;
 	const uint64_t begin = seg_begin[seg] + (uint64_t)(blockIdx.x - tile_first[seg]) * XOR_TILE;
-	const uint64_t end = begin + XOR_TILE < seg_begin[seg + 1] ? begin + XOR_TILE : seg_begin[seg + 1];
+	const uint64_t send = seg_end ? seg_end[seg] : seg_begin[seg + 1];
+	const uint64_t end = begin + XOR_TILE < send ? begin + XOR_TILE : send;
 	const uint32_t dmask = (1u << dbits) - 1;
 	if (threadIdx.x < 256) s_cnt[threadIdx.x] = 0;
 	__syncthreads();

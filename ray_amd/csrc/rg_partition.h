@@ -747,11 +747,14 @@ template <int TILE>
 __global__ __launch_bounds__(256) void k_level_hist_side(const uint8_t *__restrict__ side, uint32_t S,
                                                          const unsigned long long *__restrict__ seg_begin,
                                                          const uint32_t *__restrict__ tile_first, int dbits,
-                                                         unsigned long long *__restrict__ hist) {
+                                                         unsigned long long *__restrict__ hist,
+                                                         const unsigned long long *__restrict__ seg_end = nullptr) {
+	// seg_end: segments that do not touch (ranges sized in advance and filled in part); otherwise segment s ends where s + 1 begins
 	__shared__ uint32_t s_cnt[256];
 	const uint32_t seg = find_segment(tile_first, S, blockIdx.x);
 	const uint64_t begin = seg_begin[seg] + (uint64_t)(blockIdx.x - tile_first[seg]) * TILE;
-	const uint64_t end = begin + TILE < seg_begin[seg + 1] ? begin + TILE : seg_begin[seg + 1];
+	const uint64_t send = seg_end ? seg_end[seg] : seg_begin[seg + 1];
+	const uint64_t end = begin + TILE < send ? begin + TILE : send;
 	s_cnt[threadIdx.x] = 0;
 	__syncthreads();
 #pragma unroll
