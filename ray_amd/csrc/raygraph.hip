@@ -1743,7 +1743,7 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 		if (level > 0 && side_valid) {  // the previous level's scatter left this level's digits, one byte per record
 			PTRY(hipMemsetAsync(d_hist, 0, nout * sizeof(unsigned long long), h->stream));
 			ProfScope ps(h, "k_level_hist_side");
-			hipLaunchKernelGGL(k_level_hist_side<SCATTER_TILE>, dim3((unsigned)ntiles), dim3(256), 0, h->stream, d_side, S, d_seg, d_tile, db, d_hist);
+			hipLaunchKernelGGL(k_level_hist_side<SCATTER_TILE>, dim3((unsigned)((ntiles + HIST_SIDE_TILES - 1) / HIST_SIDE_TILES)), dim3(256), 0, h->stream, d_side, S, d_seg, d_tile, db, d_hist, (uint32_t)ntiles);
 			PTRY(hipGetLastError());
 		} else if (level > 0) {  // level 0's histogram is in place
 			PTRY(hipMemsetAsync(d_hist, 0, nout * sizeof(unsigned long long), h->stream));
@@ -2179,7 +2179,7 @@ static int bloom_partitioned(rg_handle *h, Table &T, uint64_t m_bits, uint64_t k
 		ProfScope ps(h, "k_scatter64");
 		if (level > 0) {
 			BTRY(hipMemsetAsync(d_hist, 0, nout * sizeof(unsigned long long), h->stream));
-			if (level == 1 && d_side) hipLaunchKernelGGL(k_level_hist_side<SCATTER64_TILE>, dim3((unsigned)ntiles), dim3(256), 0, h->stream, d_side, S, d_seg, d_tile, 8, d_hist);
+			if (level == 1 && d_side) hipLaunchKernelGGL(k_level_hist_side<SCATTER64_TILE>, dim3((unsigned)((ntiles + HIST_SIDE_TILES - 1) / HIST_SIDE_TILES)), dim3(256), 0, h->stream, d_side, S, d_seg, d_tile, 8, d_hist, (uint32_t)ntiles);
 			else hipLaunchKernelGGL(k_hist64, dim3((unsigned)ntiles), dim3(256), 0, h->stream, bufs[cur], S, d_seg, d_tile, shift, d_hist);
 		}
 		const uint32_t nblk = (uint32_t)((nout + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK);
@@ -2441,7 +2441,7 @@ static int bloom_xor(rg_handle *h, Table &T, uint64_t m_bits, uint64_t keys, boo
 		XTRY(hipMemsetAsync(d_hist, 0, nout * sizeof(unsigned long long), h->stream));
 		{
 			ProfScope ps(h, "k_level_hist_side");
-			hipLaunchKernelGGL(k_level_hist_side<XOR_TILE>, dim3((unsigned)ntiles), dim3(256), 0, h->stream, d_side, S, d_seg, d_tile, db, d_hist, d_segend);
+			hipLaunchKernelGGL(k_level_hist_side<XOR_TILE>, dim3((unsigned)((ntiles + HIST_SIDE_TILES - 1) / HIST_SIDE_TILES)), dim3(256), 0, h->stream, d_side, S, d_seg, d_tile, db, d_hist, (uint32_t)ntiles, d_segend);
 			XTRY(hipGetLastError());
 		}
 		if (final_level) hipLaunchKernelGGL(k_round64, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, h->stream, d_hist, nout);
@@ -2699,7 +2699,7 @@ static int build_table_ranges(rg_handle *h, const Slot *log, uint64_t n_log, uin
 			else hipLaunchKernelGGL(k_entry_hist<2>, dim3(grid), dim3(256), 0, h->stream, log, n_log, bits, shift, (1u << db) - 1u, d_hist);
 		} else {
 			ProfScope ps(h, "k_level_hist_side");
-			hipLaunchKernelGGL(k_level_hist_side<ENT_TILE>, dim3((unsigned)ntiles), dim3(256), 0, h->stream, d_side, S, d_seg, d_tile, db, d_hist);
+			hipLaunchKernelGGL(k_level_hist_side<ENT_TILE>, dim3((unsigned)((ntiles + HIST_SIDE_TILES - 1) / HIST_SIDE_TILES)), dim3(256), 0, h->stream, d_side, S, d_seg, d_tile, db, d_hist, (uint32_t)ntiles);
 		}
 		TTRY(hipGetLastError());
 		const uint32_t nblk = (uint32_t)((nout + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK);

@@ -743,35 +743,48 @@ __global__ __launch_bounds__(SCATTER_THREADS) void k_scatter(const Rec<W> *__res
 
 // digit histogram of one level from the side bytes the previous level's scatter wrote: hist[(seg << dbits) + digit]
 // (TILE = the tile of the scatter kernel that follows: SCATTER_TILE records, or SCATTER64_TILE Bloom items)
+static constexpr uint32_t HIST_SIDE_TILES = 32;  // tiles a workgroup of k_level_hist_side walks (one tile each: 222 K workgroups of 2.5 KB on C2, 0.47 ms per level; eight: see DESIGN.md)
 template <int TILE>
 __global__ __launch_bounds__(256) void k_level_hist_side(const uint8_t *__restrict__ side, uint32_t S,
                                                          const unsigned long long *__restrict__ seg_begin,
                                                          const uint32_t *__restrict__ tile_first, int dbits,
-                                                         unsigned long long *__restrict__ hist,
+                                                         unsigned long long *__restrict__ hist, uint32_t ntiles,
                                                          const unsigned long long *__restrict__ seg_end = nullptr) {
 	// seg_end: segments that do not touch (ranges sized in advance and filled in part); otherwise segment s ends where s + 1 begins
 	__shared__ uint32_t s_cnt[256];
-	const uint32_t seg = find_segment(tile_first, S, blockIdx.x);
-	const uint64_t begin = seg_begin[seg] + (uint64_t)(blockIdx.x - tile_first[seg]) * TILE;
-	const uint64_t send = seg_end ? seg_end[seg] : seg_begin[seg + 1];
-	const uint64_t end = begin + TILE < send ? begin + TILE : send;
+	const uint32_t t0 = blockIdx.x * HIST_SIDE_TILES;
+	const uint32_t t1 = t0 + HIST_SIDE_TILES < ntiles ? t0 + HIST_SIDE_TILES : ntiles;
+	uint32_t seg = find_segment(tile_first, S, t0), cur = seg;
 	s_cnt[threadIdx.x] = 0;
 	__syncthreads();
+	for (uint32_t t = t0; t < t1; ++t) {
+		while (t >= tile_first[seg + 1]) ++seg;  // tile_first[S] = ntiles > t: ends; segments without tiles are passed over
+		if (seg != cur) {  // the counts so far belong to the segment left behind
+			__syncthreads();
+			if (threadIdx.x < (1u << dbits) && s_cnt[threadIdx.x]) atomicAdd(&hist[((uint64_t)cur << dbits) + threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
+			s_cnt[threadIdx.x] = 0;
+			__syncthreads();
+			cur = seg;
+		}
+		const uint64_t begin = seg_begin[seg] + (uint64_t)(t - tile_first[seg]) * TILE;
+		const uint64_t send = seg_end ? seg_end[seg] : seg_begin[seg + 1];
+		const uint64_t end = begin + TILE < send ? begin + TILE : send;
 #pragma unroll
-	for (int r = 0; r < (TILE + 2047) / 2048; ++r) {  // eight bytes per thread in one load (any alignment), the last ones of a segment one by one
-		const uint64_t i = begin + (uint64_t)r * 2048 + (uint64_t)threadIdx.x * 8;
-		if (i + 8 <= end) {
-			uint64_t v;
-			__builtin_memcpy(&v, side + i, 8);
+		for (int r = 0; r < (TILE + 2047) / 2048; ++r) {  // eight bytes per thread in one load (any alignment), the last ones of a segment one by one
+			const uint64_t i = begin + (uint64_t)r * 2048 + (uint64_t)threadIdx.x * 8;
+			if (i + 8 <= end) {
+				uint64_t v;
+				__builtin_memcpy(&v, side + i, 8);
 #pragma unroll
-			for (int b = 0; b < 8; ++b) atomicAdd(&s_cnt[(uint32_t)(v >> (8 * b)) & 255u], 1u);
-		} else {
-			for (uint64_t j = i; j < end; ++j) atomicAdd(&s_cnt[side[j]], 1u);
+				for (int b = 0; b < 8; ++b) atomicAdd(&s_cnt[(uint32_t)(v >> (8 * b)) & 255u], 1u);
+			} else {
+				for (uint64_t j = i; j < end; ++j) atomicAdd(&s_cnt[side[j]], 1u);
+			}
 		}
 	}
 	__syncthreads();
 	if (threadIdx.x < (1u << dbits) && s_cnt[threadIdx.x])
-		atomicAdd(&hist[((uint64_t)seg << dbits) + threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
+		atomicAdd(&hist[((uint64_t)cur << dbits) + threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
 }
 
 // digit histogram of one level: hist[(seg << dbits) + digit]
