@@ -743,7 +743,7 @@ __global__ __launch_bounds__(SCATTER_THREADS) void k_scatter(const Rec<W> *__res
 
 // digit histogram of one level from the side bytes the previous level's scatter wrote: hist[(seg << dbits) + digit]
 // (TILE = the tile of the scatter kernel that follows: SCATTER_TILE records, or SCATTER64_TILE Bloom items)
-static constexpr uint32_t HIST_SIDE_TILES = 32;  // tiles a workgroup of k_level_hist_side walks (one tile each: 222 K workgroups of 2.5 KB on C2, 0.47 ms per level; eight: see DESIGN.md)
+static constexpr uint32_t HIST_SIDE_TILES = 8;  // tiles a workgroup of k_level_hist_side walks (one tile each: 222 K workgroups of 2.5 KB on C2, 1.15 ms for the five launches of a step; 8: 0.58 ms; 32: 0.64)
 template <int TILE>
 __global__ __launch_bounds__(256) void k_level_hist_side(const uint8_t *__restrict__ side, uint32_t S,
                                                          const unsigned long long *__restrict__ seg_begin,
