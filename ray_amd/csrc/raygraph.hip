@@ -1762,8 +1762,12 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 			ProfScope ps(h, "k_scatter");
 			uint8_t *side_out = (have_next && !(h->dbg & 0x100000)) ? d_side : nullptr;  // bit 20: histograms read the records (tests)
 			const int ndb = have_next ? dbits[level + 1] : 0;
-			hipLaunchKernelGGL(k_scatter<W>, dim3((unsigned)ntiles), dim3(SCATTER_THREADS), 0, h->stream, level_in, m, S, d_seg, d_tile, shift, db, d_hist,
-			                   buf[cur ^ 1], 0u, side_out, shift - ndb, (1u << ndb) - 1u);
+			if (nested)
+				hipLaunchKernelGGL((k_scatter<W, 1>), dim3((unsigned)ntiles), dim3(SCATTER_THREADS), 0, h->stream, level_in, m, S, d_seg, d_tile, shift, db, d_hist,
+				                   buf[cur ^ 1], 0u, side_out, shift - ndb, (1u << ndb) - 1u);
+			else
+				hipLaunchKernelGGL(k_scatter<W>, dim3((unsigned)ntiles), dim3(SCATTER_THREADS), 0, h->stream, level_in, m, S, d_seg, d_tile, shift, db, d_hist,
+				                   buf[cur ^ 1], 0u, side_out, shift - ndb, (1u << ndb) - 1u);
 			side_valid = side_out != nullptr;
 		}
 		PTRY(hipGetLastError());

@@ -656,7 +656,9 @@ __device__ __forceinline__ uint32_t find_segment(const uint32_t *__restrict__ ti
 	return lo;
 }
 
-template <int W>
+// TAG: 1 for the launches of the record sample's own small sweep, so that a profiler's per-kernel averages of the real
+// partition levels are not diluted by them
+template <int W, int TAG = 0>
 __global__ __launch_bounds__(SCATTER_THREADS) void k_scatter(const Rec<W> *__restrict__ in, int m, uint32_t S,
                                                  const unsigned long long *__restrict__ seg_begin,
                                                  const uint32_t *__restrict__ tile_first, int shift, int dbits,
