@@ -1,0 +1,54 @@
+"""Seeded random cases through the C ABI against the oracle: k, read length (short reads for the lane-per-read kernels,
+reads beyond 1024 bases for the wavefront-per-read one), coverage, error rate, filter size (default, off, powers of two and
+odd sizes from far too small to ample) and a random mix of the switches that force internal routes.  Every case is
+deterministic (the seed is the case number)."""
+import numpy as np
+import pytest
+
+from helpers import gpu_vs_oracle
+from ray_amd.synth import make_reads_numpy
+
+pytestmark = pytest.mark.gpu
+
+FLAG_CHOICES = (0x10000, 0x20000, 0x40000, 0x100000, 0x400000, 0x800000, 0x1000000, 0x2000000, 0x4000000)
+
+
+def _case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    k = int(rng.choice([15, 17, 21, 27, 31, 33, 37, 39, 45, 47, 55, 63]))
+    long_reads = rng.random() < 0.2
+    read_len = int(rng.integers(1100, 1600)) if long_reads else int(rng.integers(max(k + 5, 40), 320))
+    genome = int(rng.integers(2000, 30000))
+    coverage = float(rng.choice([3, 8, 20, 45]))
+    n_reads = max(50, int(genome * coverage / read_len))
+    error = float(rng.choice([0.0, 0.002, 0.01, 0.03]))
+    ragged = bool(rng.random() < 0.3)
+    bloom = rng.choice(["default", "off", "pow2", "odd"])
+    if bloom == "default":
+        bloom_bits = None
+    elif bloom == "off":
+        bloom_bits = 0
+    elif bloom == "pow2":
+        bloom_bits = 1 << int(rng.integers(10, 30))
+    else:
+        bloom_bits = int(rng.integers(5000, 3_000_000))
+    sweeps = []
+    for _ in range(3):
+        route = int(rng.choice([1, 1, 1, 2]))                      # partitioned sweep most of the time
+        s = route | int(rng.choice([0, 16, 32]))
+        if route == 1 and rng.random() < 0.7:
+            s |= int(rng.integers(8, 21)) << 8                     # forced bucket count; otherwise the library's own choice
+        for f in FLAG_CHOICES:
+            if rng.random() < 0.25:
+                s |= f
+        if (s & 0x400000) and (s & 0x800000):
+            s &= ~0x800000
+        sweeps.append(s)
+    return dict(k=k, read_len=read_len, genome=genome, n_reads=n_reads, error=error, ragged=ragged, bloom_bits=bloom_bits, sweeps=tuple(sweeps))
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_case(oracle, seed):
+    c = _case(seed)
+    packed, offsets, lengths = make_reads_numpy(c["genome"], c["read_len"], c["n_reads"], seed=500 + seed, error=c["error"], ragged=c["ragged"])
+    gpu_vs_oracle(oracle, packed, offsets, lengths, c["k"], bloom_bits=c["bloom_bits"], sweeps=c["sweeps"])
