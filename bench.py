@@ -331,7 +331,7 @@ def main():
         W = 1 if k <= 31 else 2
         Kb = 8 * W
         occ0, cand0, recs0 = st["occurrences"], st["candidates"], st["superkmer_records"]
-        rec_bytes = 8 * (2 * W + 1)
+        rec_bytes = 20 if k <= 31 else 8 * (2 * W + 1)  # rg_record_counts reports the same
         alg_bytes = {
             "k_count": occ0 * (L / (4.0 * n_per_read) + Kb + 8),            # read bits + key compare + count RMW
             "k_superkmers": occ0 * L / (4.0 * n_per_read) + recs0 * rec_bytes,  # read bits in, records out

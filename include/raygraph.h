@@ -101,7 +101,7 @@ int rg_count_kmers(rg_handle *h);
  * buckets at the full coverage whatever the number of ranks:
  *   rg_records_local    reads -> records, counted per destination rank (destination = bucket of the record's
  *                       minimizer % size; an internal choice, invisible in the results)
- *   rg_record_counts    counts[r] = records for rank r; *record_bytes = size of one record (24 or 40)
+ *   rg_record_counts    counts[r] = records for rank r; *record_bytes = size of one record (20 bytes for k <= 31, 24 for k = 32, 40 above; opaque to the caller)
  *   rg_export_records   the records grouped by destination in rank order, into the caller's device buffer
  *   -- all-to-all(v) of the records --
  *   rg_count_records    aggregates the received records (device pointer; must stay valid during the call)
@@ -286,7 +286,7 @@ int rg_release_cached_memory(void);
 
 /* ---- test and experiment switches -------------------------------------------------------------- */
 /* Forces internal routes that the library otherwise chooses by itself; results never depend on them.  No counterpart
- * in the reference; a plugin leaves it alone.  Must be called before the counting starts.  flags: bits 0-7: 0 = automatic, 1 = force the partitioned sweep, 2 = force the direct sweep; bits 8-15: log2 of the bucket count of the partitioned sweep (0 = automatic); bit 4 / bit 5: force the partitioned / the dense Bloom resolution; bit 6: start with a one-chunk log (tests of the overflow path); bit 16: cut super-k-mer records with the wavefront-per-read kernel even where the lane-per-read one applies; bit 17: produce the Bloom items straight into their first partition level even from a sparse key array; bit 18: size the log from a sample of the buckets even on small inputs (tests); bit 19: rg_merge_entries never keeps received entries as a log (tests); bit 20: the partition levels' histograms read the records instead of the digit bytes the previous level left (tests); bit 21: aggregate with a workgroup per bucket of a two-level partition (k_aggregate_wg) instead of a wavefront per bucket of a three-level one (tests); bit 22 / bit 23: always / never build the vertex table range by range from partitioned entries (tests); bit 24: resolve a power-of-two Bloom filter by key partitions whatever its fill (tests); bit 25: pick the bucket count from a sample of the records even on small inputs (tests); bit 26: aggregate with the 512-slot k-mer tables that diverse inputs get (tests) */
+ * in the reference; a plugin leaves it alone.  Must be called before the counting starts.  flags: bits 0-7: 0 = automatic, 1 = force the partitioned sweep, 2 = force the direct sweep; bits 8-15: log2 of the bucket count of the partitioned sweep (0 = automatic); bit 4 / bit 5: force the partitioned / the dense Bloom resolution; bit 6: start with a one-chunk log (tests of the overflow path); bit 16: cut super-k-mer records with the wavefront-per-read kernel even where the lane-per-read one applies; bit 17: produce the Bloom items straight into their first partition level even from a sparse key array; bit 18: size the log from a sample of the buckets even on small inputs (tests); bit 19: rg_merge_entries never keeps received entries as a log (tests); bit 20: the partition levels' histograms read the records instead of the digit bytes the previous level left (tests); bit 21: aggregate with a workgroup per bucket of a two-level partition (k_aggregate_wg) instead of a wavefront per bucket of a three-level one (tests); bit 22 / bit 23: always / never build the vertex table range by range from partitioned entries (tests); bit 24: resolve a power-of-two Bloom filter by key partitions whatever its fill (tests); bit 25: pick the bucket count from a sample of the records even on small inputs (tests); bit 26: aggregate with the 512-slot k-mer tables that diverse inputs get (tests); bit 27: keep super-k-mer records in their 24-byte form where the 20-byte one applies (k <= 31; tests) */
 int rg_debug_set(rg_handle *h, uint32_t flags);
 
 /* ---- profiling (the reference's MACRO_COLLECT_PROFILING_INFORMATION probes,

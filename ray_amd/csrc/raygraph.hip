@@ -1391,32 +1391,37 @@ static int table_reserve(rg_handle *h, Table &t, uint64_t need, int fill_counter
 // ext != nullptr: the records come from outside (record exchange between ranks: ext_n valid records
 // received from all ranks) instead of from this handle's reads.
 
+// 20-byte records (Rec20) whenever they can hold every record of this k; rg_debug_set bit 27 keeps the 24-byte form (tests).
+// Every rank of a job decides alike: the form is a function of k.
+static bool rec_compact(const rg_handle *h) { return rec_compact_for(h->W, h->cfg.k) && !(h->dbg & 0x8000000); }
+
 // reads -> records: k_superkmers_lanes (a lane per read) for short reads and windows that fit its LDS block,
 // k_superkmers (a wavefront per read) otherwise; rg_debug_set bit 16 forces the latter (tests)
 static constexpr int SKL_HOST_MAX_W = 24;        // 4 wavefronts x w x 64 lanes x 8 B <= 48 KiB of dynamic LDS
 static constexpr uint32_t SKL_MAX_READ = 1024;   // longer reads: lanes of one wavefront would idle behind the longest
-template <int W>
+template <int W, bool C>
 struct SuperkmerLaunch {
+	using RM = RecMem<W, C>;
 	int grid_wave = 1, grid_lane = 0;
 	size_t lds_lane = 0;
-	bool wide = false;  // k_superkmers_lanes<W, true>: 6-byte window slots, windows of up to 64 m-mers
+	bool wide = false;  // k_superkmers_lanes<W, true, C>: 6-byte window slots, windows of up to 64 m-mers
 	int grid_max() const { return grid_wave > grid_lane ? grid_wave : grid_lane; }
 	void plan(rg_handle *h, int n_cu, int k, int m, uint64_t total_reads) {
 		const int w = k - m + 1;
 		int occ = 4;
-		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_superkmers<W>, 256, 0) != hipSuccess || occ < 1) occ = 4;
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (k_superkmers<W, C>), 256, 0) != hipSuccess || occ < 1) occ = 4;
 		grid_wave = (int)std::min<uint64_t>((uint64_t)n_cu * occ, std::max<uint64_t>(1, (total_reads + 255) / 256));
 		grid_lane = 0;
 		if (w <= SKL_HOST_MAX_W && w <= SKL_MAX_W && !(h->dbg & 0x10000)) {
 			lds_lane = (size_t)4 * w * 64 * sizeof(unsigned long long);
 			int occl = 0;
-			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occl, k_superkmers_lanes<W, false>, 256, lds_lane) == hipSuccess && occl >= 1)
+			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occl, (k_superkmers_lanes<W, false, C>), 256, lds_lane) == hipSuccess && occl >= 1)
 				grid_lane = (int)std::min<uint64_t>((uint64_t)n_cu * occl, std::max<uint64_t>(1, (total_reads + 255) / 256));
 		} else if (w <= SKL_MAX_W_WIDE && !(h->dbg & 0x10000)) {
 			lds_lane = (size_t)4 * w * 64 * 6;
 			int occl = 0;
-			if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_superkmers_lanes<W, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lane) == hipSuccess &&
-			    hipOccupancyMaxActiveBlocksPerMultiprocessor(&occl, k_superkmers_lanes<W, true>, 256, lds_lane) == hipSuccess && occl >= 1) {
+			if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_superkmers_lanes<W, true, C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lane) == hipSuccess &&
+			    hipOccupancyMaxActiveBlocksPerMultiprocessor(&occl, (k_superkmers_lanes<W, true, C>), 256, lds_lane) == hipSuccess && occl >= 1) {
 				grid_lane = (int)std::min<uint64_t>((uint64_t)n_cu * occl, std::max<uint64_t>(1, (total_reads + 255) / 256));
 				wide = true;
 			}
@@ -1425,24 +1430,25 @@ struct SuperkmerLaunch {
 	}
 	bool lanes(const ReadBatch &b) const { return grid_lane > 0 && b.maxlen <= SKL_MAX_READ; }
 	const char *name(const ReadBatch &b) const { return lanes(b) ? "k_superkmers_lanes" : "k_superkmers"; }
-	void launch(rg_handle *h, const ReadBatch &b, uint64_t lo, uint64_t n, int k, int m, Rec<W> *buf, uint64_t rec_cap,
-	            unsigned long long *d_hist, uint32_t modulo, uint32_t hist_shift, Rec<W> *sample = nullptr, uint64_t sample_cap = 0) const {
+	void launch(rg_handle *h, const ReadBatch &b, uint64_t lo, uint64_t n, int k, int m, RM *buf, uint64_t rec_cap,
+	            unsigned long long *d_hist, uint32_t modulo, uint32_t hist_shift, RM *sample = nullptr, uint64_t sample_cap = 0) const {
 		if (lanes(b) && wide)
-			hipLaunchKernelGGL((k_superkmers_lanes<W, true>), dim3(grid_lane), dim3(256), lds_lane, h->stream, b.d_packed, b.d_off + lo, b.d_len + lo, n,
+			hipLaunchKernelGGL((k_superkmers_lanes<W, true, C>), dim3(grid_lane), dim3(256), lds_lane, h->stream, b.d_packed, b.d_off + lo, b.d_len + lo, n,
 			                   b.first_id + lo, k, m, buf, rec_cap, h->d_counters, d_hist, modulo, hist_shift, sample, sample_cap);
 		else if (lanes(b))
-			hipLaunchKernelGGL((k_superkmers_lanes<W, false>), dim3(grid_lane), dim3(256), lds_lane, h->stream, b.d_packed, b.d_off + lo, b.d_len + lo, n,
+			hipLaunchKernelGGL((k_superkmers_lanes<W, false, C>), dim3(grid_lane), dim3(256), lds_lane, h->stream, b.d_packed, b.d_off + lo, b.d_len + lo, n,
 			                   b.first_id + lo, k, m, buf, rec_cap, h->d_counters, d_hist, modulo, hist_shift, sample, sample_cap);
 		else
-			hipLaunchKernelGGL(k_superkmers<W>, dim3(grid_wave), dim3(256), 0, h->stream, b.d_packed, b.d_off + lo, b.d_len + lo, n,
+			hipLaunchKernelGGL((k_superkmers<W, C>), dim3(grid_wave), dim3(256), 0, h->stream, b.d_packed, b.d_off + lo, b.d_len + lo, n,
 			                   b.first_id + lo, k, m, buf, rec_cap, h->d_counters, d_hist, modulo, hist_shift, sample, sample_cap);
 	}
 };
 
 // the aggregation kernel of the sweep: a wavefront per bucket of a three-level partition (k_aggregate), or -- rg_debug_set flags
 // bit 21 -- a workgroup per bucket of a two-level one (k_aggregate_wg)
-template <int W>
+template <int W, bool C>
 struct AggLaunch {
+	using RM = RecMem<W, C>;
 	static constexpr int THREADS = 1024, KS = 4096, RS = (W == 1 ? 1024 : 512);  // 132 / 152 KB of LDS: one workgroup of 16 wavefronts per CU
 	static constexpr uint32_t KLIMIT = KS * 5 / 8;
 	bool wg = true;
@@ -1453,10 +1459,10 @@ struct AggLaunch {
 		big = use_big && !use_wg;
 		occ = wg ? 1 : 4;
 		if (wg) {
-			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_aggregate_wg<W, THREADS, KS, RS, false>, THREADS, 0) != hipSuccess || occ < 1) occ = 1;
+			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (k_aggregate_wg<W, THREADS, KS, RS, false, C>), THREADS, 0) != hipSuccess || occ < 1) occ = 1;
 		} else if (big) {
-			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_aggregate<W, false, AGG_SLOTS_BIG>, 64 * agg_waves<W>(), 0) != hipSuccess || occ < 1) occ = 2;
-		} else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_aggregate<W, false>, 64 * agg_waves<W>(), 0) != hipSuccess || occ < 1) occ = 4;
+			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (k_aggregate<W, false, AGG_SLOTS_BIG, C>), 64 * agg_waves<W>(), 0) != hipSuccess || occ < 1) occ = 2;
+		} else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (k_aggregate<W, false, AGG_SLOTS, C>), 64 * agg_waves<W>(), 0) != hipSuccess || occ < 1) occ = 4;
 		(void)hipGetLastError();
 	}
 	uint32_t per_group() const { return wg ? 1u : agg_waves<W>(); }           // buckets a workgroup works on at a time
@@ -1465,37 +1471,39 @@ struct AggLaunch {
 	// occurrences a bucket should hold at most: its distinct k-mers must fit the LDS table at the coverage assemblies are run at
 	uint64_t occ_per_bucket() const { return wg ? (uint64_t)KS * 24 : 2048; }
 	unsigned grid_for_buckets(uint64_t n, int n_cu) const { return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n + per_group() - 1) / per_group(), (uint64_t)n_cu * occ)); }
-	void fast(rg_handle *h, unsigned grid, const Rec<W> *recs, const unsigned long long *begin, uint32_t nb, int k, Slot *log, uint64_t log_cap,
+	void fast(rg_handle *h, unsigned grid, const RM *recs, const unsigned long long *begin, uint32_t nb, int k, Slot *log, uint64_t log_cap,
 	          uint32_t flag_unique, uint32_t *retry, int m, uint32_t rbits) const {
 		if (wg)
-			hipLaunchKernelGGL((k_aggregate_wg<W, THREADS, KS, RS, false>), dim3(grid), dim3(THREADS), 0, h->stream, recs, begin, nb, k, log, log_cap, h->d_counters,
+			hipLaunchKernelGGL((k_aggregate_wg<W, THREADS, KS, RS, false, C>), dim3(grid), dim3(THREADS), 0, h->stream, recs, begin, nb, k, log, log_cap, h->d_counters,
 			                   flag_unique, (const uint32_t *)nullptr, retry, m, rbits);
 		else if (big)
-			hipLaunchKernelGGL((k_aggregate<W, false, AGG_SLOTS_BIG>), dim3(grid), dim3(64 * agg_waves<W>()), 0, h->stream, recs, begin, nb, k, log, log_cap, h->d_counters,
+			hipLaunchKernelGGL((k_aggregate<W, false, AGG_SLOTS_BIG, C>), dim3(grid), dim3(64 * agg_waves<W>()), 0, h->stream, recs, begin, nb, k, log, log_cap, h->d_counters,
 			                   flag_unique, (const uint32_t *)nullptr, retry, m, rbits);
 		else
-			hipLaunchKernelGGL((k_aggregate<W, false>), dim3(grid), dim3(64 * agg_waves<W>()), 0, h->stream, recs, begin, nb, k, log, log_cap, h->d_counters, flag_unique,
+			hipLaunchKernelGGL((k_aggregate<W, false, AGG_SLOTS, C>), dim3(grid), dim3(64 * agg_waves<W>()), 0, h->stream, recs, begin, nb, k, log, log_cap, h->d_counters, flag_unique,
 			                   (const uint32_t *)nullptr, retry, m, rbits);
 	}
-	void slow(rg_handle *h, unsigned grid, const Rec<W> *recs, const unsigned long long *begin, uint32_t nlist, int k, Slot *log, uint64_t log_cap,
+	void slow(rg_handle *h, unsigned grid, const RM *recs, const unsigned long long *begin, uint32_t nlist, int k, Slot *log, uint64_t log_cap,
 	          uint32_t flag_unique, const uint32_t *list, int m, uint32_t rbits) const {
 		if (wg)
-			hipLaunchKernelGGL((k_aggregate_wg<W, THREADS, KS, RS, true>), dim3(grid), dim3(THREADS), 0, h->stream, recs, begin, nlist, k, log, log_cap, h->d_counters,
+			hipLaunchKernelGGL((k_aggregate_wg<W, THREADS, KS, RS, true, C>), dim3(grid), dim3(THREADS), 0, h->stream, recs, begin, nlist, k, log, log_cap, h->d_counters,
 			                   flag_unique, list, (uint32_t *)nullptr, m, rbits);
 		else if (big)
-			hipLaunchKernelGGL((k_aggregate<W, true, AGG_SLOTS_BIG>), dim3(grid), dim3(64 * agg_waves<W>()), 0, h->stream, recs, begin, nlist, k, log, log_cap, h->d_counters,
+			hipLaunchKernelGGL((k_aggregate<W, true, AGG_SLOTS_BIG, C>), dim3(grid), dim3(64 * agg_waves<W>()), 0, h->stream, recs, begin, nlist, k, log, log_cap, h->d_counters,
 			                   flag_unique, list, (uint32_t *)nullptr, m, rbits);
 		else
-			hipLaunchKernelGGL((k_aggregate<W, true>), dim3(grid), dim3(64 * agg_waves<W>()), 0, h->stream, recs, begin, nlist, k, log, log_cap, h->d_counters, flag_unique,
+			hipLaunchKernelGGL((k_aggregate<W, true, AGG_SLOTS, C>), dim3(grid), dim3(64 * agg_waves<W>()), 0, h->stream, recs, begin, nlist, k, log, log_cap, h->d_counters, flag_unique,
 			                   list, (uint32_t *)nullptr, m, rbits);
 	}
 };
 
 // top / nested_bits: the sweep over the sample of the records that sizes the real one (see SAMPLE_BITS): the buckets are
 // numbered by the nested_bits bits below bit `top` of the bucket number, nothing is sampled or probed, no statistics kept.
-template <int W>
+template <int W, bool C>
 static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bool *ok, const void *ext = nullptr, uint64_t ext_n = 0,
                                int top = BUCKET_TOP, int nested_bits = 0) {
+	using RM = RecMem<W, C>;                          // the records' form in memory: 24 / 40 bytes, or 20 when k <= 31
+	constexpr int SCATTER_TILE = scatter_tile<W, C>();
 	const bool nested = nested_bits > 0;
 	*ok = false;
 	h->log_all_unique = false;
@@ -1529,7 +1537,7 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	// number of buckets: at most 2048 k-mer occurrences each, so that at the coverage assemblies are run at (>= 10)
 	// a bucket's distinct k-mers fit the LDS table of k_aggregate; buckets of more diverse inputs are split further
 	// by k_aggregate<SLOW> itself
-	AggLaunch<W> agg;
+	AggLaunch<W, C> agg;
 	agg.plan((h->dbg & 0x200000) != 0, (h->dbg & 0x4000000) != 0);  // bit 21: a workgroup per bucket of a coarser partition (slower as it stands: DESIGN.md); bit 26: the 512-slot tables (tests)
 	int bits = nested ? nested_bits : (int)((h->dbg >> 8) & 0xFF);
 	const bool bits_forced = bits != 0;
@@ -1561,7 +1569,7 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	// workgroups runs behind the first
 	int n_cu = 256;
 	(void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-	SuperkmerLaunch<W> sk;
+	SuperkmerLaunch<W, C> sk;
 	sk.plan(h, n_cu, k, m, total_reads);
 	const int grid1 = sk.grid_max();
 	uint64_t launches1 = 0;  // every launch of k_superkmers leaves up to one open chunk per wavefront
@@ -1569,9 +1577,9 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 		if (b.maxlen >= (uint32_t)k) launches1++;
 	const uint64_t rec_cap = rec_bound + launches1 * (uint64_t)grid1 * 4 * REC_CHUNK;
 	const uint64_t sample_cap = sampling ? (rec_bound >> (SAMPLE_BITS - 2)) + 65536 : 0;  // four times its expected share
-	Rec<W> *d_sample = nullptr;
+	RM *d_sample = nullptr;
 
-	Rec<W> *buf[2] = {nullptr, nullptr};
+	RM *buf[2] = {nullptr, nullptr};
 	unsigned long long *d_seg = nullptr, *d_hist = nullptr, *d_begin = nullptr, *d_sums = nullptr;
 	uint32_t *d_tile = nullptr;
 	uint8_t *d_side = nullptr;  // next-level digit of every record of the current level's output
@@ -1597,7 +1605,7 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 			return fail(h, e_ == hipErrorOutOfMemory ? RG_ERR_NOMEM : RG_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
 		}                                                                                                   \
 	} while (0)
-	if (!ext && pool_alloc(dev, (void **)&buf[0], rec_cap * sizeof(Rec<W>)) != hipSuccess) {  // not enough memory: direct sweep
+	if (!ext && pool_alloc(dev, (void **)&buf[0], rec_cap * sizeof(RM)) != hipSuccess) {  // not enough memory: direct sweep
 		(void)hipGetLastError();
 		{ if (getenv("RG_DEBUG")) fprintf(stderr, "[raygraph] partitioned sweep gives up at line %d (no memory)\n", __LINE__); return RG_OK; }
 	}
@@ -1607,7 +1615,7 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	PTRY(pool_alloc(dev, (void **)&d_hist, std::max<uint64_t>(NBUCK_MAX, 256) * sizeof(unsigned long long)));
 	PTRY(pool_alloc(dev, (void **)&d_begin, (NBUCK_MAX + 1) * sizeof(unsigned long long)));
 	PTRY(pool_alloc(dev, (void **)&d_sums, (NBUCK_MAX / SCAN_PER_BLOCK + 2) * sizeof(unsigned long long)));
-	if (sampling && pool_alloc(dev, (void **)&d_sample, sample_cap * sizeof(Rec<W>)) != hipSuccess) {
+	if (sampling && pool_alloc(dev, (void **)&d_sample, sample_cap * sizeof(RM)) != hipSuccess) {
 		(void)hipGetLastError();
 		d_sample = nullptr;  // no sample, no harm: the rule of thumb above stands
 	}
@@ -1638,7 +1646,7 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 		PTRY(hipStreamSynchronize(h->stream));  // seg1 / tile1 live on this stack frame
 		if (ntiles) {
 			ProfScope ps(h, "k_level_hist");
-			hipLaunchKernelGGL(k_level_hist<W>, dim3((unsigned)ntiles), dim3(256), 0, h->stream, (const Rec<W> *)ext, m, 1u, d_seg, d_tile, hist0_shift, 8, d_hist,
+			hipLaunchKernelGGL((k_level_hist<W, C>), dim3((unsigned)ntiles), dim3(256), 0, h->stream, (const RM *)ext, m, 1u, d_seg, d_tile, hist0_shift, 8, d_hist,
 			                   d_sample, sample_cap, h->d_counters);
 		}
 		PTRY(hipGetLastError());
@@ -1675,7 +1683,7 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 			uint64_t sn = 0;
 			bool sok = false;
 			h->prof_alias = "sample_sweep";
-			const int src = sweep_partitioned_t<W>(h, &slog, &sn, &sok, d_sample, n_sample, BUCKET_TOP - SAMPLE_BITS, 12);
+			const int src = sweep_partitioned_t<W, C>(h, &slog, &sn, &sok, d_sample, n_sample, BUCKET_TOP - SAMPLE_BITS, 12);
 			h->prof_alias = nullptr;
 			pool_free(dev, slog);
 			if (src != RG_OK) {
@@ -1709,15 +1717,15 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 		PTRY(hipMemcpyAsync(d_hist, hist0.data(), 256 * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
 	}
 	if (ext && nlev > 1) {  // received records: both level buffers are ours; one block (see build_table_ranges)
-		PTRY(pool_alloc(dev, (void **)&buf[1], 2 * valid * sizeof(Rec<W>)));
+		PTRY(pool_alloc(dev, (void **)&buf[1], 2 * valid * sizeof(RM)));
 		buf[0] = buf[1] + valid;  // (pool_free ignores it: not a block of its own)
 	} else {
-		PTRY(pool_alloc(dev, (void **)&buf[1], valid * sizeof(Rec<W>)));
+		PTRY(pool_alloc(dev, (void **)&buf[1], valid * sizeof(RM)));
 	}
 
 	// 2. partition levels
 	int cur = 0;                                      // buf[cur] holds the level's input (level 0 of received records: ext)
-	const Rec<W> *level_in = ext ? (const Rec<W> *)ext : buf[0];
+	const RM *level_in = ext ? (const RM *)ext : buf[0];
 	std::vector<unsigned long long> seg_begin = {0, n_in};  // host copy of the current segmentation
 	std::vector<uint32_t> tile_first;
 	int used_bits = 0;
@@ -1748,10 +1756,10 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 		} else if (level > 0) {  // level 0's histogram is in place
 			PTRY(hipMemsetAsync(d_hist, 0, nout * sizeof(unsigned long long), h->stream));
 			ProfScope ps(h, "k_level_hist");
-			hipLaunchKernelGGL(k_level_hist<W>, dim3((unsigned)ntiles), dim3(256), 0, h->stream, level_in, m, S, d_seg, d_tile, shift, db, d_hist);
+			hipLaunchKernelGGL((k_level_hist<W, C>), dim3((unsigned)ntiles), dim3(256), 0, h->stream, level_in, m, S, d_seg, d_tile, shift, db, d_hist);
 			PTRY(hipGetLastError());
 		}
-		if (!buf[cur ^ 1]) PTRY(pool_alloc(dev, (void **)&buf[cur ^ 1], valid * sizeof(Rec<W>)));
+		if (!buf[cur ^ 1]) PTRY(pool_alloc(dev, (void **)&buf[cur ^ 1], valid * sizeof(RM)));
 		// exclusive scan -> d_begin[nout+1]; the scatter's cursors are a copy of it (reusing d_hist)
 		const uint32_t nblk = (uint32_t)((nout + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK);
 		hipLaunchKernelGGL(k_scan_local, dim3(nblk), dim3(256), 0, h->stream, d_hist, d_begin, nout, d_sums);
@@ -1763,10 +1771,10 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 			uint8_t *side_out = (have_next && !(h->dbg & 0x100000)) ? d_side : nullptr;  // bit 20: histograms read the records (tests)
 			const int ndb = have_next ? dbits[level + 1] : 0;
 			if (nested)
-				hipLaunchKernelGGL((k_scatter<W, 1>), dim3((unsigned)ntiles), dim3(SCATTER_THREADS), 0, h->stream, level_in, m, S, d_seg, d_tile, shift, db, d_hist,
+				hipLaunchKernelGGL((k_scatter<W, 1, C>), dim3((unsigned)ntiles), dim3(SCATTER_THREADS), 0, h->stream, level_in, m, S, d_seg, d_tile, shift, db, d_hist,
 				                   buf[cur ^ 1], 0u, side_out, shift - ndb, (1u << ndb) - 1u);
 			else
-				hipLaunchKernelGGL(k_scatter<W>, dim3((unsigned)ntiles), dim3(SCATTER_THREADS), 0, h->stream, level_in, m, S, d_seg, d_tile, shift, db, d_hist,
+				hipLaunchKernelGGL((k_scatter<W, 0, C>), dim3((unsigned)ntiles), dim3(SCATTER_THREADS), 0, h->stream, level_in, m, S, d_seg, d_tile, shift, db, d_hist,
 				                   buf[cur ^ 1], 0u, side_out, shift - ndb, (1u << ndb) - 1u);
 			side_valid = side_out != nullptr;
 		}
@@ -1927,12 +1935,14 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 }
 
 static int sweep_partitioned(rg_handle *h, Slot **out_log, uint64_t *out_n, bool *ok, const void *ext = nullptr, uint64_t ext_n = 0) {
-	return h->W == 1 ? sweep_partitioned_t<1>(h, out_log, out_n, ok, ext, ext_n) : sweep_partitioned_t<2>(h, out_log, out_n, ok, ext, ext_n);
+	if (h->W == 2) return sweep_partitioned_t<2, false>(h, out_log, out_n, ok, ext, ext_n);
+	return rec_compact(h) ? sweep_partitioned_t<1, true>(h, out_log, out_n, ok, ext, ext_n) : sweep_partitioned_t<1, false>(h, out_log, out_n, ok, ext, ext_n);
 }
 
 // ---- record exchange between ranks: stage 1 on the sender (reads -> records, counted per destination) ----
-template <int W>
+template <int W, bool C>
 static int records_local_t(rg_handle *h, uint32_t part, uint32_t nparts) {
+	using RM = RecMem<W, C>;
 	const int dev = h->cfg.device;
 	const int k = h->cfg.k;
 	const int m = k < MMER_MAX ? k : MMER_MAX;
@@ -1963,7 +1973,7 @@ static int records_local_t(rg_handle *h, uint32_t part, uint32_t nparts) {
 	// does the exact bound is used in a second attempt
 	int n_cu = 256;
 	(void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-	SuperkmerLaunch<W> sk;
+	SuperkmerLaunch<W, C> sk;
 	sk.plan(h, n_cu, k, m, total_reads);
 	const int grid1 = sk.grid_max();
 	unsigned long long *d_hist = nullptr;
@@ -1971,8 +1981,8 @@ static int records_local_t(rg_handle *h, uint32_t part, uint32_t nparts) {
 	for (int attempt = 0; attempt < 2; ++attempt) {
 		double frac = attempt ? 1.0 : std::min(1.0, 3.0 / (w + 1));
 		const uint64_t rec_cap = (uint64_t)(rec_bound * frac) + total_reads * 3 + launches1 * (uint64_t)grid1 * 4 * REC_CHUNK;
-		Rec<W> *buf = nullptr;
-		if (pool_alloc(dev, (void **)&buf, rec_cap * sizeof(Rec<W>)) != hipSuccess) {
+		RM *buf = nullptr;
+		if (pool_alloc(dev, (void **)&buf, rec_cap * sizeof(RM)) != hipSuccess) {
 			(void)hipGetLastError();
 			pool_free(dev, d_hist);
 			return fail(h, RG_ERR_NOMEM, "out of device memory for %llu records", (unsigned long long)rec_cap);
@@ -2012,8 +2022,10 @@ static int records_local_t(rg_handle *h, uint32_t part, uint32_t nparts) {
 }
 
 // stage 2 on the sender: one scatter pass by destination rank straight into the caller's send buffer
-template <int W>
+template <int W, bool C>
 static int export_records_t(rg_handle *h, void *d_out) {
+	using RM = RecMem<W, C>;
+	constexpr int SCATTER_TILE = scatter_tile<W, C>();
 	const int dev = h->cfg.device;
 	const int k = h->cfg.k;
 	const int m = k < MMER_MAX ? k : MMER_MAX;
@@ -2039,8 +2051,8 @@ static int export_records_t(rg_handle *h, void *d_out) {
 	if (e == hipSuccess) e = hipMemcpyAsync(d_cur, cursors.data(), 256 * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream);
 	if (e == hipSuccess) {
 		ProfScope ps(h, "k_scatter");
-		hipLaunchKernelGGL(k_scatter<W>, dim3((unsigned)ntiles), dim3(SCATTER_THREADS), 0, h->stream, (const Rec<W> *)h->rec_buf, m, 1u, d_seg, d_tile, 0, 8, d_cur,
-		                   (Rec<W> *)d_out, size, (uint8_t *)nullptr, 0, 0u);
+		hipLaunchKernelGGL((k_scatter<W, 0, C>), dim3((unsigned)ntiles), dim3(SCATTER_THREADS), 0, h->stream, (const RM *)h->rec_buf, m, 1u, d_seg, d_tile, 0, 8, d_cur,
+		                   (RM *)d_out, size, (uint8_t *)nullptr, 0, 0u);
 		e = hipGetLastError();
 	}
 	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
@@ -3054,7 +3066,7 @@ int rg_records_local_part(rg_handle *h, uint32_t part, uint32_t nparts) {
 	if (h->phase != PH_CREATED) return fail(h, RG_ERR_STATE, "rg_records_local called after counting started");
 	if (h->rec_buf) return fail(h, RG_ERR_STATE, "the records of the previous part have not been exported");
 	HIP_TRY(h, hipSetDevice(h->cfg.device));
-	int rc = h->W == 1 ? records_local_t<1>(h, part, nparts) : records_local_t<2>(h, part, nparts);
+	int rc = h->W == 2 ? records_local_t<2, false>(h, part, nparts) : (rec_compact(h) ? records_local_t<1, true>(h, part, nparts) : records_local_t<1, false>(h, part, nparts));
 	if (rc) return rc;
 	if (part == 0) h->stats.occurrences = 0;
 	h->stats.reads = h->n_reads;
@@ -3068,7 +3080,7 @@ int rg_record_counts(rg_handle *h, uint64_t *counts, uint32_t *record_bytes) {
 	if (!h || !counts) return RG_ERR_ARG;
 	if (h->rec_counts.size() != (size_t)h->cfg.size) return fail(h, RG_ERR_STATE, "rg_record_counts needs rg_records_local first");
 	for (int r = 0; r < h->cfg.size; ++r) counts[r] = h->rec_counts[r];
-	if (record_bytes) *record_bytes = (uint32_t)(8 * (2 * h->W + 1));
+	if (record_bytes) *record_bytes = rec_compact(h) ? (uint32_t)sizeof(Rec20) : (uint32_t)(8 * (2 * h->W + 1));
 	return RG_OK;
 }
 
@@ -3080,7 +3092,8 @@ int rg_export_records(rg_handle *h, void *d_out, uint64_t capacity_records) {
 	if (total > capacity_records) return fail(h, RG_ERR_CAPACITY, "record buffer holds %llu records, need %llu", (unsigned long long)capacity_records, (unsigned long long)total);
 	if (total && !d_out) return fail(h, RG_ERR_ARG, "null record buffer");
 	HIP_TRY(h, hipSetDevice(h->cfg.device));
-	return h->W == 1 ? export_records_t<1>(h, d_out) : export_records_t<2>(h, d_out);
+	if (h->W == 2) return export_records_t<2, false>(h, d_out);
+	return rec_compact(h) ? export_records_t<1, true>(h, d_out) : export_records_t<1, false>(h, d_out);
 }
 
 int rg_count_records(rg_handle *h, const void *d_records, uint64_t n_records) {
@@ -3109,7 +3122,8 @@ int rg_count_records(rg_handle *h, const void *d_records, uint64_t n_records) {
 		if (rc) return rc;
 		if (n_records) {
 			ProfScope ps(h, "k_count_records");
-			if (h->W == 1) hipLaunchKernelGGL(k_count_records<1>, dim3(grid_for(n_records)), dim3(256), 0, h->stream, (const Rec<1> *)d_records, n_records, h->cfg.k, h->local.slots, h->local.cap, h->d_counters, (int)C_FILL_LOCAL);
+			if (h->W == 1 && rec_compact(h)) hipLaunchKernelGGL((k_count_records<1, true>), dim3(grid_for(n_records)), dim3(256), 0, h->stream, (const Rec20 *)d_records, n_records, h->cfg.k, h->local.slots, h->local.cap, h->d_counters, (int)C_FILL_LOCAL);
+			else if (h->W == 1) hipLaunchKernelGGL(k_count_records<1>, dim3(grid_for(n_records)), dim3(256), 0, h->stream, (const Rec<1> *)d_records, n_records, h->cfg.k, h->local.slots, h->local.cap, h->d_counters, (int)C_FILL_LOCAL);
 			else hipLaunchKernelGGL(k_count_records<2>, dim3(grid_for(n_records)), dim3(256), 0, h->stream, (const Rec<2> *)d_records, n_records, h->cfg.k, h->local.slots, h->local.cap, h->d_counters, (int)C_FILL_LOCAL);
 			HIP_TRY(h, hipGetLastError());
 		}

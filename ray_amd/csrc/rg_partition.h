@@ -43,6 +43,69 @@ struct Rec {
 	uint64_t w[2 * W + 1];
 };
 
+// The same record in 20 bytes, the form it takes in memory when k <= 31: a record of w = k - m + 1 <= 17 k-mers spans at most
+// 1 + k + 16 + 1 <= 49 bases (98 bits), its minimizer starts before base 64 and the header's two top bits of those fields are
+// zero, which leaves 160 - 98 = 62 bits for the other 62 of the header: position, number of k-mers - 1 (5 bits), the two
+// neighbour bits, minimizer offset (6 bits), read id.  Every pass over the records is bound by their bytes: a sixth less
+// of them.  Kernels work on the unpacked form; only loads and stores see this one.
+//   bits 0..97 bases          bits 98..159: header bits 0..20, 22..29, 31..63
+struct Rec20 {
+	uint32_t w[5];
+};
+template <int W, bool C>
+struct RecMemT {
+	using type = Rec<W>;
+};
+template <>
+struct RecMemT<1, true> {
+	using type = Rec20;
+};
+template <int W, bool C>
+using RecMem = typename RecMemT<W, C>::type;
+__host__ __device__ inline bool rec_compact_for(int W, int k) { return W == 1 && k <= 31; }
+
+__device__ __forceinline__ Rec<1> rec_unpack(const Rec20 &c) {
+	Rec<1> r;
+	r.w[0] = (uint64_t)c.w[0] | ((uint64_t)c.w[1] << 32);
+	r.w[1] = (uint64_t)c.w[2] | ((uint64_t)(c.w[3] & 3u) << 32);
+	const uint64_t h62 = (uint64_t)(c.w[3] >> 2) | ((uint64_t)c.w[4] << 30);
+	const uint64_t H = (h62 & 0x1FFFFFull) | (((h62 >> 21) & 0xFFull) << 22) | ((h62 >> 29) << 31);
+	r.w[2] = h62 == 0x3FFFFFFFFFFFFFFFull ? REC_INVALID : H;
+	return r;
+}
+__device__ __forceinline__ Rec20 rec_pack(const Rec<1> &r, Rec20 *) {
+	const uint64_t H = r.w[2];
+	const uint64_t h62 = (H & 0x1FFFFFull) | (((H >> 22) & 0xFFull) << 21) | ((H >> 31) << 29);
+	Rec20 c;
+	c.w[0] = (uint32_t)r.w[0];
+	c.w[1] = (uint32_t)(r.w[0] >> 32);
+	c.w[2] = (uint32_t)r.w[1];
+	c.w[3] = ((uint32_t)(r.w[1] >> 32) & 3u) | ((uint32_t)h62 << 2);
+	c.w[4] = (uint32_t)(h62 >> 30);
+	return c;
+}
+template <int W>
+__device__ __forceinline__ const Rec<W> &rec_unpack(const Rec<W> &r) {
+	return r;
+}
+template <int W>
+__device__ __forceinline__ const Rec<W> &rec_pack(const Rec<W> &r, Rec<W> *) {
+	return r;
+}
+__device__ __forceinline__ bool rec_valid(const Rec20 &c) { return (c.w[3] >> 2) != 0x3FFFFFFFu || c.w[4] != 0xFFFFFFFFu; }
+template <int W>
+__device__ __forceinline__ bool rec_valid(const Rec<W> &r) {
+	return r.w[2 * W] != REC_INVALID;
+}
+__device__ __forceinline__ void rec_mark_invalid(Rec20 *c) {
+	c->w[3] = 0xFFFFFFFFu;
+	c->w[4] = 0xFFFFFFFFu;
+}
+template <int W>
+__device__ __forceinline__ void rec_mark_invalid(Rec<W> *r) {
+	r->w[2 * W] = REC_INVALID;
+}
+
 __host__ __device__ inline uint32_t fmix32(uint32_t h) {  // murmur3 finalizer: a bijection on 32 bits
 	h ^= h >> 16;
 	h *= 0x85ebca6bu;
@@ -113,6 +176,14 @@ __device__ __forceinline__ uint32_t rec_bucket(const Rec<W> &r, int m) {
 	return bucket_number(canon_mmer(f, m));
 }
 
+template <int W>
+__device__ __forceinline__ uint32_t rec_bucket(const Rec20 &c, int m) {  // W == 1
+	const uint64_t b[2] = {(uint64_t)c.w[0] | ((uint64_t)c.w[1] << 32), (uint64_t)c.w[2] | ((uint64_t)(c.w[3] & 3u) << 32)};
+	const uint32_t moff = (c.w[3] >> 25) & 63u;  // header bits 24..29 = bits 23..28 of the 62, which start at bit 2 of w[3]
+	const uint64_t f = rec_ext<1>(b, moff) & ((1ull << (2 * m)) - 1);
+	return bucket_number(canon_mmer(f, m));
+}
+
 enum PartCounter { PC_REC_CURSOR = 16, PC_REC_OVF, PC_LOG_CURSOR, PC_LOG_OVF, PC_LDS_SPILL, PC_AGG_RETRY, PC_NONUNIQUE, PC_LOG_KEYS, PC_SAMPLE };
 
 // The sample of the records that sizes the partition: the records whose bucket number has its top SAMPLE_BITS bits clear,
@@ -120,8 +191,8 @@ enum PartCounter { PC_REC_CURSOR = 16, PC_REC_OVF, PC_LOG_CURSOR, PC_LOG_OVF, PC
 // input, whatever it is).  The kernels that see every record anyway copy them aside (sample != nullptr); the host counts the
 // distinct k-mers in them with a small sweep of its own and picks the number of buckets from that.
 static constexpr int SAMPLE_BITS = 12;
-template <int W>
-__device__ __forceinline__ void sample_record(const Rec<W> &rec, uint32_t bucket, Rec<W> *__restrict__ sample, uint64_t sample_cap,
+template <typename RM>
+__device__ __forceinline__ void sample_record(const RM &rec, uint32_t bucket, RM *__restrict__ sample, uint64_t sample_cap,
                                               unsigned long long *__restrict__ counters) {
 	if (sample && (bucket >> (BUCKET_TOP - SAMPLE_BITS)) == 0) {
 		const unsigned long long pos = atomicAdd(&counters[PC_SAMPLE], 1ull);
@@ -154,13 +225,14 @@ static constexpr uint32_t SK_WORDS = 24;  // staged 32-bit words: 2 * (1 + 128 +
 // multiplications are quarter rate: the super-k-mer kernels are bound by instruction issue)
 __device__ __forceinline__ uint32_t order_mix(uint32_t c) { return (c ^ 0x5bd1e995u) * 0x9E3779B1u; }
 
-template <int W>
+template <int W, bool C = false>
 __global__ __launch_bounds__(256) void k_superkmers(const uint64_t *__restrict__ P, const uint64_t *__restrict__ offsets,
                                                     const uint32_t *__restrict__ lengths, uint64_t nreads, uint64_t read_id_base,
-                                                    int k, int m, Rec<W> *__restrict__ recs, uint64_t rec_cap,
+                                                    int k, int m, RecMem<W, C> *__restrict__ recs, uint64_t rec_cap,
                                                     unsigned long long *__restrict__ counters,
                                                     unsigned long long *__restrict__ coarse_hist, uint32_t modulo, uint32_t hist_shift,
-                                                    Rec<W> *__restrict__ sample, uint64_t sample_cap) {
+                                                    RecMem<W, C> *__restrict__ sample, uint64_t sample_cap) {
+	using RM = RecMem<W, C>;
 	// coarse_hist[256]: records per first-level digit (bucket >> hist_shift, at most 8 bits), or, with modulo != 0, per
 	// destination rank bucket % modulo (record exchange between ranks, modulo <= 256)
 	constexpr int NB = 2 * W;
@@ -289,7 +361,7 @@ __global__ __launch_bounds__(256) void k_superkmers(const uint64_t *__restrict__
 				const uint32_t c = c0 + (uint32_t)__popcll(b1);
 				if (chunk_used + c > REC_CHUNK) {  // wave-uniform
 					if (have_chunk && !dead)
-						for (uint32_t q = chunk_used + lane; q < REC_CHUNK; q += 64) recs[chunk_base + q].w[NB] = REC_INVALID;
+						for (uint32_t q = chunk_used + lane; q < REC_CHUNK; q += 64) rec_mark_invalid(&recs[chunk_base + q]);
 					unsigned long long nbase = 0;
 					if (lane == 0) nbase = atomicAdd(&counters[PC_REC_CURSOR], (unsigned long long)REC_CHUNK);
 					nbase = __shfl(nbase, 0);
@@ -337,10 +409,11 @@ __global__ __launch_bounds__(256) void k_superkmers(const uint64_t *__restrict__
 							const uint32_t moff = p0 + jm - first;
 							rec.w[NB] = (uint64_t)p | ((uint64_t)(len - 1) << 16) | ((uint64_t)hasL << 22) | ((uint64_t)hasR << 23) |
 							            ((uint64_t)moff << 24) | rid;
-							recs[chunk_base + chunk_used + idx] = rec;
+							const RM packed = rec_pack(rec, (RM *)nullptr);
+							recs[chunk_base + chunk_used + idx] = packed;
 							const uint32_t bk = bucket_number(cn[jm]);
 							atomicAdd(&s_hist[modulo ? bk % modulo : bk >> hist_shift], 1u);
-							sample_record<W>(rec, bk, sample, sample_cap, counters);
+							sample_record<RM>(packed, bk, sample, sample_cap, counters);
 						}
 					}
 				chunk_used += c;
@@ -350,7 +423,7 @@ __global__ __launch_bounds__(256) void k_superkmers(const uint64_t *__restrict__
 		}
 	}
 	if (have_chunk && !dead)
-		for (uint32_t q = chunk_used + lane; q < REC_CHUNK; q += 64) recs[chunk_base + q].w[NB] = REC_INVALID;
+		for (uint32_t q = chunk_used + lane; q < REC_CHUNK; q += 64) rec_mark_invalid(&recs[chunk_base + q]);
 	if (lane == 0 && occ) atomicAdd(&counters[2 /*C_OCC*/], occ);
 	__syncthreads();
 	if (s_hist[threadIdx.x]) atomicAdd(&coarse_hist[threadIdx.x], (unsigned long long)s_hist[threadIdx.x]);
@@ -389,13 +462,14 @@ __device__ __forceinline__ uint32_t order_unmix(uint32_t h) {  // order_mix is a
 	return (h * inv32(0x9E3779B1u)) ^ 0x5bd1e995u;
 }
 
-template <int W, bool WIDE>
+template <int W, bool WIDE, bool C = false>
 __global__ __launch_bounds__(256) void k_superkmers_lanes(const uint64_t *__restrict__ P, const uint64_t *__restrict__ offsets,
                                                           const uint32_t *__restrict__ lengths, uint64_t nreads, uint64_t read_id_base,
-                                                          int k, int m, Rec<W> *__restrict__ recs, uint64_t rec_cap,
+                                                          int k, int m, RecMem<W, C> *__restrict__ recs, uint64_t rec_cap,
                                                           unsigned long long *__restrict__ counters,
                                                           unsigned long long *__restrict__ coarse_hist, uint32_t modulo, uint32_t hist_shift,
-                                                          Rec<W> *__restrict__ sample, uint64_t sample_cap) {
+                                                          RecMem<W, C> *__restrict__ sample, uint64_t sample_cap) {
+	using RM = RecMem<W, C>;
 	constexpr int NB = 2 * W;
 	extern __shared__ unsigned long long s_win_all[];  // [4 wavefronts][w entries][64 lanes]
 	__shared__ unsigned long long s_q[4][SKL_RING];
@@ -566,7 +640,7 @@ __global__ __launch_bounds__(256) void k_superkmers_lanes(const uint64_t *__rest
 					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 					if (chunk_used + cnt > REC_CHUNK) {
 						if (have_chunk && !dead)
-							for (uint32_t q = chunk_used + lane; q < REC_CHUNK; q += 64) recs[chunk_base + q].w[NB] = REC_INVALID;
+							for (uint32_t q = chunk_used + lane; q < REC_CHUNK; q += 64) rec_mark_invalid(&recs[chunk_base + q]);
 						unsigned long long nbase = 0;
 						if (lane == 0) nbase = atomicAdd(&counters[PC_REC_CURSOR], (unsigned long long)REC_CHUNK);
 						nbase = __shfl(nbase, 0);
@@ -614,10 +688,11 @@ __global__ __launch_bounds__(256) void k_superkmers_lanes(const uint64_t *__rest
 						const uint32_t moff = jrel + hasL;
 						rec.w[NB] = (uint64_t)pr | ((uint64_t)(len - 1) << 16) | ((uint64_t)hasL << 22) | ((uint64_t)hasR << 23) |
 						            ((uint64_t)moff << 24) | ((read_id_base + rb + src) << 31);
-						recs[chunk_base + chunk_used + lane] = rec;
+						const RM packed = rec_pack(rec, (RM *)nullptr);
+						recs[chunk_base + chunk_used + lane] = packed;
 						const uint32_t bk = bucket_number(order_unmix((uint32_t)(d >> 32)));
 						atomicAdd(&s_hist[modulo ? bk % modulo : bk >> hist_shift], 1u);
-						sample_record<W>(rec, bk, sample, sample_cap, counters);
+						sample_record<RM>(packed, bk, sample, sample_cap, counters);
 					}
 					chunk_used += cnt;
 					qhead += cnt;
@@ -628,7 +703,7 @@ __global__ __launch_bounds__(256) void k_superkmers_lanes(const uint64_t *__rest
 		}
 	}
 	if (have_chunk && !dead)
-		for (uint32_t q = chunk_used + lane; q < REC_CHUNK; q += 64) recs[chunk_base + q].w[NB] = REC_INVALID;
+		for (uint32_t q = chunk_used + lane; q < REC_CHUNK; q += 64) rec_mark_invalid(&recs[chunk_base + q]);
 #pragma unroll
 	for (int d = 32; d; d >>= 1) occ += __shfl_xor(occ, d);
 	if (lane == 0 && occ) atomicAdd(&counters[2 /*C_OCC*/], occ);
@@ -644,6 +719,9 @@ __global__ __launch_bounds__(256) void k_superkmers_lanes(const uint64_t *__rest
 // 2560 records of 24 bytes + digits = 72 KB: still two workgroups per CU, runs a quarter longer than with 2048 (k_scatter x3
 // 21.9-23.1 -> 21.0-22.3 ms on C2, same box; 3072 would leave one workgroup per CU)
 static constexpr int SCATTER_TILE = 2560;
+static constexpr int SCATTER_TILE_C = 3072;  // 20-byte records: the same 60 KB
+template <int W, bool C>
+constexpr int scatter_tile() { return (W == 1 && C) ? SCATTER_TILE_C : SCATTER_TILE; }
 static constexpr int SCATTER_THREADS = 512;  // threads of a scatter workgroup: 4 records each (256 threads x 8: 23-25 ms for the three levels on C2, 512 x 4: 20.5-22)
 
 __device__ __forceinline__ uint32_t find_segment(const uint32_t *__restrict__ tile_first, uint32_t S, uint32_t tile) {
@@ -658,17 +736,19 @@ __device__ __forceinline__ uint32_t find_segment(const uint32_t *__restrict__ ti
 
 // TAG: 1 for the launches of the record sample's own small sweep, so that a profiler's per-kernel averages of the real
 // partition levels are not diluted by them
-template <int W, int TAG = 0>
-__global__ __launch_bounds__(SCATTER_THREADS) void k_scatter(const Rec<W> *__restrict__ in, int m, uint32_t S,
+template <int W, int TAG = 0, bool C = false>
+__global__ __launch_bounds__(SCATTER_THREADS) void k_scatter(const RecMem<W, C> *__restrict__ in, int m, uint32_t S,
                                                  const unsigned long long *__restrict__ seg_begin,
                                                  const uint32_t *__restrict__ tile_first, int shift, int dbits,
-                                                 unsigned long long *__restrict__ cursors, Rec<W> *__restrict__ out, uint32_t modulo,
+                                                 unsigned long long *__restrict__ cursors, RecMem<W, C> *__restrict__ out, uint32_t modulo,
                                                  uint8_t *__restrict__ side, int next_shift, uint32_t next_mask) {
+	using RM = RecMem<W, C>;
+	constexpr int SCATTER_TILE = scatter_tile<W, C>();
 	// modulo != 0: the digit is bucket % modulo (destination rank of the record exchange) instead of bits of the bucket
 	// side != null: side[i] = the NEXT level's digit of out[i], so that the next level's histogram reads one byte per
 	// record instead of the record (k_level_hist_side)
-	constexpr int NB = 2 * W, PER = SCATTER_TILE / SCATTER_THREADS;
-	__shared__ Rec<W> s_rec[SCATTER_TILE];
+	constexpr int PER = SCATTER_TILE / SCATTER_THREADS;
+	__shared__ RM s_rec[SCATTER_TILE];
 	__shared__ uint8_t s_dig[SCATTER_TILE], s_next[SCATTER_TILE];
 	__shared__ uint32_t s_cnt[256], s_off[256];
 	__shared__ unsigned long long s_gbase[256];
@@ -679,7 +759,7 @@ __global__ __launch_bounds__(SCATTER_THREADS) void k_scatter(const Rec<W> *__res
 	const uint32_t dmask = (1u << dbits) - 1;
 	if (threadIdx.x < 256) s_cnt[threadIdx.x] = 0;
 	__syncthreads();
-	Rec<W> mine[PER];
+	RM mine[PER];
 	uint32_t dig[PER], rank[PER], nxt[PER];
 #pragma unroll
 	for (int j = 0; j < PER; ++j) {
@@ -689,7 +769,7 @@ __global__ __launch_bounds__(SCATTER_THREADS) void k_scatter(const Rec<W> *__res
 		nxt[j] = 0;
 		if (i < end) {
 			mine[j] = in[i];
-			if (mine[j].w[NB] != REC_INVALID) {
+			if (rec_valid(mine[j])) {
 				const uint32_t bk = rec_bucket<W>(mine[j], m);
 				nxt[j] = (bk >> next_shift) & next_mask;
 				dig[j] = modulo ? bk % modulo : (bk >> shift) & dmask;
@@ -790,12 +870,14 @@ __global__ __launch_bounds__(256) void k_level_hist_side(const uint8_t *__restri
 }
 
 // digit histogram of one level: hist[(seg << dbits) + digit]
-template <int W>
-__global__ __launch_bounds__(256) void k_level_hist(const Rec<W> *__restrict__ in, int m, uint32_t S,
+template <int W, bool C = false>
+__global__ __launch_bounds__(256) void k_level_hist(const RecMem<W, C> *__restrict__ in, int m, uint32_t S,
                                                     const unsigned long long *__restrict__ seg_begin,
                                                     const uint32_t *__restrict__ tile_first, int shift, int dbits,
-                                                    unsigned long long *__restrict__ hist, Rec<W> *__restrict__ sample = nullptr,
+                                                    unsigned long long *__restrict__ hist, RecMem<W, C> *__restrict__ sample = nullptr,
                                                     uint64_t sample_cap = 0, unsigned long long *__restrict__ counters = nullptr) {
+	using RM = RecMem<W, C>;
+	constexpr int SCATTER_TILE = scatter_tile<W, C>();
 	__shared__ uint32_t s_cnt[256];
 	const uint32_t seg = find_segment(tile_first, S, blockIdx.x);
 	const uint64_t begin = seg_begin[seg] + (uint64_t)(blockIdx.x - tile_first[seg]) * SCATTER_TILE;
@@ -804,11 +886,11 @@ __global__ __launch_bounds__(256) void k_level_hist(const Rec<W> *__restrict__ i
 	s_cnt[threadIdx.x] = 0;
 	__syncthreads();
 	for (uint64_t i = begin + threadIdx.x; i < end; i += 256) {
-		Rec<W> r = in[i];
-		if (r.w[2 * W] != REC_INVALID) {
+		const RM r = in[i];
+		if (rec_valid(r)) {
 			const uint32_t bk = rec_bucket<W>(r, m);
 			atomicAdd(&s_cnt[(bk >> shift) & dmask], 1u);
-			sample_record<W>(r, bk, sample, sample_cap, counters);
+			sample_record<RM>(r, bk, sample, sample_cap, counters);
 		}
 	}
 	__syncthreads();
@@ -844,16 +926,29 @@ __global__ __launch_bounds__(256) void k_scan_local(const unsigned long long *__
 	}
 	if (threadIdx.x == 255) block_sums[blockIdx.x] = s_t[255];
 }
-__global__ void k_scan_sums(unsigned long long *__restrict__ block_sums, uint32_t nblocks, unsigned long long *__restrict__ total) {
-	if (threadIdx.x == 0 && blockIdx.x == 0) {
-		unsigned long long run = 0;
-		for (uint32_t i = 0; i < nblocks; ++i) {
-			unsigned long long t = block_sums[i];
-			block_sums[i] = run;
-			run += t;
-		}
-		*total = run;
+// one wavefront (launched as <<<1, 64>>>): every lane sums a contiguous share of the block sums, the shares are scanned with
+// shuffles, every lane writes its share back (one thread walking 2048 sums took 0.24 ms)
+__global__ __launch_bounds__(64) void k_scan_sums(unsigned long long *__restrict__ block_sums, uint32_t nblocks, unsigned long long *__restrict__ total) {
+	if (blockIdx.x != 0) return;
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t per = (nblocks + 63u) / 64u;
+	const uint32_t lo = lane * per < nblocks ? lane * per : nblocks;
+	const uint32_t hi = lo + per < nblocks ? lo + per : nblocks;
+	unsigned long long sum = 0;
+	for (uint32_t i = lo; i < hi; ++i) sum += block_sums[i];
+	unsigned long long incl = sum;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		const unsigned long long o = __shfl_up(incl, d);
+		if (lane >= (uint32_t)d) incl += o;
 	}
+	unsigned long long run = incl - sum;
+	for (uint32_t i = lo; i < hi; ++i) {
+		const unsigned long long t = block_sums[i];
+		block_sums[i] = run;
+		run += t;
+	}
+	if (lane == 63) *total = incl;
 }
 __global__ __launch_bounds__(256) void k_scan_add(unsigned long long *__restrict__ out, uint64_t n,
                                                   const unsigned long long *__restrict__ block_sums,
@@ -989,8 +1084,8 @@ __device__ __forceinline__ bool lds_upsert(AggTable<W, SLOTS> &t, uint32_t hash,
 // SLOW == false: every bucket once, no sub-passes; a bucket whose k-mers do not fit the table is dropped unwritten
 // and its number appended to retry_list (counters[PC_AGG_RETRY] of them).  SLOW == true: the buckets of
 // bucket_list, with sub-passes.  Two instantiations so that the common path carries none of the retry machinery.
-template <int W, bool SLOW, int SLOTS = AGG_SLOTS>
-__global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const Rec<W> *__restrict__ recs,
+template <int W, bool SLOW, int SLOTS = AGG_SLOTS, bool C = false>
+__global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<W, C> *__restrict__ recs,
                                                               const unsigned long long *__restrict__ bucket_begin, uint32_t nbuckets,
                                                               int k, Slot *__restrict__ log, uint64_t log_cap,
                                                               unsigned long long *__restrict__ counters, uint32_t flag_unique,
@@ -1009,6 +1104,9 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const Rec<W> 
 	__shared__ AggTable<W, SLOTS> s_tables[agg_waves<W>()];
 	constexpr uint32_t LIMIT = agg_limit<SLOTS>();
 	__shared__ RecTable<W> s_rtables[agg_waves<W>()];
+	// 20-byte records: a round's 64 records are loaded as 5 x 64 consecutive words (whole cache lines, where a lane loading
+	// its own 20 bytes straddles them: 14.3 ms on C2 against 12.9 with the 24-byte records) and handed to their lanes through LDS
+	__shared__ uint32_t s_stage[C ? agg_waves<W>() : 1][C ? 320 : 1];
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	AggTable<W, SLOTS> &T = s_tables[wave];
 	RecTable<W> &R = s_rtables[wave];
@@ -1016,6 +1114,34 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const Rec<W> 
 	const uint64_t mask1 = (k > 32) ? ((1ull << (2 * k - 64)) - 1) : 0ull;
 	const unsigned long long NO_CHUNK = ~0ull;
 	unsigned long long chunk_base = NO_CHUNK;  // wave-uniform
+	RecMem<W, C> nxt = {};
+	// records [first, end) of a round (at most 64) -> nxt: a lane's own record, or (C) words lane, lane + 64, ... of the round
+	auto load_round = [&](uint64_t first, uint64_t end) {
+		if constexpr (C) {
+			const uint32_t *__restrict__ p = reinterpret_cast<const uint32_t *>(recs + first);
+			const uint32_t nd = 5u * (uint32_t)(end - first < 64 ? end - first : 64);
+#pragma unroll
+			for (uint32_t j = 0; j < 5; ++j)
+				if (lane + 64u * j < nd) nxt.w[j] = p[lane + 64u * j];
+		} else {
+			if (first + lane < end) nxt = recs[first + lane];
+		}
+	};
+	auto take_round = [&]() -> Rec<W> {
+		if constexpr (C) {
+			uint32_t *st = s_stage[wave];
+#pragma unroll
+			for (uint32_t j = 0; j < 5; ++j) st[lane + 64u * j] = nxt.w[j];
+			wave_sync();
+			Rec20 c;
+#pragma unroll
+			for (uint32_t j = 0; j < 5; ++j) c.w[j] = st[5u * lane + j];
+			wave_sync();
+			return rec_unpack(c);
+		} else {
+			return nxt;
+		}
+	};
 	uint32_t chunk_used = 0;
 	unsigned long long keys_written = 0;
 	uint32_t nonunique_flushes = 0;
@@ -1234,9 +1360,6 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const Rec<W> 
 		cb = bucket_begin[bb];
 		ce = bucket_begin[bb + 1];
 	}
-	Rec<W> nxt;
-#pragma unroll
-	for (int i = 0; i <= NB; ++i) nxt.w[i] = 0;
 	bool prefetched = false;  // nxt holds records [cb, cb+64) of the current bucket
 	while (b < nbuckets && !log_full) {
 		const uint32_t b2 = b + stride;  // the bucket after this one: its bounds are fetched now, used at the last round
@@ -1255,16 +1378,16 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const Rec<W> 
 			const uint32_t rl = SLOW ? min(31u - (uint32_t)__clz((int)nsub), rbits) : 0u;
 			const uint32_t rmask = (1u << rl) - 1u, rsub = sub & rmask;
 			const uint32_t hsub = sub >> rl, hn = nsub >> rl;
-			if (!prefetched && cb + lane < ce) nxt = recs[cb + lane];
+			if (!prefetched) load_round(cb, ce);
 			prefetched = false;
 			for (uint64_t base = cb; base < ce && !overflow; base += 64) {
-				const Rec<W> rec = nxt;
+				const Rec<W> rec = take_round();
 				bool pending = base + lane < ce;
 				if (SLOW && rl && pending && (rec_bucket<W>(rec, m) & rmask) != rsub) pending = false;  // a record of another pass
 				if (base + 64 < ce) {
-					if (base + 64 + lane < ce) nxt = recs[base + 64 + lane];
+					load_round(base + 64, ce);
 				} else if (sub + 1 == nsub) {  // last round of the last sub-pass: the next bucket's first round
-					if (nb_begin + lane < nb_end) nxt = recs[nb_begin + lane];
+					load_round(nb_begin, nb_end);
 					prefetched = true;
 					next_ready = true;
 				}
@@ -1494,8 +1617,8 @@ __device__ __forceinline__ bool wg_upsert(WgTables<W, KS, RS> &t, bool active, u
 	return !searching;
 }
 
-template <int W, int THREADS, int KS, int RS, bool SLOW>
-__global__ __launch_bounds__(THREADS) void k_aggregate_wg(const Rec<W> *__restrict__ recs, const unsigned long long *__restrict__ bucket_begin,
+template <int W, int THREADS, int KS, int RS, bool SLOW, bool C = false>
+__global__ __launch_bounds__(THREADS) void k_aggregate_wg(const RecMem<W, C> *__restrict__ recs, const unsigned long long *__restrict__ bucket_begin,
                                                           uint32_t nbuckets, int k, Slot *__restrict__ log, uint64_t log_cap,
                                                           unsigned long long *__restrict__ counters, uint32_t flag_unique,
                                                           const uint32_t *__restrict__ bucket_list, uint32_t *__restrict__ retry_list, int m,
@@ -1693,9 +1816,7 @@ __global__ __launch_bounds__(THREADS) void k_aggregate_wg(const Rec<W> *__restri
 			lds_barrier();
 			uint32_t blk = wave, next_blk = 0;
 			bool finished = false, counted = false, carry = false;
-			Rec<W> nxt;
-#pragma unroll
-			for (int i = 0; i <= NB; ++i) nxt.w[i] = 0;
+			RecMem<W, C> nxt = {};
 			if (blk < nblk && cb + (uint64_t)blk * 64 + lane < ce) nxt = recs[cb + (uint64_t)blk * 64 + lane];
 			uint64_t bw[NB], stamp0 = 0;
 			unsigned long long fp = 0;
@@ -1708,7 +1829,7 @@ __global__ __launch_bounds__(THREADS) void k_aggregate_wg(const Rec<W> *__restri
 							finished = true;
 							break;
 						}
-						const Rec<W> rec = nxt;
+						const Rec<W> rec = rec_unpack(nxt);
 						pending = cb + (uint64_t)blk * 64 + lane < ce;
 						if (SLOW && rl && pending && (rec_bucket<W>(rec, m) & rmask) != rsub) pending = false;  // a record of another pass
 						next_blk = 0;
@@ -1849,8 +1970,8 @@ __global__ __launch_bounds__(THREADS) void k_aggregate_wg(const Rec<W> *__restri
 
 // Fallback of the record path: every k-mer of every record goes straight to the vertex table (one upsert per
 // occurrence), used when an estimate of the partitioned path was exceeded.
-template <int W>
-__global__ __launch_bounds__(256) void k_count_records(const Rec<W> *__restrict__ recs, uint64_t n, int k, Slot *__restrict__ tab,
+template <int W, bool C = false>
+__global__ __launch_bounds__(256) void k_count_records(const RecMem<W, C> *__restrict__ recs, uint64_t n, int k, Slot *__restrict__ tab,
                                                        uint64_t cap, unsigned long long *__restrict__ counters, int c_fill) {
 	constexpr int NB = 2 * W;
 	__shared__ uint32_t s_claimed;
@@ -1861,7 +1982,7 @@ __global__ __launch_bounds__(256) void k_count_records(const Rec<W> *__restrict_
 	uint32_t claimed = 0;
 	bool failed = false;
 	for (uint64_t ri = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; ri < n; ri += (uint64_t)gridDim.x * blockDim.x) {
-		const Rec<W> rec = recs[ri];
+		const Rec<W> rec = rec_unpack(recs[ri]);
 		if (rec.w[NB] == REC_INVALID) continue;
 		uint64_t bw[NB];
 #pragma unroll

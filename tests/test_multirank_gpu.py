@@ -125,6 +125,7 @@ def markers_ranks(builders, n_reads):
             start, n = sum(counts[:dst]), counts[dst]
             part = keys[start * unit:(start + n) * unit].clone()
             ans = torch.full((max(1, n),), 0x7FFFFFFF, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()   # the builder works on a stream of its own: torch's copies and fills must have landed
             b.markers_answer(part.data_ptr(), n, ans.data_ptr())
             answers[src][dst] = ans[:n]
     torch.cuda.synchronize()
@@ -158,11 +159,13 @@ def purge_ranks(builders):
             start, n = sum(counts[:dst]), counts[dst]
             part = keys[start * unit:(start + n) * unit].clone()
             ans = torch.zeros(max(1, n), dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()   # (as above)
             b.purge_answer(part.data_ptr(), n, ans.data_ptr())
             answers[src][dst] = ans[:n]
     torch.cuda.synchronize()
     for src, b in enumerate(builders):
         back = torch.cat(answers[src]) if sum(asked[src][0]) else torch.zeros(1, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
         b.purge_apply(back.data_ptr(), sum(asked[src][0]))
 
 
