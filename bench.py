@@ -332,6 +332,7 @@ def main():
         Kb = 8 * W
         occ0, cand0, recs0 = st["occurrences"], st["candidates"], st["superkmer_records"]
         rec_bytes = 20 if k <= 31 else 8 * (2 * W + 1)  # rg_record_counts reports the same
+        ent_bytes = 16 if W == 1 else 32                # an admitted entry between the log and the table (rg_table.h)
         alg_bytes = {
             "k_count": occ0 * (L / (4.0 * n_per_read) + Kb + 8),            # read bits + key compare + count RMW
             "k_superkmers": occ0 * L / (4.0 * n_per_read) + recs0 * rec_bytes,  # read bits in, records out
@@ -353,8 +354,8 @@ def main():
             "k_histogram": st["table_slots"] * 32,
             "k_entry_hist": st["log_entries"] * 32,                                                  # log scan
             "k_admit_count": st["log_entries"] * 33,                                                 # log scan + one mark byte per entry, nothing written
-            "k_scatter_entries": st["log_entries"] * 32 + st["stored_pairs"] * 32,                   # first level: log in, admitted entries out (further levels added below)
-            "k_build_ranges": st["stored_pairs"] * 32 + st["table_slots"] * 32,                      # entries in, every slot of the table written once
+            "k_scatter_entries": st["log_entries"] * 33 + st["stored_pairs"] * ent_bytes,                   # first level: log in, admitted entries out (further levels added below)
+            "k_build_ranges": st["stored_pairs"] * ent_bytes + st["table_slots"] * 32,                      # entries in, every slot of the table written once
             "k_xor_hist": (st["log_entries"] if "k_build_ranges" in kprof or "k_insert_admitted" in kprof else st["table_slots"]) * 32,
             "k_xor_keys": (st["log_entries"] if "k_build_ranges" in kprof or "k_insert_admitted" in kprof else st["table_slots"]) * 32 + cand0 * 17,  # key scan in, one 16-byte item + digit byte out
             "k_scatter16": cand0 * (16 + 12),                                                        # last level: items in, packed word + slot index out (middle levels added below)
@@ -364,7 +365,7 @@ def main():
         if "k_build_ranges" in kprof:
             del alg_bytes["k_insert_admitted"]   # only the few entries that left their range go through it: no byte model
         if kprof.get("k_scatter_entries", (0, 0))[1] > args.steps:
-            alg_bytes["k_scatter_entries"] += (kprof["k_scatter_entries"][1] / args.steps - 1) * 2 * st["stored_pairs"] * 32
+            alg_bytes["k_scatter_entries"] += (kprof["k_scatter_entries"][1] / args.steps - 1) * 2 * st["stored_pairs"] * ent_bytes
         if kprof.get("k_scatter16", (0, 0))[1] > args.steps:
             alg_bytes["k_scatter16"] += (kprof["k_scatter16"][1] / args.steps - 1) * cand0 * 33
         if "k_scatter64" in kprof:

@@ -2642,7 +2642,10 @@ static int build_table_ranges(rg_handle *h, const Slot *log, uint64_t n_log, uin
 		dbits[2] = rem - dbits[1];
 	}
 	const uint64_t NBUCK = 1ull << bits;
-	Slot *tab = nullptr, *buf[2] = {nullptr, nullptr}, *ovf = nullptr;
+	Slot *tab = nullptr, *ovf = nullptr;
+	uint8_t *buf[2] = {nullptr, nullptr};  // admitted entries between the levels: Ent<W>, 16 bytes for one-word keys
+	const size_t esz = h->W == 1 ? sizeof(Ent<1>) : sizeof(Ent<2>);
+	const uint64_t TILE = h->W == 1 ? ent_tile<1>() : ent_tile<2>();
 	unsigned long long *d_seg = nullptr, *d_hist = nullptr, *d_begin = nullptr, *d_sums = nullptr;
 	uint32_t *d_tile = nullptr;
 	uint8_t *d_side = nullptr;
@@ -2661,8 +2664,8 @@ static int build_table_ranges(rg_handle *h, const Slot *log, uint64_t n_log, uin
 	hipError_t e = pool_alloc(dev, (void **)&tab, cap * sizeof(Slot));
 	// the two entry buffers are one block: a few large blocks of the same sizes every time are what the pool can hand out
 	// again when the device is nearly full (C5's share per GPU), where many middling ones go back to the driver and return
-	if (e == hipSuccess) e = pool_alloc(dev, (void **)&buf[0], (nlev > 1 ? 2 : 1) * retained * sizeof(Slot));
-	if (e == hipSuccess && nlev > 1) buf[1] = buf[0] + retained;
+	if (e == hipSuccess) e = pool_alloc(dev, (void **)&buf[0], (nlev > 1 ? 2 : 1) * retained * esz);
+	if (e == hipSuccess && nlev > 1) buf[1] = buf[0] + retained * esz;
 	if (e == hipSuccess) e = pool_alloc(dev, (void **)&ovf, ovf_cap * sizeof(Slot));
 	if (e == hipSuccess) e = pool_alloc(dev, (void **)&d_seg, (SEGMAX + 1) * sizeof(unsigned long long));
 	if (e == hipSuccess) e = pool_alloc(dev, (void **)&d_tile, (SEGMAX + 1) * sizeof(uint32_t));
@@ -2689,7 +2692,7 @@ static int build_table_ranges(rg_handle *h, const Slot *log, uint64_t n_log, uin
 	TTRY(hipMemsetAsync(h->d_counters + C_FILL, 0, sizeof(unsigned long long), h->stream));
 	std::vector<unsigned long long> seg_begin = {0, n_log};
 	std::vector<uint32_t> tile_first;
-	const Slot *level_in = log;
+	const void *level_in = log;
 	int used_bits = 0, cur = 0;
 	for (int level = 0; level < nlev; ++level) {
 		const uint32_t S = (uint32_t)seg_begin.size() - 1;
@@ -2699,7 +2702,7 @@ static int build_table_ranges(rg_handle *h, const Slot *log, uint64_t n_log, uin
 		uint64_t ntiles = 0;
 		for (uint32_t sgi = 0; sgi < S; ++sgi) {
 			tile_first[sgi] = (uint32_t)ntiles;
-			ntiles += (seg_begin[sgi + 1] - seg_begin[sgi] + ENT_TILE - 1) / ENT_TILE;
+			ntiles += (seg_begin[sgi + 1] - seg_begin[sgi] + TILE - 1) / TILE;
 		}
 		tile_first[S] = (uint32_t)ntiles;
 		TTRY(hipMemcpyAsync(d_seg, seg_begin.data(), (S + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
@@ -2715,7 +2718,8 @@ static int build_table_ranges(rg_handle *h, const Slot *log, uint64_t n_log, uin
 			else hipLaunchKernelGGL(k_entry_hist<2>, dim3(grid), dim3(256), 0, h->stream, log, n_log, bits, shift, (1u << db) - 1u, d_hist);
 		} else {
 			ProfScope ps(h, "k_level_hist_side");
-			hipLaunchKernelGGL(k_level_hist_side<ENT_TILE>, dim3((unsigned)((ntiles + HIST_SIDE_TILES - 1) / HIST_SIDE_TILES)), dim3(256), 0, h->stream, d_side, S, d_seg, d_tile, db, d_hist, (uint32_t)ntiles);
+			if (h->W == 1) hipLaunchKernelGGL(k_level_hist_side<ent_tile<1>()>, dim3((unsigned)((ntiles + HIST_SIDE_TILES - 1) / HIST_SIDE_TILES)), dim3(256), 0, h->stream, d_side, S, d_seg, d_tile, db, d_hist, (uint32_t)ntiles);
+			else hipLaunchKernelGGL(k_level_hist_side<ent_tile<2>()>, dim3((unsigned)((ntiles + HIST_SIDE_TILES - 1) / HIST_SIDE_TILES)), dim3(256), 0, h->stream, d_side, S, d_seg, d_tile, db, d_hist, (uint32_t)ntiles);
 		}
 		TTRY(hipGetLastError());
 		const uint32_t nblk = (uint32_t)((nout + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK);
@@ -2728,13 +2732,13 @@ static int build_table_ranges(rg_handle *h, const Slot *log, uint64_t n_log, uin
 			const bool have_next = level + 1 < nlev;
 			const int ndb = have_next ? dbits[level + 1] : 0;
 			uint8_t *side_out = have_next ? d_side : nullptr;
-			Slot *out = buf[cur];
+			uint8_t *out = buf[cur];
 			if (h->W == 1) {
-				if (level == 0) hipLaunchKernelGGL((k_scatter_entries<1, true>), dim3((unsigned)ntiles), dim3(ENT_THREADS), 0, h->stream, level_in, S, d_seg, d_tile, bits, shift, db, d_hist, out, side_out, shift - ndb, (1u << ndb) - 1u, lost);
-				else hipLaunchKernelGGL((k_scatter_entries<1, false>), dim3((unsigned)ntiles), dim3(ENT_THREADS), 0, h->stream, level_in, S, d_seg, d_tile, bits, shift, db, d_hist, out, side_out, shift - ndb, (1u << ndb) - 1u, (const uint8_t *)nullptr);
+				if (level == 0) hipLaunchKernelGGL((k_scatter_entries<1, true>), dim3((unsigned)ntiles), dim3(ENT_THREADS), 0, h->stream, (const Slot *)level_in, S, d_seg, d_tile, bits, shift, db, d_hist, (Ent<1> *)out, side_out, shift - ndb, (1u << ndb) - 1u, lost);
+				else hipLaunchKernelGGL((k_scatter_entries<1, false>), dim3((unsigned)ntiles), dim3(ENT_THREADS), 0, h->stream, (const Ent<1> *)level_in, S, d_seg, d_tile, bits, shift, db, d_hist, (Ent<1> *)out, side_out, shift - ndb, (1u << ndb) - 1u, (const uint8_t *)nullptr);
 			} else {
-				if (level == 0) hipLaunchKernelGGL((k_scatter_entries<2, true>), dim3((unsigned)ntiles), dim3(ENT_THREADS), 0, h->stream, level_in, S, d_seg, d_tile, bits, shift, db, d_hist, out, side_out, shift - ndb, (1u << ndb) - 1u, lost);
-				else hipLaunchKernelGGL((k_scatter_entries<2, false>), dim3((unsigned)ntiles), dim3(ENT_THREADS), 0, h->stream, level_in, S, d_seg, d_tile, bits, shift, db, d_hist, out, side_out, shift - ndb, (1u << ndb) - 1u, (const uint8_t *)nullptr);
+				if (level == 0) hipLaunchKernelGGL((k_scatter_entries<2, true>), dim3((unsigned)ntiles), dim3(ENT_THREADS), 0, h->stream, (const Slot *)level_in, S, d_seg, d_tile, bits, shift, db, d_hist, (Ent<2> *)out, side_out, shift - ndb, (1u << ndb) - 1u, lost);
+				else hipLaunchKernelGGL((k_scatter_entries<2, false>), dim3((unsigned)ntiles), dim3(ENT_THREADS), 0, h->stream, (const Ent<2> *)level_in, S, d_seg, d_tile, bits, shift, db, d_hist, (Ent<2> *)out, side_out, shift - ndb, (1u << ndb) - 1u, (const uint8_t *)nullptr);
 			}
 		}
 		TTRY(hipGetLastError());
@@ -2764,8 +2768,8 @@ static int build_table_ranges(rg_handle *h, const Slot *log, uint64_t n_log, uin
 		               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_build_ranges<2>, 1024, lds)) != hipSuccess || occ < 1)
 			occ = 1;
 		const unsigned grid = (unsigned)std::min<uint64_t>(NR, (uint64_t)n_cu * occ);
-		if (h->W == 1) hipLaunchKernelGGL(k_build_ranges<1>, dim3(grid), dim3(1024), lds, h->stream, level_in, d_begin, (uint32_t)NR, bits, tab, cap, ovf, ovf_cap, h->d_counters);
-		else hipLaunchKernelGGL(k_build_ranges<2>, dim3(grid), dim3(1024), lds, h->stream, level_in, d_begin, (uint32_t)NR, bits, tab, cap, ovf, ovf_cap, h->d_counters);
+		if (h->W == 1) hipLaunchKernelGGL(k_build_ranges<1>, dim3(grid), dim3(1024), lds, h->stream, (const Ent<1> *)level_in, d_begin, (uint32_t)NR, bits, tab, cap, ovf, ovf_cap, h->d_counters);
+		else hipLaunchKernelGGL(k_build_ranges<2>, dim3(grid), dim3(1024), lds, h->stream, (const Ent<2> *)level_in, d_begin, (uint32_t)NR, bits, tab, cap, ovf, ovf_cap, h->d_counters);
 	}
 	TTRY(hipGetLastError());
 	int rc = sync_counters(h);

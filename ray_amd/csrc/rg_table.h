@@ -22,11 +22,54 @@
 // the ordinary insert after every range had been written, so there is no free slot between its home and itself.
 #pragma once
 #include "rg_device.h"
+#include <type_traits>
 
 namespace rg {
 
 static constexpr int ENT_TILE = 2048;     // entries per scatter tile: 64 KB of LDS
 static constexpr int ENT_THREADS = 512;
+
+// An admitted entry on its way to the table.  The arrival stamp has done its work once admission is decided and one-word keys
+// have no second word, so they travel as 16 bytes (half the bytes of every pass between the log and the table, tiles of
+// twice the entries); two-word keys keep the slot's 32.
+struct Ent16 {
+	uint64_t k0, meta;
+};
+template <int W>
+struct EntT {
+	using type = Slot;
+};
+template <>
+struct EntT<1> {
+	using type = Ent16;
+};
+template <int W>
+using Ent = typename EntT<W>::type;
+template <int W>
+constexpr int ent_tile() { return ENT_TILE * (int)(sizeof(Slot) / sizeof(Ent<W>)); }
+__device__ __forceinline__ Slot ent_load(const Slot *p) {
+	const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(&p->k0), b = *reinterpret_cast<const ulonglong2 *>(&p->stamp);
+	Slot v;
+	v.k0 = a.x;
+	v.k1 = a.y;
+	v.stamp = b.x;
+	v.meta = b.y;
+	return v;
+}
+__device__ __forceinline__ Slot ent_load(const Ent16 *p) {
+	const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(p);
+	Slot v;
+	v.k0 = a.x;
+	v.k1 = EMPTY;
+	v.stamp = INF_STAMP;
+	v.meta = a.y;
+	return v;
+}
+__device__ __forceinline__ void ent_pack(const Slot &v, Slot *out) { *out = v; }
+__device__ __forceinline__ void ent_pack(const Slot &v, Ent16 *out) {
+	out->k0 = v.k0;
+	out->meta = v.meta;
+}
 
 enum TableCounter { TC_OVF_CURSOR = 27, TC_OVF_LOST = 28 };
 
@@ -69,14 +112,17 @@ __global__ __launch_bounds__(256) void k_entry_hist(const Slot *__restrict__ in,
 // unused chunk entries and entries that are not admitted are dropped here; lost != nullptr: the log is as the sweep wrote
 // it and the admission rule is applied on the way (lost[i] = the mark of entry i), lost == nullptr: admitted in place.
 template <int W, bool FIRST>
-__global__ __launch_bounds__(ENT_THREADS) void k_scatter_entries(const Slot *__restrict__ in, uint32_t S, const unsigned long long *__restrict__ seg_begin,
+__global__ __launch_bounds__(ENT_THREADS) void k_scatter_entries(const std::conditional_t<FIRST, Slot, Ent<W>> *__restrict__ in, uint32_t S,
+                                                                 const unsigned long long *__restrict__ seg_begin,
                                                                  const uint32_t *__restrict__ tile_first, int bits, int shift, int dbits,
-                                                                 unsigned long long *__restrict__ cursors, Slot *__restrict__ out,
+                                                                 unsigned long long *__restrict__ cursors, Ent<W> *__restrict__ out,
                                                                  uint8_t *__restrict__ side, int next_shift, uint32_t next_mask,
                                                                  const uint8_t *__restrict__ lost) {
-	constexpr int PER = ENT_TILE / ENT_THREADS;
-	__shared__ Slot s_ent[ENT_TILE];
-	__shared__ uint8_t s_dig[ENT_TILE], s_next[ENT_TILE];
+	using E = Ent<W>;
+	constexpr int TILE = ent_tile<W>();
+	constexpr int PER = TILE / ENT_THREADS;
+	__shared__ E s_ent[TILE];
+	__shared__ uint8_t s_dig[TILE], s_next[TILE];
 	__shared__ uint32_t s_cnt[256], s_off[256], s_scan[8];
 	__shared__ unsigned long long s_gbase[256];
 	uint32_t lo = 0, hi = S;  // largest s with tile_first[s] <= tile
@@ -86,12 +132,12 @@ __global__ __launch_bounds__(ENT_THREADS) void k_scatter_entries(const Slot *__r
 		else hi = mid;
 	}
 	const uint32_t seg = lo;
-	const uint64_t begin = seg_begin[seg] + (uint64_t)(blockIdx.x - tile_first[seg]) * ENT_TILE;
-	const uint64_t end = begin + ENT_TILE < seg_begin[seg + 1] ? begin + ENT_TILE : seg_begin[seg + 1];
+	const uint64_t begin = seg_begin[seg] + (uint64_t)(blockIdx.x - tile_first[seg]) * TILE;
+	const uint64_t end = begin + TILE < seg_begin[seg + 1] ? begin + TILE : seg_begin[seg + 1];
 	const uint32_t dmask = (1u << dbits) - 1;
 	if (threadIdx.x < 256) s_cnt[threadIdx.x] = 0;
 	__syncthreads();
-	Slot mine[PER];
+	E mine[PER];
 	uint32_t dig[PER], rank[PER], nxt[PER];
 #pragma unroll
 	for (int j = 0; j < PER; ++j) {
@@ -100,18 +146,15 @@ __global__ __launch_bounds__(ENT_THREADS) void k_scatter_entries(const Slot *__r
 		rank[j] = 0;
 		nxt[j] = 0;
 		if (i < end) {
-			const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(&in[i].k0), b = *reinterpret_cast<const ulonglong2 *>(&in[i].stamp);
-			mine[j].k0 = a.x;
-			mine[j].k1 = a.y;
-			mine[j].stamp = b.x;
-			mine[j].meta = b.y;
+			Slot v = ent_load(&in[i]);
 			bool keep = true;
-			if (FIRST) keep = lost ? admit_entry(mine[j], lost, i) : entry_admitted(mine[j]);
+			if (FIRST) keep = lost ? admit_entry(v, lost, i) : entry_admitted(v);
 			if (keep) {
-				const uint32_t r = entry_range<W>(mine[j], bits);
+				const uint32_t r = entry_range<W>(v, bits);
 				dig[j] = (r >> shift) & dmask;
 				nxt[j] = (r >> next_shift) & next_mask;
 				rank[j] = atomicAdd(&s_cnt[dig[j]], 1u);
+				ent_pack(v, &mine[j]);
 			}
 		}
 	}
@@ -146,20 +189,20 @@ __global__ __launch_bounds__(ENT_THREADS) void k_scatter_entries(const Slot *__r
 	for (int j = 0; j < PER; ++j)
 		if (dig[j] != 0xFFFFFFFFu) {
 			const uint32_t pos = s_off[dig[j]] + rank[j];
-			*reinterpret_cast<ulonglong2 *>(&s_ent[pos].k0) = make_ulonglong2(mine[j].k0, mine[j].k1);
-			*reinterpret_cast<ulonglong2 *>(&s_ent[pos].stamp) = make_ulonglong2(mine[j].stamp, mine[j].meta);
+			s_ent[pos] = mine[j];
 			s_dig[pos] = (uint8_t)dig[j];
 			s_next[pos] = (uint8_t)nxt[j];
 		}
 	__syncthreads();
-	// two threads per entry: 16 bytes each, so that a wavefront writes 1 KB of consecutive bytes of a run
-	for (uint32_t i2 = threadIdx.x; i2 < 2 * total; i2 += ENT_THREADS) {
-		const uint32_t i = i2 >> 1, half = i2 & 1u;
+	// 16 bytes per thread and step (two threads per 32-byte entry): a wavefront writes 1 KB of consecutive bytes of a run
+	constexpr uint32_t PARTS = sizeof(E) / 16;
+	for (uint32_t i2 = threadIdx.x; i2 < PARTS * total; i2 += ENT_THREADS) {
+		const uint32_t i = i2 / PARTS, part = i2 % PARTS;
 		const uint32_t d = s_dig[i];
 		const unsigned long long dst = s_gbase[d] + (i - s_off[d]);
-		const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(reinterpret_cast<const uint64_t *>(&s_ent[i]) + 2 * half);
-		*reinterpret_cast<ulonglong2 *>(reinterpret_cast<uint64_t *>(&out[dst]) + 2 * half) = v;
-		if (side && half == 0) side[dst] = s_next[i];
+		const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(reinterpret_cast<const uint64_t *>(&s_ent[i]) + 2 * part);
+		*reinterpret_cast<ulonglong2 *>(reinterpret_cast<uint64_t *>(&out[dst]) + 2 * part) = v;
+		if (side && part == 0) side[dst] = s_next[i];
 	}
 }
 
@@ -171,7 +214,7 @@ __global__ __launch_bounds__(ENT_THREADS) void k_scatter_entries(const Slot *__r
 // way).
 static constexpr uint32_t RANGE_SPAN_MAX = 4096;
 template <int W>
-__global__ __launch_bounds__(1024) void k_build_ranges(const Slot *__restrict__ entries, const unsigned long long *__restrict__ range_begin,
+__global__ __launch_bounds__(1024) void k_build_ranges(const Ent<W> *__restrict__ entries, const unsigned long long *__restrict__ range_begin,
                                                        uint32_t nranges, int bits, Slot *__restrict__ tab, uint64_t cap, Slot *__restrict__ ovf,
                                                        uint64_t ovf_cap, unsigned long long *__restrict__ counters) {
 	extern __shared__ Slot s_tab[];  // the largest span of this table: (cap >> bits) + 1 slots (two workgroups per CU up to 2560)
@@ -187,7 +230,8 @@ __global__ __launch_bounds__(1024) void k_build_ranges(const Slot *__restrict__ 
 		__syncthreads();
 		const uint64_t begin = range_begin[r], end = range_begin[r + 1];
 		for (uint64_t e = begin + threadIdx.x; e < end; e += blockDim.x) {
-			const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(&entries[e].k0), b = *reinterpret_cast<const ulonglong2 *>(&entries[e].stamp);
+			const Slot v = ent_load(&entries[e]);
+			const ulonglong2 a = make_ulonglong2(v.k0, v.k1), b = make_ulonglong2(v.stamp, v.meta);
 			const uint64_t home = slot_home(slot_hash<W>(a.x, W == 2 ? a.y : 0), cap);
 			uint32_t s = (uint32_t)(home - lo);  // the partition guarantees lo <= home <= hi
 			bool done = false;

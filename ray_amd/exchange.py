@@ -30,12 +30,14 @@ def _staged(group):
 
 
 def _a2a(recv, src, out_counts, in_counts, unit, group, async_op=False):
-    """all-to-all(v) of `unit`-byte items held in uint8 tensors.  Items of a multiple of 8 bytes travel as int64
-    elements, so that no per-peer element count comes near 2^31 (3.2 GB of entries to one peer at N = 2)."""
-    if unit % 8 == 0 and recv.numel() % 8 == 0 and src.numel() % 8 == 0 and recv.storage_offset() % 8 == 0 and src.storage_offset() % 8 == 0:
-        q = unit // 8
-        return dist.all_to_all_single(recv.view(torch.int64), src.view(torch.int64), output_split_sizes=[c * q for c in out_counts],
-                                      input_split_sizes=[c * q for c in in_counts], group=group, async_op=async_op)
+    """all-to-all(v) of `unit`-byte items held in uint8 tensors.  The items travel as the widest integer type that divides
+    them (32-byte entries as int64, 20-byte records as int32), so that no per-peer element count comes near 2^31
+    (3.2 GB of entries, 6.9 GB of records to one peer at N = 2)."""
+    for es, dt in ((8, torch.int64), (4, torch.int32), (2, torch.int16)):
+        if unit % es == 0 and recv.numel() % es == 0 and src.numel() % es == 0 and recv.storage_offset() % es == 0 and src.storage_offset() % es == 0:
+            q = unit // es
+            return dist.all_to_all_single(recv.view(dt), src.view(dt), output_split_sizes=[c * q for c in out_counts],
+                                          input_split_sizes=[c * q for c in in_counts], group=group, async_op=async_op)
     return dist.all_to_all_single(recv, src, output_split_sizes=[c * unit for c in out_counts],
                                   input_split_sizes=[c * unit for c in in_counts], group=group, async_op=async_op)
 
