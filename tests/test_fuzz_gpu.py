@@ -52,3 +52,29 @@ def test_random_case(oracle, seed):
     c = _case(seed)
     packed, offsets, lengths = make_reads_numpy(c["genome"], c["read_len"], c["n_reads"], seed=500 + seed, error=c["error"], ragged=c["ragged"])
     gpu_vs_oracle(oracle, packed, offsets, lengths, c["k"], bloom_bits=c["bloom_bits"], sweeps=c["sweeps"])
+
+
+@pytest.mark.parametrize("k", [21, 31, 47])
+def test_record_header_extremes(oracle, k):
+    """what a super-k-mer record's header must hold at its largest: read ids just below 2^33 (the arrival stamps only order
+    the occurrences, so the results are those of ids from 0) and positions up to the longest read the reference stores
+    (65534 bases: the wavefront-per-read kernel), in the 20-byte records of k <= 31 and in the full-size ones; a Bloom filter
+    small enough that false positives, which depend on the order, do occur"""
+    rng = np.random.default_rng(k)
+    genome = rng.integers(0, 4, size=70000, dtype=np.uint8)
+    reads = [genome[:65534], genome[3000:68534], genome[::-1][:40000].copy()]
+    for _ in range(300):
+        a = int(rng.integers(0, 69000))
+        reads.append(genome[a:a + int(rng.integers(k, 900))])
+    lengths = np.array([len(r) for r in reads], dtype=np.uint32)
+    nbytes = (lengths.astype(np.int64) + 3) // 4
+    offsets = np.concatenate([[0], np.cumsum(nbytes)[:-1]]).astype(np.uint64)
+    packed = np.zeros(int(nbytes.sum()) + 16, dtype=np.uint8)
+    for r, o in zip(reads, offsets):
+        pad = np.zeros((len(r) + 3) // 4 * 4, dtype=np.uint8)
+        pad[:len(r)] = r
+        q = pad.reshape(-1, 4)
+        packed[int(o):int(o) + len(q)] = q[:, 0] | (q[:, 1] << 2) | (q[:, 2] << 4) | (q[:, 3] << 6)
+    first = (1 << 33) - 2 - len(reads)
+    gpu_vs_oracle(oracle, packed, offsets, lengths, k, bloom_bits=300_000, first_read_id=first,
+                  sweeps=(1 | 16 | (12 << 8), 1 | 32 | (14 << 8) | 0x8000000, 1 | 16 | (9 << 8) | 0x10000, 2 | 32))
