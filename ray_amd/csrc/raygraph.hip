@@ -1867,6 +1867,7 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 		}
 		bool too_small = false;
 		hipError_t e0 = hipMemsetAsync(h->d_counters + PC_LOG_CURSOR, 0, 6 * sizeof(unsigned long long), h->stream);
+		if (e0 == hipSuccess) e0 = hipMemsetAsync(h->d_counters + PC_CUT_ANCHORED, 0, 2 * sizeof(unsigned long long), h->stream);
 		if (e0 == hipSuccess && mostly_overflowing) {
 			// an attempt at whole buckets would be thrown away for most of them (C2 with 1 % errors: 47 ms): every bucket goes
 			// through the splitting kernel at once
@@ -1930,6 +1931,9 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 		        (unsigned long long)total_reads, (unsigned long long)h->h_counters[C_OCC], bits, (unsigned long long)n_in, (unsigned long long)valid,
 		        (unsigned long long)rec_cap, (unsigned long long)*out_n, (unsigned long long)log_cap, (unsigned long long)h->h_counters[PC_LDS_SPILL],
 		        (unsigned long long)h->h_counters[PC_AGG_RETRY]);
+	if (getenv("RG_DEBUG") && (h->h_counters[PC_CUT_ANCHORED] || h->h_counters[PC_CUT_EXPANDED]))
+		fprintf(stderr, "[raygraph] records cut by a read end: %llu added to an anchor's k-mers, %llu expanded\n", (unsigned long long)h->h_counters[PC_CUT_ANCHORED],
+		        (unsigned long long)h->h_counters[PC_CUT_EXPANDED]);
 #undef PTRY
 	return RG_OK;
 }

@@ -131,16 +131,27 @@ __device__ __forceinline__ uint32_t canon_mmer(uint64_t f, int m) {
 	return (uint32_t)(f < r ? f : r);
 }
 
+// Two-word keys: the compiler turns the chain of selects over a record's four words into one load at a computed address,
+// which leaves the words in a private array -- in LDS while there is room for 64 bytes per thread, in scratch memory
+// otherwise.  An empty asm statement per word makes each a register value that only selects can choose between.
+__device__ __forceinline__ uint64_t in_register(uint64_t v) {
+	uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+	asm volatile("" : "+v"(lo), "+v"(hi));
+	return ((uint64_t)hi << 32) | lo;
+}
+
 // base t of a record
 template <int W>
 __device__ __forceinline__ uint32_t rec_base(const uint64_t (&b)[2 * W], uint32_t t) {
 	uint32_t j = t >> 5;
+	if (W == 2) {
+		const uint64_t b0 = in_register(b[0]), b1 = in_register(b[1]), b2 = in_register(b[2]), b3 = in_register(b[3]);
+		const uint64_t lo = (j & 1u) ? b1 : b0, hi = (j & 1u) ? b3 : b2;
+		const uint64_t word = (j & 2u) ? hi : lo;
+		return (uint32_t)(word >> ((t & 31u) * 2u)) & 3u;
+	}
 	uint64_t word = b[0];
 	if (j == 1) word = b[1];
-	if (W == 2) {
-		if (j == 2) word = b[2];
-		if (j == 3) word = b[3];
-	}
 	return (uint32_t)(word >> ((t & 31u) * 2u)) & 3u;
 }
 
@@ -149,19 +160,13 @@ template <int W>
 __device__ __forceinline__ uint64_t rec_ext(const uint64_t (&b)[2 * W], uint32_t t) {
 	uint32_t j = t >> 5, s = (t & 31u) * 2u;
 	uint64_t lo = b[0], hi = b[1];
-	if (j == 1) {
-		lo = b[1];
-		hi = (W == 2) ? b[2 * W - 2] : 0;
-	}
 	if (W == 2) {
-		if (j == 2) {
-			lo = b[2];
-			hi = b[3];
-		}
-		if (j == 3) {
-			lo = b[3];
-			hi = 0;
-		}
+		const uint64_t b0 = in_register(b[0]), b1 = in_register(b[1]), b2 = in_register(b[2]), b3 = in_register(b[3]);
+		lo = (j & 2u) ? ((j & 1u) ? b3 : b2) : ((j & 1u) ? b1 : b0);
+		hi = (j & 2u) ? ((j & 1u) ? 0ull : b3) : ((j & 1u) ? b2 : b1);
+	} else if (j == 1) {
+		lo = b[1];
+		hi = 0;
 	}
 	return s ? ((lo >> s) | (hi << (64 - s))) : lo;
 }
@@ -184,7 +189,7 @@ __device__ __forceinline__ uint32_t rec_bucket(const Rec20 &c, int m) {  // W ==
 	return bucket_number(canon_mmer(f, m));
 }
 
-enum PartCounter { PC_REC_CURSOR = 16, PC_REC_OVF, PC_LOG_CURSOR, PC_LOG_OVF, PC_LDS_SPILL, PC_AGG_RETRY, PC_NONUNIQUE, PC_LOG_KEYS, PC_SAMPLE };
+enum PartCounter { PC_REC_CURSOR = 16, PC_REC_OVF, PC_LOG_CURSOR, PC_LOG_OVF, PC_LDS_SPILL, PC_AGG_RETRY, PC_NONUNIQUE, PC_LOG_KEYS, PC_SAMPLE, PC_CUT_ANCHORED = 30, PC_CUT_EXPANDED = 31 };
 
 // The sample of the records that sizes the partition: the records whose bucket number has its top SAMPLE_BITS bits clear,
 // i.e. the first 2^(b - SAMPLE_BITS) buckets of a partition into 2^b, whole (the bucket number is a hash: 1 / 4096 of the
@@ -1044,8 +1049,8 @@ static_assert(AGG_SLOTS == 256 && AGG_SLOTS_BIG == 512, "the slot is the top 8 o
 static constexpr uint32_t AGG_MAX_SUBPASSES = 4096;
 
 template <int W, int SLOTS>
-__device__ __forceinline__ bool lds_upsert(AggTable<W, SLOTS> &t, uint32_t hash, uint64_t i0, uint64_t i1, uint64_t stamp, uint32_t emask,
-                                           uint32_t weight) {
+__device__ __forceinline__ int lds_upsert(AggTable<W, SLOTS> &t, uint32_t hash, uint64_t i0, uint64_t i1, uint64_t stamp, uint32_t emask,
+                                          uint32_t weight) {  // -> the k-mer's slot, or -1: no slot left
 	uint32_t s = hash >> (SLOTS == 512 ? 23 : 24);
 	for (uint32_t probe = 0; probe < (uint32_t)SLOTS; ++probe) {
 		uint64_t c0 = t.k0[s];
@@ -1073,13 +1078,34 @@ __device__ __forceinline__ bool lds_upsert(AggTable<W, SLOTS> &t, uint32_t hash,
 				atomicMin(reinterpret_cast<unsigned long long *>(&t.stamp[s]), stamp);
 				atomicAdd(&t.cnt[s], weight);
 				atomicOr(&t.edges[s], emask);
-				return true;
+				return (int)s;
 			}
 		}
 		s = (s + 1) & ((uint32_t)SLOTS - 1);
 	}
-	return false;
+	return -1;
 }
+
+// Anchors: the records that a read end cut short are the many that nothing merges -- no other read repeats them -- and
+// with long windows (k = 63: w = 49) nearly every k-mer is expanded on their account (C3's shape: 18 of the 25 ms of
+// k_aggregate, measured by leaving them out).  But such a record is a stretch of the complete super-k-mer that other
+// reads of the same locus and strand brought whole, aligned at the minimizer.  So a bucket is walked twice: first the
+// records that no read end cut, merged and expanded as ever -- and the first ANCHORS distinct ones of them remembered with
+// the table slot of each of their k-mers; then the cut ones: one that lies inside an anchor, base for base, adds its
+// multiplicity and its arrival stamps to the anchor's slots (two LDS atomics per k-mer: no extraction, reverse complement,
+// hash or probe; its edge bits are a subset of the anchor's), any other goes the usual way.
+static constexpr uint32_t ANCHORS = 32;
+static constexpr uint32_t ANCHOR_KMERS = 52;  // >= the longest window (w <= 49), a multiple of 4
+template <int W>
+struct AnchorTable {
+	uint64_t w[2 * W][ANCHORS];
+	uint32_t mm[ANCHORS];    // the minimizer as it stands in the record (not canonical)
+	uint32_t tag[ANCHORS];   // as RecTable's
+	uint8_t kslot[ANCHORS][ANCHOR_KMERS];
+	uint32_t fill;
+};
+template <int W, bool SLOW, int SLOTS>
+constexpr bool agg_anchors() { return W == 2 && !SLOW && SLOTS == 256; }  // one-word keys: no LDS to spare at three workgroups per CU
 
 // SLOW == false: every bucket once, no sub-passes; a bucket whose k-mers do not fit the table is dropped unwritten
 // and its number appended to retry_list (counters[PC_AGG_RETRY] of them).  SLOW == true: the buckets of
@@ -1107,9 +1133,13 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<
 	// 20-byte records: a round's 64 records are loaded as 5 x 64 consecutive words (whole cache lines, where a lane loading
 	// its own 20 bytes straddles them: 14.3 ms on C2 against 12.9 with the 24-byte records) and handed to their lanes through LDS
 	__shared__ uint32_t s_stage[C ? agg_waves<W>() : 1][C ? 320 : 1];
+	constexpr bool ANCH = agg_anchors<W, SLOW, SLOTS>();
+	__shared__ AnchorTable<W> s_anchors[ANCH ? agg_waves<W>() : 1];
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	AggTable<W, SLOTS> &T = s_tables[wave];
 	RecTable<W> &R = s_rtables[wave];
+	AnchorTable<W> &A = s_anchors[ANCH ? wave : 0];
+	const int mlen = m;
 	const uint64_t mask0 = (2 * k >= 64) ? ~0ull : ((1ull << (2 * k)) - 1);
 	const uint64_t mask1 = (k > 32) ? ((1ull << (2 * k - 64)) - 1) : 0ull;
 	const unsigned long long NO_CHUNK = ~0ull;
@@ -1145,6 +1175,7 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<
 	uint32_t chunk_used = 0;
 	unsigned long long keys_written = 0;
 	uint32_t nonunique_flushes = 0;
+	uint32_t cut_anchored = 0, cut_expanded = 0;  // statistics (lane 0): records cut by a read end that lay inside an anchor / were expanded
 	bool log_full = false;         // wave-uniform
 	bool partial_flushes = false;  // last resort for a bucket that more than AGG_MAX_SUBPASSES passes cannot hold
 
@@ -1230,12 +1261,13 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<
 	// lanes idle for most of the w iterations.  Lane t of a round finds its record by a binary search over the prefix
 	// sums of the lengths (held in registers, read through the lane crossbar) and takes its k-mer and the two
 	// neighbour bases straight out of the record's words.
-	auto expand = [&](uint32_t sub, uint32_t nsub) -> bool {
+	// anchoring (ANCH): the records are whole super-k-mers; the first ANCHORS of the bucket become anchors
+	auto expand = [&](uint32_t sub, uint32_t nsub, bool anchoring) -> bool {
 		const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)R.fill);
 		if (n == 0) return true;
 		for (uint32_t e0 = 0; e0 < n; e0 += 64) {
 			const uint32_t e = e0 + lane;
-			uint32_t rlen = 0, rsl = 0, rweight = 0;
+			uint32_t rlen = 0, rsl = 0, rweight = 0, ranch = ANCHORS;
 			uint64_t rstamp = 0;
 			if (e < n) {
 				rsl = R.list[e];
@@ -1245,6 +1277,21 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<
 				R.fp[rsl] = 0;  // the slot is free again (its words and tag stay readable until it is claimed anew)
 				R.cnt[rsl] = 0;
 				R.stamp[rsl] = INF_STAMP;
+				if (ANCH && anchoring) {
+					const uint32_t a = atomicAdd(&A.fill, 1u);
+					if (a < ANCHORS) {
+						ranch = a;
+						uint64_t aw[NB];
+#pragma unroll
+						for (int q = 0; q < NB; ++q) {
+							aw[q] = R.w[q][rsl];
+							A.w[q][a] = aw[q];
+						}
+						const uint32_t tg = R.tag[rsl];
+						A.tag[a] = tg;
+						A.mm[a] = (uint32_t)(rec_ext<W>(aw, (tg >> 8) & 127u) & ((1ull << (2 * mlen)) - 1));
+					}
+				}
 			}
 			uint32_t incl = rlen;  // inclusive prefix sums of the lengths
 #pragma unroll
@@ -1268,6 +1315,7 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<
 				const uint32_t sl = (uint32_t)__shfl((int)rsl, (int)own);
 				const uint32_t i = t - (uint32_t)__shfl((int)rpre, (int)own);
 				const uint32_t weight = (uint32_t)__shfl((int)rweight, (int)own);
+				const uint32_t anch = ANCH ? (uint32_t)__shfl((int)ranch, (int)own) : ANCHORS;
 				const uint64_t stamp0 = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(rstamp >> 32), (int)own) << 32) | (uint32_t)__shfl((int)(uint32_t)rstamp, (int)own);
 				if (t < total) {
 					uint64_t bw[NB];
@@ -1293,9 +1341,10 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<
 					uint64_t i0, i1;
 					to_internal<W>(use_rc ? r0 : f0, use_rc ? r1 : f1, i0, i1);
 					const uint32_t hx = agg_hash<W>(i0, i1);
+					int kslot = 0;
 					if (SLOW && ((hx >> (SLOTS == 512 ? 11 : 12)) & (nsub - 1)) != sub) {
 						// another sub-pass owns this k-mer
-					} else if (!lds_upsert<W, SLOTS>(T, hx, i0, i1, stamp0 + i, em, weight)) {
+					} else if ((kslot = lds_upsert<W, SLOTS>(T, hx, i0, i1, stamp0 + i, em, weight)) < 0) {
 						if (!partial_flushes) {
 							T.spilled = 2;  // no slot left: the attempt is void
 						} else {
@@ -1314,6 +1363,8 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<
 						atomicAdd(&counters[PC_LDS_SPILL], 1ull);
 						T.spilled = 1;
 						}
+					} else if (ANCH && anch < ANCHORS) {
+						A.kslot[anch][i] = (uint8_t)kslot;
 					}
 				}
 				if (checked) {
@@ -1371,9 +1422,16 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<
 		}
 		// one pass over the bucket's records for sub-pass `sub` of `nsub`; true = the k-mer table overflowed
 		bool next_ready = false;  // nxt already holds the next bucket's first round
-		auto pass = [&](uint32_t sub, uint32_t nsub) -> bool {
+		// phase (ANCH only): 0 = the records no read end cut, which become anchors; 1 = the cut ones; 2 = all alike.
+		// last: nothing of this bucket is read after this call (the next bucket's first round may be fetched)
+		auto pass = [&](uint32_t sub, uint32_t nsub, int phase, bool last) -> bool {
 			bool overflow = false;
 			next_ready = false;
+			if (ANCH && phase == 0) {
+				if (lane == 0) A.fill = 0;
+				wave_sync();
+			}
+			const uint32_t n_anch = (ANCH && phase == 1) ? min((uint32_t)__builtin_amdgcn_readfirstlane((int)A.fill), ANCHORS) : 0u;
 			// record levels of the split (SLOW only), then hash levels
 			const uint32_t rl = SLOW ? min(31u - (uint32_t)__clz((int)nsub), rbits) : 0u;
 			const uint32_t rmask = (1u << rl) - 1u, rsub = sub & rmask;
@@ -1386,7 +1444,7 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<
 				if (SLOW && rl && pending && (rec_bucket<W>(rec, m) & rmask) != rsub) pending = false;  // a record of another pass
 				if (base + 64 < ce) {
 					load_round(base + 64, ce);
-				} else if (sub + 1 == nsub) {  // last round of the last sub-pass: the next bucket's first round
+				} else if (last && sub + 1 == nsub) {  // last round of the last sub-pass: the next bucket's first round
 					load_round(nb_begin, nb_end);
 					prefetched = true;
 					next_ready = true;
@@ -1398,10 +1456,95 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<
 					const uint64_t hdr = rec.w[NB];
 					tag = (uint32_t)(hdr >> 16) & 0x7FFFu;
 					stamp0 = ((hdr >> 31) << 16) | ((uint32_t)hdr & 0xFFFFu);
+#pragma unroll
+					for (int i = 0; i < NB; ++i) bw[i] = rec.w[i];
+				}
+				if (ANCH && phase != 2) {
+					const bool whole = ((tag >> 6) & 3u) == 3u;
+					if (pending && whole != (phase == 0)) pending = false;  // the other phase's record
+				}
+				if (ANCH && phase == 1 && n_anch) {
+					// a cut record inside an anchor, base for base: its k-mer j is the anchor's k-mer dd + j
+					const uint32_t lenT = (tag & 63u) + 1, hasLT = (tag >> 6) & 1u, hasRT = (tag >> 7) & 1u, moffT = (tag >> 8) & 127u;
+					const uint32_t nbT = hasLT + lenT + (uint32_t)k - 1 + hasRT;
+					const uint32_t mmT = (uint32_t)(rec_ext<W>(bw, moffT) & ((1ull << (2 * mlen)) - 1));
+					uint32_t found = ANCHORS, dd = 0, from = 0;
+					bool searching = pending;
+					while (__any(searching)) {
+						// the next anchor with this record's minimizer (every lane reads the same words) ...
+						uint32_t cand = ANCHORS;
+						for (uint32_t a = 0; a < n_anch; ++a) {
+							const uint32_t mma = A.mm[a];
+							if (searching && cand == ANCHORS && a >= from && mma == mmT) cand = a;
+						}
+						if (searching && cand == ANCHORS) searching = false;
+						// ... compared base for base, every lane against its own candidate
+						if (searching) {
+							const uint32_t tga = A.tag[cand];
+							const uint32_t moffS = (tga >> 8) & 127u, lenS = (tga & 63u) + 1;
+							const uint32_t delta = moffS - moffT;  // the record's base 0 is the anchor's base delta
+							const uint32_t d1 = delta + hasLT;     // its first k-mer starts there; the anchor's k-mer 0 at base 1
+							bool same = moffS >= moffT && d1 >= 1u && d1 - 1u + lenT <= lenS && delta + nbT <= lenS + (uint32_t)k + 1u;
+							if (same) {
+								uint64_t sw[NB];
+#pragma unroll
+								for (int q = 0; q < NB; ++q) sw[q] = A.w[q][cand];
+#pragma unroll
+								for (int q = 0; q < NB; ++q)
+									if (nbT > 32u * q) {
+										uint64_t x = rec_ext<W>(sw, delta + 32u * q);
+										const uint32_t rem = nbT - 32u * q;
+										if (rem < 32u) x &= (1ull << (2u * rem)) - 1;
+										same = same && x == bw[q];
+									}
+							}
+							if (same) {
+								found = cand;
+								dd = d1 - 1u;
+								searching = false;
+							} else {
+								from = cand + 1;
+							}
+						}
+					}
+					const bool anchored = pending && found < ANCHORS;
+					const uint32_t clen = anchored ? lenT : 0u;
+					uint32_t incl = clen;
+#pragma unroll
+					for (int d = 1; d < 64; d <<= 1) {
+						const uint32_t o = __shfl_up(incl, d);
+						if (lane >= (uint32_t)d) incl += o;
+					}
+					const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+					const uint32_t cpre = incl - clen;
+					for (uint32_t t0 = 0; t0 < total; t0 += 64) {  // a lane per k-mer, as in expand()
+						const uint32_t t = t0 + lane;
+						uint32_t own = 0;
+#pragma unroll
+						for (uint32_t st = 32; st; st >>= 1) {
+							const uint32_t v = (uint32_t)__shfl((int)incl, (int)(own + st - 1));
+							if (v <= t) own += st;
+						}
+						own = own < 63u ? own : 63u;
+						const uint32_t a = (uint32_t)__shfl((int)found, (int)own);
+						const uint32_t i = t - (uint32_t)__shfl((int)cpre, (int)own);
+						const uint32_t d0 = (uint32_t)__shfl((int)dd, (int)own);
+						const uint64_t st0 = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(stamp0 >> 32), (int)own) << 32) | (uint32_t)__shfl((int)(uint32_t)stamp0, (int)own);
+						if (t < total) {
+							const uint32_t ks = A.kslot[a][d0 + i];
+							atomicAdd(&T.cnt[ks], 1u);
+							atomicMin(reinterpret_cast<unsigned long long *>(&T.stamp[ks]), (unsigned long long)(st0 + i));
+						}
+					}
+					if (anchored) pending = false;
+					cut_anchored += (uint32_t)__popcll(__ballot(anchored));
+					cut_expanded += (uint32_t)__popcll(__ballot(pending));
+					if (total) wave_sync();
+				}
+				if (!ANCH || __any(pending)) {  // (a round of cut records that all lay inside anchors has nothing to insert)
 					uint64_t h = (uint64_t)tag * 0x9E3779B97F4A7C15ull;
 #pragma unroll
 					for (int i = 0; i < NB; ++i) {
-						bw[i] = rec.w[i];
 						h = (h ^ bw[i]) * 0xC2B2AE3D27D4EB4Full;
 						h ^= h >> 29;
 					}
@@ -1410,6 +1553,7 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<
 					fp = h | 1ull;
 					sl = (uint32_t)(h >> 40) & (RT_SLOTS - 1);
 				}
+				if (!ANCH || __any(pending))
 				do {
 					bool owner = false;
 					if (pending) {
@@ -1450,14 +1594,14 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<
 					}
 					wave_sync();
 				} while (__any(pending));
-				if ((uint32_t)__builtin_amdgcn_readfirstlane((int)R.fill) > RT_FLUSH) overflow = !expand(hsub, hn);
+				if ((uint32_t)__builtin_amdgcn_readfirstlane((int)R.fill) > RT_FLUSH) overflow = !expand(hsub, hn, phase == 0);
 			}
-			if (!overflow) overflow = !expand(hsub, hn);
+			if (!overflow) overflow = !expand(hsub, hn, phase == 0);
 			return overflow;
 		};
 		partial_flushes = false;
 		if (!SLOW) {
-			if (!pass(0, 1)) {
+			if (ANCH ? !(pass(0, 1, 0, false) || pass(0, 1, 1, true)) : !pass(0, 1, 2, true)) {
 				flush();  // once per bucket: the entries are unique in the log
 			} else {      // leave the bucket to the second launch; nothing of it was written
 				discard();
@@ -1472,7 +1616,7 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<
 			// be halved any more is redone with partial flushes, and its entries alone lose the unique mark.
 			uint32_t nsub = 2, sub = 0;  // a listed bucket is known not to fit in one pass
 			for (;;) {
-				if (!pass(sub, nsub)) {
+				if (!pass(sub, nsub, 2, true)) {
 					flush();  // once per (bucket, node): the entries are unique in the log
 					partial_flushes = false;
 					bool done = false;
@@ -1507,6 +1651,8 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<
 	if (lane == 0) {
 		if (keys_written) atomicAdd(&counters[PC_LOG_KEYS], keys_written);
 		if (nonunique_flushes) atomicAdd(&counters[PC_NONUNIQUE], (unsigned long long)nonunique_flushes);
+		if (cut_anchored) atomicAdd(&counters[PC_CUT_ANCHORED], (unsigned long long)cut_anchored);
+		if (cut_expanded) atomicAdd(&counters[PC_CUT_EXPANDED], (unsigned long long)cut_expanded);
 	}
 	// close the last chunk
 	if (chunk_base != NO_CHUNK)
