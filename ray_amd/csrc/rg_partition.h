@@ -1094,18 +1094,22 @@ __device__ __forceinline__ int lds_upsert(AggTable<W, SLOTS> &t, uint32_t hash, 
 // the table slot of each of their k-mers; then the cut ones: one that lies inside an anchor, base for base, adds its
 // multiplicity and its arrival stamps to the anchor's slots (two LDS atomics per k-mer: no extraction, reverse complement,
 // hash or probe; its edge bits are a subset of the anchor's), any other goes the usual way.
-static constexpr uint32_t ANCHORS = 32;
-static constexpr uint32_t ANCHOR_KMERS = 52;  // >= the longest window (w <= 49), a multiple of 4
+// Two-word keys only.  With one-word keys (w <= 17) a cut record holds five k-mers on average, and finding its anchor costs
+// more than expanding them: built and measured on C2 with 16 anchors per wavefront in the 1 KB of LDS that packing the
+// table's edge bytes four to a word frees (three workgroups per CU kept), all 8.0e7 cut records anchored: k_aggregate
+// 13.5 -> 18.0 ms (and 13.7 with the packed bytes alone, so they went again too).
 template <int W>
 struct AnchorTable {
-	uint64_t w[2 * W][ANCHORS];
-	uint32_t mm[ANCHORS];    // the minimizer as it stands in the record (not canonical)
-	uint32_t tag[ANCHORS];   // as RecTable's
-	uint8_t kslot[ANCHORS][ANCHOR_KMERS];
+	static constexpr uint32_t N = 32;
+	static constexpr uint32_t KMERS = 52;  // >= the longest window (w <= 49), a multiple of 4
+	uint64_t w[2 * W][N];
+	uint32_t mm[N];    // the minimizer as it stands in the record (not canonical)
+	uint16_t tag[N];   // as RecTable's
+	uint8_t kslot[N][KMERS];
 	uint32_t fill;
 };
 template <int W, bool SLOW, int SLOTS>
-constexpr bool agg_anchors() { return W == 2 && !SLOW && SLOTS == 256; }  // one-word keys: no LDS to spare at three workgroups per CU
+constexpr bool agg_anchors() { return W == 2 && !SLOW && SLOTS == 256; }  // (the slot index is a byte; the 512-slot tables are for inputs whose records rarely repeat)
 
 // SLOW == false: every bucket once, no sub-passes; a bucket whose k-mers do not fit the table is dropped unwritten
 // and its number appended to retry_list (counters[PC_AGG_RETRY] of them).  SLOW == true: the buckets of
@@ -1134,6 +1138,7 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<
 	// its own 20 bytes straddles them: 14.3 ms on C2 against 12.9 with the 24-byte records) and handed to their lanes through LDS
 	__shared__ uint32_t s_stage[C ? agg_waves<W>() : 1][C ? 320 : 1];
 	constexpr bool ANCH = agg_anchors<W, SLOW, SLOTS>();
+	constexpr uint32_t ANCHORS = AnchorTable<W>::N;
 	__shared__ AnchorTable<W> s_anchors[ANCH ? agg_waves<W>() : 1];
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	AggTable<W, SLOTS> &T = s_tables[wave];
@@ -1288,7 +1293,7 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<
 							A.w[q][a] = aw[q];
 						}
 						const uint32_t tg = R.tag[rsl];
-						A.tag[a] = tg;
+						A.tag[a] = (uint16_t)tg;
 						A.mm[a] = (uint32_t)(rec_ext<W>(aw, (tg >> 8) & 127u) & ((1ull << (2 * mlen)) - 1));
 					}
 				}
