@@ -49,6 +49,10 @@ typedef struct rg_config {
 	uint64_t first_read_id; /* global id of this rank's first read (SequencesLoader.cpp:287-297) */
 	void *stream;           /* hipStream_t to launch on; NULL = the library creates its own */
 } rg_config;
+/* Ordering: every entry point queues its work on the handle's stream and, unless its comment says otherwise, returns after
+ * that stream has drained -- results are complete on return.  The other direction is the caller's: a device buffer handed
+ * in (reads, received records / entries, queries, answers) must be complete before the call, i.e. whatever other stream
+ * or collective wrote or cleared it must have finished (the library's own stream is non-blocking and waits for nobody). */
 
 /* ---- life cycle ----------------------------------------------------------------------- */
 /* replaces the constructors KmerAcademyBuilder.cpp:217-246, VerticesExtractor.cpp:322-341,

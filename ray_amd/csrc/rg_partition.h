@@ -1368,7 +1368,7 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<
 						atomicAdd(&counters[PC_LDS_SPILL], 1ull);
 						T.spilled = 1;
 						}
-					} else if (ANCH && anch < ANCHORS) {
+					} else if (ANCH && anch < ANCHORS && i < AnchorTable<W>::KMERS) {  // (i < w <= 49 for records this library cut)
 						A.kslot[anch][i] = (uint8_t)kslot;
 					}
 				}
@@ -1489,7 +1489,7 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<
 							const uint32_t moffS = (tga >> 8) & 127u, lenS = (tga & 63u) + 1;
 							const uint32_t delta = moffS - moffT;  // the record's base 0 is the anchor's base delta
 							const uint32_t d1 = delta + hasLT;     // its first k-mer starts there; the anchor's k-mer 0 at base 1
-							bool same = moffS >= moffT && d1 >= 1u && d1 - 1u + lenT <= lenS && delta + nbT <= lenS + (uint32_t)k + 1u;
+							bool same = moffS >= moffT && d1 >= 1u && d1 - 1u + lenT <= lenS && lenS <= AnchorTable<W>::KMERS && delta + nbT <= lenS + (uint32_t)k + 1u;
 							if (same) {
 								uint64_t sw[NB];
 #pragma unroll
