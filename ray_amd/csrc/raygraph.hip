@@ -2636,6 +2636,9 @@ static int build_table_ranges(rg_handle *h, const Slot *log, uint64_t n_log, uin
 	int bits = 8;
 	while (bits < 25 && (cap >> bits) >= RANGE_SPAN_MAX) bits++;
 	if (bits > 24) return RG_OK;
+	// ranges of up to 2560 slots leave room for two workgroups per CU, whose zero / fill / write-out phases then overlap
+	// (C5's share per GPU: 3147 slots, one workgroup per CU, 2.8 TB/s against C2's 3.6): one more bit where that adds no level
+	if ((cap >> bits) >= 2560 && bits != 8 && bits != 16 && bits < 24) bits++;
 	const uint64_t NR = 1ull << bits;
 	const int rem = bits - 8;
 	const int nlev = 1 + (rem > 0 ? 1 : 0) + (rem > 8 ? 1 : 0);
