@@ -445,16 +445,31 @@ __global__ __launch_bounds__(THREADS) void k_xor_region_sparse(const unsigned lo
 	if (threadIdx.x == 0 && s_setbits) atomicAdd(&counters[c_setbits], (unsigned long long)s_setbits);
 }
 
-// a key that won none of its eight bits is a false positive: its byte of `lost` becomes 8 (what k_admit_lost tests)
+// a key that won none of its eight bits is a false positive: its byte of `lost` becomes 8 (what k_admit_lost tests).
+// A wavefront's 64 positions share one word of each plane: lanes 0..7 fetch the eight words in one load and the OR is handed
+// round (eight loads of one word for all lanes: C5's share per GPU 40.8 ms at 0.9 TB/s).
+// Tried and dropped for crowded filters, where a quarter of the keys end here: the marks written from a list sorted by
+// stretch of the log (a pass that lists, a tile sort, a pass that marks): 21 + 17 ms against 40 on C5's share, 9.5 + 5.5
+// against 10.7 on C2 with 1 % errors -- the scattered bytes were not what the time went on.
 __global__ __launch_bounds__(256) void k_xor_fp(const unsigned long long *__restrict__ pk, const uint32_t *__restrict__ ix,
                                                 const unsigned long long *__restrict__ planes, uint64_t plane_words, uint64_t npos,
                                                 uint8_t *__restrict__ lost) {
-	for (uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x; j < npos; j += (uint64_t)gridDim.x * 256) {
-		if (pk[j] == XOR_PAD) continue;
-		unsigned long long w = 0;
+	const uint32_t lane = threadIdx.x & 63u;
+	for (uint64_t j0 = (uint64_t)blockIdx.x * 256; j0 < npos; j0 += (uint64_t)gridDim.x * 256) {  // (wave-uniform bounds)
+		const uint64_t j = j0 + threadIdx.x;  // a multiple of 64 + lane
+		const uint64_t word = j >> 6;
+		unsigned long long mine = 0;
+		if (lane < 8 && word < plane_words) mine = planes[(uint64_t)lane * plane_words + word];
+		uint32_t lo = (uint32_t)mine, hi = (uint32_t)(mine >> 32), wlo = 0, whi = 0;
 #pragma unroll
-		for (int i = 0; i < 8; ++i) w |= planes[(uint64_t)i * plane_words + (j >> 6)];
-		if (!((w >> (j & 63)) & 1ull)) lost[ix[j]] = 8;
+		for (int i = 0; i < 8; ++i) {
+			wlo |= (uint32_t)__builtin_amdgcn_readlane((int)lo, i);
+			whi |= (uint32_t)__builtin_amdgcn_readlane((int)hi, i);
+		}
+		if (j >= npos) continue;
+		const unsigned long long key = pk[j];
+		const uint32_t bit = lane < 32 ? (wlo >> lane) & 1u : (whi >> (lane - 32)) & 1u;
+		if (key != XOR_PAD && !bit) lost[ix[j]] = 8;
 	}
 }
 
