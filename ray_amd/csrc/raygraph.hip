@@ -1522,6 +1522,9 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 		double frac = 3.0 / (w + 1);
 		if (frac > 1.0) frac = 1.0;
 		rec_bound += b.n * ((uint64_t)(per * frac) + (per + 63) / 64 + 2);
+		// w <= 2: the bound above is the number of k-mers itself, and a wavefront that cannot fit a step's records (up to 128)
+		// into its chunk of REC_CHUNK leaves the rest of the chunk unused
+		if (frac >= 1.0) rec_bound += b.n * per / (REC_CHUNK / 128) + REC_CHUNK;
 		total_reads += b.n;
 		if (b.first_id + b.n >= (1ull << 33) - 1) return RG_OK;  // read ids must fit the record header
 	}
@@ -1984,7 +1987,8 @@ static int records_local_t(rg_handle *h, uint32_t part, uint32_t nparts) {
 	HIP_TRY(h, pool_alloc(dev, (void **)&d_hist, 256 * sizeof(unsigned long long)));
 	for (int attempt = 0; attempt < 2; ++attempt) {
 		double frac = attempt ? 1.0 : std::min(1.0, 3.0 / (w + 1));
-		const uint64_t rec_cap = (uint64_t)(rec_bound * frac) + total_reads * 3 + launches1 * (uint64_t)grid1 * 4 * REC_CHUNK;
+		// (frac == 1: one record per k-mer at most, plus what wavefronts leave unused at the end of their chunks)
+		const uint64_t rec_cap = (uint64_t)(rec_bound * frac) + (frac >= 1.0 ? rec_bound / (REC_CHUNK / 128) : 0) + total_reads * 3 + launches1 * (uint64_t)grid1 * 4 * REC_CHUNK;
 		RM *buf = nullptr;
 		if (pool_alloc(dev, (void **)&buf, rec_cap * sizeof(RM)) != hipSuccess) {
 			(void)hipGetLastError();
