@@ -1,6 +1,7 @@
 """Seeded random cases through the C ABI against the oracle: k, read length (short reads for the lane-per-read kernels,
 reads beyond 1024 bases for the wavefront-per-read one), coverage, error rate, filter size (default, off, powers of two and
-odd sizes from far too small to ample) and a random mix of the switches that force internal routes.  Every case is
+odd sizes from far too small to ample), reads added in one to three batches, two-word keys for a k that one word holds, and
+a random mix of the switches that force internal routes.  Every case is
 deterministic (the seed is the case number)."""
 import os
 
@@ -46,7 +47,11 @@ def _case(seed):
         if (s & 0x400000) and (s & 0x800000):
             s &= ~0x800000
         sweeps.append(s)
-    return dict(k=k, read_len=read_len, genome=genome, n_reads=n_reads, error=error, ragged=ragged, bloom_bits=bloom_bits, sweeps=tuple(sweeps))
+    # (drawn last, so that the cases keep what they had before these were added)
+    batches = int(rng.choice([1, 1, 2, 3]))
+    W = 2 if (k <= 31 and rng.random() < 0.15) else None
+    return dict(k=k, read_len=read_len, genome=genome, n_reads=n_reads, error=error, ragged=ragged, bloom_bits=bloom_bits, sweeps=tuple(sweeps),
+                batches=batches, W=W)
 
 
 # RG_FUZZ_SEEDS=N widens the run for a one-off check (24 cases are the suite's share)
@@ -55,7 +60,7 @@ def _case(seed):
 def test_random_case(oracle, seed):
     c = _case(seed)
     packed, offsets, lengths = make_reads_numpy(c["genome"], c["read_len"], c["n_reads"], seed=500 + seed, error=c["error"], ragged=c["ragged"])
-    gpu_vs_oracle(oracle, packed, offsets, lengths, c["k"], bloom_bits=c["bloom_bits"], sweeps=c["sweeps"])
+    gpu_vs_oracle(oracle, packed, offsets, lengths, c["k"], bloom_bits=c["bloom_bits"], sweeps=c["sweeps"], batches=c["batches"], W=c["W"])
 
 
 @pytest.mark.parametrize("k", [21, 31, 47])
@@ -82,3 +87,41 @@ def test_record_header_extremes(oracle, k):
     first = (1 << 33) - 2 - len(reads)
     gpu_vs_oracle(oracle, packed, offsets, lengths, k, bloom_bits=300_000, first_read_id=first,
                   sweeps=(1 | 16 | (12 << 8), 1 | 32 | (14 << 8) | 0x8000000, 1 | 16 | (9 << 8) | 0x10000, 2 | 32))
+
+
+def _rank_case(seed):
+    rng = np.random.default_rng(7000 + seed)
+    k = int(rng.choice([15, 21, 31, 33, 47, 63]))
+    nranks = int(rng.choice([2, 3, 5, 8]))
+    read_len = int(rng.integers(max(k + 5, 50), 260))
+    genome = int(rng.integers(3000, 20000))
+    n_reads = max(4 * nranks, int(genome * float(rng.choice([4, 12, 30])) / read_len))
+    bloom = [None, 0, int(rng.integers(20000, 400000)), 1 << int(rng.integers(14, 24))][int(rng.integers(0, 4))]
+    route = str(rng.choice(["records", "entries"]))
+    parts = int(rng.choice([1, 1, 2, 3])) if route == "records" else 1
+    one = [False, True, "adopt"][int(rng.integers(0, 3))]
+    sweep = 1 | int(rng.choice([16, 32])) | (int(rng.integers(8, 18)) << 8)
+    for f in (0x10000, 0x100000, 0x400000, 0x800000, 0x1000000, 0x4000000, 0x8000000):
+        if rng.random() < 0.2:
+            sweep |= f
+    if (sweep & 0x400000) and (sweep & 0x800000):
+        sweep &= ~0x800000
+    return dict(k=k, nranks=nranks, read_len=read_len, genome=genome, n_reads=n_reads, bloom=bloom, route=route, parts=parts, one=one,
+                sweep=sweep, error=float(rng.choice([0.0, 0.01])))
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RG_FUZZ_RANK_SEEDS", "8"))))
+def test_random_ranks(oracle, seed):
+    """R builders on one device swapping records / entries, purge queries and answers through device buffers, against the
+    R-rank oracle: random k, rank count, route, slices, delivery (several merges, one merge, adoption in place) and switches"""
+    from helpers import assert_records_equal, oracle_run
+    from test_multirank_gpu import check_ranks, purge_ranks, run_ranks
+    c = _rank_case(seed)
+    packed, offsets, lengths = make_reads_numpy(c["genome"], c["read_len"], c["n_reads"], seed=900 + seed, error=c["error"])
+    want = oracle_run(oracle, packed, offsets, lengths, c["k"], c["nranks"], c["bloom"])
+    builders = run_ranks(packed, offsets, lengths, c["k"], c["nranks"], c["bloom"], sweep=c["sweep"], route=c["route"], parts=c["parts"], one_merge=c["one"])
+    check_ranks(builders, want, "%s" % c)
+    want["graph"].purge_edges()
+    purge_ranks(builders)
+    for r, b in enumerate(builders):
+        assert_records_equal(b.export(), want["graph"].export(r), "rank %d after purge: %s" % (r, c))
