@@ -1679,6 +1679,7 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 		return RG_OK;
 	}
 	// 1b. the sample's own sweep: distinct k-mers in 1 / 2^SAMPLE_BITS of the buckets -> buckets of about AGG_TARGET k-mers
+	double sample_distinct = 0;  // its estimate of the input's distinct k-mers (0 = no sample): also sizes the log
 	if (d_sample) {
 		const uint64_t n_sample = h->h_counters[PC_SAMPLE];
 		if (n_sample && n_sample <= sample_cap) {
@@ -1695,6 +1696,7 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 			}
 			if (sok) {
 				const double distinct = (double)h->h_counters[PC_LOG_KEYS] * (double)(1u << SAMPLE_BITS);
+				sample_distinct = distinct;
 				int want = bits;
 				while (want < MAX_BUCKET_BITS && distinct / (double)(1ull << want) > (double)AGG_TARGET) want++;
 				if (getenv("RG_DEBUG"))
@@ -1805,6 +1807,10 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	const unsigned agg_grid = agg.grid_for_buckets(NBUCK, n_cu);
 	const uint64_t log_slack = agg.slack(agg_grid);
 	uint64_t log_cap = std::min<uint64_t>(occ_bound, std::max<uint64_t>(occ_bound / 4, 1ull << 20)) + log_slack;
+	// the record sample has counted the distinct k-mers of 1 / 4096 of the buckets already: the log is sized from that and the
+	// bucket probe below (1 / 256 of the buckets aggregated ahead of the rest, 0.17 ms and two round trips on C2) is left out
+	const bool sized_by_sample = sample_distinct > 0 && !(h->dbg & 0x40000);
+	if (sized_by_sample) log_cap = std::min<uint64_t>(occ_bound, std::max<uint64_t>((uint64_t)(sample_distinct * 1.15) + (1ull << 16), 1ull << 20)) + log_slack;
 	if ((h->dbg & 64) && !nested) log_cap = LOG_CHUNK;  // tests: the first attempt overflows
 	uint32_t *d_retry = nullptr;
 	if (pool_alloc(dev, (void **)&d_retry, NBUCK * sizeof(uint32_t)) != hipSuccess) {
@@ -1816,7 +1822,7 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	const uint32_t flag_unique = (h->cfg.size == 1 || ext) ? 1u : 0u;
 	for (int attempt = 0;; ++attempt) {
 		const bool force_probe = (h->dbg & 0x40000) != 0;
-		const bool will_probe = !nested && attempt == 0 && !(h->dbg & 64) && (NBUCK >= (1u << 16) || force_probe);
+		const bool will_probe = !nested && attempt == 0 && !(h->dbg & 64) && !sized_by_sample && (NBUCK >= (1u << 16) || force_probe);
 		const uint32_t P = force_probe ? std::max<uint32_t>((uint32_t)NBUCK / 4, 1u) : (uint32_t)NBUCK / 256;
 		// the sample runs on a small log of its own (one entry per occurrence of its share would always do; 1.5 x the average
 		// share + the chunks left open is what it gets), the real log is allocated once its size is known
@@ -1833,6 +1839,7 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 		// redundancy (errors in most reads) then gets its larger log at once instead of losing a whole aggregation to
 		// find out.  Costs 1/256 of the aggregation; bit 18 of rg_debug_set runs it on small inputs too and always resizes (tests).
 		bool mostly_overflowing = false;  // the sample says that most buckets hold more k-mers than the LDS table: split them all from the start
+		if (sized_by_sample && attempt == 0) mostly_overflowing = sample_distinct / (double)NBUCK > 0.9 * (double)agg.key_limit();
 		if (will_probe) {
 			bool fine = hipMemsetAsync(h->d_counters + PC_LOG_CURSOR, 0, 6 * sizeof(unsigned long long), h->stream) == hipSuccess;
 			if (fine) {
