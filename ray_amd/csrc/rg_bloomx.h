@@ -380,6 +380,9 @@ __global__ __launch_bounds__(THREADS) void k_xor_region_sparse(const unsigned lo
 		for (int i = 0; i < 8; ++i) itA[i] = (fitsA && r < P && threadIdx.x < lenA[i]) ? pk[sbA[i] + threadIdx.x] : XOR_PAD;
 		fetch_bounds(r + G, nb0, nb1);
 	}
+	// The cells start free once; a region whose keys sat in registers frees just the cells those keys touched when it is
+	// done (at most eight stores per thread where clearing the region takes sixteen), any other region clears them all.
+	bool all_free = false;
 	for (; r < P; r += G) {
 		// the next region's items, the bounds of the one after
 		unsigned long long sbB[8], itB[8];
@@ -390,8 +393,11 @@ __global__ __launch_bounds__(THREADS) void k_xor_region_sparse(const unsigned lo
 		for (int i = 0; i < 8; ++i) itB[i] = (fitsB && threadIdx.x < lenB[i]) ? pk[sbB[i] + threadIdx.x] : XOR_PAD;
 		fetch_bounds(r + 2 * G, nb0, nb1);
 
-		for (uint32_t i = threadIdx.x; i < ncell; i += THREADS) s_cell[i] = INF_STAMP;
-		xor_lds_barrier();
+		if (!all_free) {
+			for (uint32_t i = threadIdx.x; i < ncell; i += THREADS) s_cell[i] = INF_STAMP;
+			xor_lds_barrier();
+		}
+		all_free = false;
 		if (fitsA) {
 #pragma unroll
 			for (int i = 0; i < 8; ++i)
@@ -407,6 +413,13 @@ __global__ __launch_bounds__(THREADS) void k_xor_region_sparse(const unsigned lo
 						if (count_winners) set_total += (uint32_t)__popcll(bal);
 					}
 				}
+			}
+			if (count_winners) {  // (otherwise the sweep over the cells below needs them as they are)
+				xor_lds_barrier();  // every comparison above has read its cell
+#pragma unroll
+				for (int i = 0; i < 8; ++i)
+					if (itA[i] != XOR_PAD) s_cell[((uint32_t)itA[i] ^ K.low[i]) & cmask] = INF_STAMP;
+				all_free = true;
 			}
 		} else {
 			// a region with a stream longer than the workgroup: read twice
