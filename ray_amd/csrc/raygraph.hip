@@ -2511,9 +2511,9 @@ static int bloom_xor(rg_handle *h, Table &T, uint64_t m_bits, uint64_t keys, boo
 	if (!sparse && dense_small) {
 		ProfScope ps(h, "k_xor_region");
 		if (rmax == 13)
-			hipLaunchKernelGGL((k_xor_region<13, 1024>), dim3((unsigned)std::min<uint64_t>(P, (uint64_t)n_cu)), dim3(1024), 0, h->stream, pk, d_begin, (uint32_t)P, R, K, planes, plane_words, h->d_counters, (int)C_SETBITS);
+			hipLaunchKernelGGL((k_xor_region<13, 1024>), dim3((unsigned)std::min<uint64_t>(P, (uint64_t)n_cu)), dim3(1024), 0, h->stream, pk, d_begin, (uint32_t)P, R, K, planes, plane_words, h->d_counters, (int)C_SETBITS, distinct_bits ? 1 : 0);
 		else
-			hipLaunchKernelGGL((k_xor_region<12, 1024>), dim3((unsigned)std::min<uint64_t>(P, (uint64_t)n_cu)), dim3(1024), 0, h->stream, pk, d_begin, (uint32_t)P, R, K, planes, plane_words, h->d_counters, (int)C_SETBITS);
+			hipLaunchKernelGGL((k_xor_region<12, 1024>), dim3((unsigned)std::min<uint64_t>(P, (uint64_t)n_cu)), dim3(1024), 0, h->stream, pk, d_begin, (uint32_t)P, R, K, planes, plane_words, h->d_counters, (int)C_SETBITS, distinct_bits ? 1 : 0);
 		XTRY(hipGetLastError());
 	} else
 	if (sparse) {
@@ -2524,11 +2524,11 @@ static int bloom_xor(rg_handle *h, Table &T, uint64_t m_bits, uint64_t keys, boo
 	} else {
 		ProfScope ps(h, "k_xor_region");
 		if (rmax == 14)
-			hipLaunchKernelGGL((k_xor_region<14, 1024>), dim3((unsigned)std::min<uint64_t>(P, (uint64_t)n_cu)), dim3(1024), 0, h->stream, pk, d_begin, (uint32_t)P, R, K, planes, plane_words, h->d_counters, (int)C_SETBITS);
+			hipLaunchKernelGGL((k_xor_region<14, 1024>), dim3((unsigned)std::min<uint64_t>(P, (uint64_t)n_cu)), dim3(1024), 0, h->stream, pk, d_begin, (uint32_t)P, R, K, planes, plane_words, h->d_counters, (int)C_SETBITS, distinct_bits ? 1 : 0);
 		else if (rmax == 13)
-			hipLaunchKernelGGL((k_xor_region<13, 512>), dim3((unsigned)std::min<uint64_t>(P, (uint64_t)n_cu * 2)), dim3(512), 0, h->stream, pk, d_begin, (uint32_t)P, R, K, planes, plane_words, h->d_counters, (int)C_SETBITS);
+			hipLaunchKernelGGL((k_xor_region<13, 512>), dim3((unsigned)std::min<uint64_t>(P, (uint64_t)n_cu * 2)), dim3(512), 0, h->stream, pk, d_begin, (uint32_t)P, R, K, planes, plane_words, h->d_counters, (int)C_SETBITS, distinct_bits ? 1 : 0);
 		else
-			hipLaunchKernelGGL((k_xor_region<12, 256>), dim3((unsigned)std::min<uint64_t>(P, (uint64_t)n_cu * 4)), dim3(256), 0, h->stream, pk, d_begin, (uint32_t)P, R, K, planes, plane_words, h->d_counters, (int)C_SETBITS);
+			hipLaunchKernelGGL((k_xor_region<12, 256>), dim3((unsigned)std::min<uint64_t>(P, (uint64_t)n_cu * 4)), dim3(256), 0, h->stream, pk, d_begin, (uint32_t)P, R, K, planes, plane_words, h->d_counters, (int)C_SETBITS, distinct_bits ? 1 : 0);
 		XTRY(hipGetLastError());
 	}
 	{

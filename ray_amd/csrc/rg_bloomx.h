@@ -233,18 +233,32 @@ struct XorConsts {
 // entries, multiples of 64).  planes: bit j of plane i = the key at position j won bit_i, i.e. its arrival set it.
 // RMAX, THREADS: 2^RMAX cells of LDS and the workgroup size -- (14, 1024): one workgroup per CU; (13, 512) / (12, 256): two /
 // four, whose loads and LDS phases overlap (a region is a chain of dependent loads: range bounds, then items).
+// The cells are cleared once: a region writes its stamps under a tag that falls from region to region (the top 14 bits of the
+// cell; a stamp is 49 bits), so what earlier regions left in a cell is larger than anything this one offers to the atomic
+// minimum and equal to nothing it compares with.  count_winners: the set bits are the winners (one per touched bit: stamps
+// are unique, and the host checks that no two hashes of a key can name the same bit) instead of a sweep over the cells.
+// Together: no clearing and no sweep per region (2 x 16 LDS operations per thread at 2^14 cells, beside some 40 for the
+// keys of a crowded filter) and one barrier less.
 template <int RMAX, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_xor_region(const unsigned long long *__restrict__ pk, const unsigned long long *__restrict__ part_begin,
                                                         uint32_t P, int R, XorConsts K, unsigned long long *__restrict__ planes, uint64_t plane_words,
-                                                        unsigned long long *__restrict__ counters, int c_setbits) {
+                                                        unsigned long long *__restrict__ counters, int c_setbits, int count_winners) {
 	__shared__ unsigned long long s_cell[1u << RMAX];
 	__shared__ uint32_t s_setbits;
 	const uint32_t ncell = 1u << R, cmask = ncell - 1;
 	const uint32_t lane = threadIdx.x & 63u;
 	uint32_t set_total = 0;
 	if (threadIdx.x == 0) s_setbits = 0;
+	constexpr uint32_t EPOCHS = 1u << 14;
+	uint32_t epoch = EPOCHS;
 	for (uint32_t r = blockIdx.x; r < P; r += gridDim.x) {
-		for (uint32_t i = threadIdx.x; i < ncell; i += THREADS) s_cell[i] = INF_STAMP;
+		if (epoch == EPOCHS) {
+			for (uint32_t i = threadIdx.x; i < ncell; i += THREADS) s_cell[i] = INF_STAMP;
+			epoch = 0;
+			__syncthreads();
+		}
+		const unsigned long long tag = (unsigned long long)(EPOCHS - 1u - epoch) << 50;
+		++epoch;
 		// the eight streams of this region, laid end to end (every length is a multiple of 64)
 		unsigned long long sb[8];
 		uint32_t pre[9];
@@ -255,7 +269,6 @@ __global__ __launch_bounds__(THREADS) void k_xor_region(const unsigned long long
 			sb[i] = part_begin[q];
 			pre[i + 1] = pre[i] + (uint32_t)(part_begin[q + 1] - sb[i]);
 		}
-		__syncthreads();
 		uint32_t longest = 0;
 #pragma unroll
 		for (int i = 0; i < 8; ++i) longest = max(longest, pre[i + 1] - pre[i]);
@@ -276,7 +289,7 @@ __global__ __launch_bounds__(THREADS) void k_xor_region(const unsigned long long
 			for (int i = 0; i < 8; ++i)
 #pragma unroll
 				for (int u = 0; u < XOR_SPER; ++u)
-					if (item[i][u] != XOR_PAD) atomicMin(&s_cell[((uint32_t)item[i][u] ^ K.low[i]) & cmask], item[i][u] >> 14);
+					if (item[i][u] != XOR_PAD) atomicMin(&s_cell[((uint32_t)item[i][u] ^ K.low[i]) & cmask], tag | (item[i][u] >> 14));
 			__syncthreads();
 #pragma unroll
 			for (int i = 0; i < 8; ++i) {
@@ -285,9 +298,12 @@ __global__ __launch_bounds__(THREADS) void k_xor_region(const unsigned long long
 				for (int u = 0; u < XOR_SPER; ++u) {
 					const uint32_t t = threadIdx.x + (uint32_t)THREADS * u;
 					if (t - lane < len) {  // wave-uniform: every stream is a whole number of wavefronts long
-						const bool win = item[i][u] != XOR_PAD && s_cell[((uint32_t)item[i][u] ^ K.low[i]) & cmask] == (item[i][u] >> 14);
+						const bool win = item[i][u] != XOR_PAD && s_cell[((uint32_t)item[i][u] ^ K.low[i]) & cmask] == (tag | (item[i][u] >> 14));
 						const unsigned long long bal = __ballot(win);
-						if (lane == 0) planes[(uint64_t)i * plane_words + ((sb[i] + t) >> 6)] = bal;
+						if (lane == 0) {
+							planes[(uint64_t)i * plane_words + ((sb[i] + t) >> 6)] = bal;
+							if (count_winners) set_total += (uint32_t)__popcll(bal);
+						}
 					}
 				}
 			}
@@ -298,7 +314,7 @@ __global__ __launch_bounds__(THREADS) void k_xor_region(const unsigned long long
 				const uint32_t len = pre[i + 1] - pre[i];
 				for (uint32_t t = threadIdx.x; t < len; t += THREADS) {
 					const unsigned long long it = pk[sb[i] + t];
-					if (it != XOR_PAD) atomicMin(&s_cell[((uint32_t)it ^ K.low[i]) & cmask], it >> 14);
+					if (it != XOR_PAD) atomicMin(&s_cell[((uint32_t)it ^ K.low[i]) & cmask], tag | (it >> 14));
 				}
 			}
 			__syncthreads();
@@ -307,15 +323,18 @@ __global__ __launch_bounds__(THREADS) void k_xor_region(const unsigned long long
 				const uint32_t len = pre[i + 1] - pre[i];
 				for (uint32_t t = threadIdx.x; t < len; t += THREADS) {
 					const unsigned long long it = pk[sb[i] + t];
-					const bool win = it != XOR_PAD && s_cell[((uint32_t)it ^ K.low[i]) & cmask] == (it >> 14);
+					const bool win = it != XOR_PAD && s_cell[((uint32_t)it ^ K.low[i]) & cmask] == (tag | (it >> 14));
 					const unsigned long long bal = __ballot(win);
-					if (lane == 0) planes[(uint64_t)i * plane_words + ((sb[i] + t) >> 6)] = bal;
+					if (lane == 0) {
+						planes[(uint64_t)i * plane_words + ((sb[i] + t) >> 6)] = bal;
+						if (count_winners) set_total += (uint32_t)__popcll(bal);
+					}
 				}
 			}
 		}
-		// bits of this region that any key touched
-		for (uint32_t i = threadIdx.x; i < ncell; i += THREADS) set_total += (s_cell[i] != INF_STAMP) ? 1u : 0u;
-		__syncthreads();
+		if (!count_winners)  // bits of this region that any key touched: the cells that carry its tag
+			for (uint32_t i = threadIdx.x; i < ncell; i += THREADS) set_total += ((s_cell[i] >> 50) == (tag >> 50) && s_cell[i] != INF_STAMP) ? 1u : 0u;
+		__syncthreads();  // the next region's stamps must not land before every comparison above has read its cell
 	}
 	if (set_total) atomicAdd(&s_setbits, set_total);
 	__syncthreads();
