@@ -1776,10 +1776,10 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 			uint8_t *side_out = (have_next && !(h->dbg & 0x100000)) ? d_side : nullptr;  // bit 20: histograms read the records (tests)
 			const int ndb = have_next ? dbits[level + 1] : 0;
 			if (nested)
-				hipLaunchKernelGGL((k_scatter<W, 1, C>), dim3((unsigned)ntiles), dim3(SCATTER_THREADS), 0, h->stream, level_in, m, S, d_seg, d_tile, shift, db, d_hist,
+				hipLaunchKernelGGL((k_scatter<W, 1, C>), dim3((unsigned)ntiles), dim3(scatter_threads<W, C>()), 0, h->stream, level_in, m, S, d_seg, d_tile, shift, db, d_hist,
 				                   buf[cur ^ 1], 0u, side_out, shift - ndb, (1u << ndb) - 1u);
 			else
-				hipLaunchKernelGGL((k_scatter<W, 0, C>), dim3((unsigned)ntiles), dim3(SCATTER_THREADS), 0, h->stream, level_in, m, S, d_seg, d_tile, shift, db, d_hist,
+				hipLaunchKernelGGL((k_scatter<W, 0, C>), dim3((unsigned)ntiles), dim3(scatter_threads<W, C>()), 0, h->stream, level_in, m, S, d_seg, d_tile, shift, db, d_hist,
 				                   buf[cur ^ 1], 0u, side_out, shift - ndb, (1u << ndb) - 1u);
 			side_valid = side_out != nullptr;
 		}
@@ -2066,7 +2066,7 @@ static int export_records_t(rg_handle *h, void *d_out) {
 	if (e == hipSuccess) e = hipMemcpyAsync(d_cur, cursors.data(), 256 * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream);
 	if (e == hipSuccess) {
 		ProfScope ps(h, "k_scatter");
-		hipLaunchKernelGGL((k_scatter<W, 0, C>), dim3((unsigned)ntiles), dim3(SCATTER_THREADS), 0, h->stream, (const RM *)h->rec_buf, m, 1u, d_seg, d_tile, 0, 8, d_cur,
+		hipLaunchKernelGGL((k_scatter<W, 0, C>), dim3((unsigned)ntiles), dim3(scatter_threads<W, C>()), 0, h->stream, (const RM *)h->rec_buf, m, 1u, d_seg, d_tile, 0, 8, d_cur,
 		                   (RM *)d_out, size, (uint8_t *)nullptr, 0, 0u);
 		e = hipGetLastError();
 	}

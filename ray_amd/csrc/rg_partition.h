@@ -727,6 +727,10 @@ static constexpr int SCATTER_TILE = 2560;
 static constexpr int SCATTER_TILE_C = 3072;  // 20-byte records: the same 60 KB
 template <int W, bool C>
 constexpr int scatter_tile() { return (W == 1 && C) ? SCATTER_TILE_C : SCATTER_TILE; }
+// threads of a k_scatter workgroup.  The 20-byte tile with 1024 (three records each, 32 wavefronts per CU): the three levels
+// on C2 19.8 -> 18.4 ms on a box where 512 threads are slow (boxes differ: 18.3-19.8 with 512), 768: 18.45
+template <int W, bool C>
+constexpr int scatter_threads() { return (W == 1 && C) ? 1024 : 512; }
 static constexpr int SCATTER_THREADS = 512;  // threads of a scatter workgroup: 4 records each (256 threads x 8: 23-25 ms for the three levels on C2, 512 x 4: 20.5-22)
 
 __device__ __forceinline__ uint32_t find_segment(const uint32_t *__restrict__ tile_first, uint32_t S, uint32_t tile) {
@@ -742,13 +746,15 @@ __device__ __forceinline__ uint32_t find_segment(const uint32_t *__restrict__ ti
 // TAG: 1 for the launches of the record sample's own small sweep, so that a profiler's per-kernel averages of the real
 // partition levels are not diluted by them
 template <int W, int TAG = 0, bool C = false>
-__global__ __launch_bounds__(SCATTER_THREADS) void k_scatter(const RecMem<W, C> *__restrict__ in, int m, uint32_t S,
+__global__ __launch_bounds__((scatter_threads<W, C>())) void k_scatter(const RecMem<W, C> *__restrict__ in, int m, uint32_t S,
                                                  const unsigned long long *__restrict__ seg_begin,
                                                  const uint32_t *__restrict__ tile_first, int shift, int dbits,
                                                  unsigned long long *__restrict__ cursors, RecMem<W, C> *__restrict__ out, uint32_t modulo,
                                                  uint8_t *__restrict__ side, int next_shift, uint32_t next_mask) {
 	using RM = RecMem<W, C>;
 	constexpr int SCATTER_TILE = scatter_tile<W, C>();
+	constexpr int SCATTER_THREADS = scatter_threads<W, C>();
+	static_assert(SCATTER_TILE % SCATTER_THREADS == 0, "whole records per thread");
 	// modulo != 0: the digit is bucket % modulo (destination rank of the record exchange) instead of bits of the bucket
 	// side != null: side[i] = the NEXT level's digit of out[i], so that the next level's histogram reads one byte per
 	// record instead of the record (k_level_hist_side)
@@ -1368,8 +1374,9 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<
 						atomicAdd(&counters[PC_LDS_SPILL], 1ull);
 						T.spilled = 1;
 						}
-					} else if (ANCH && anch < ANCHORS && i < AnchorTable<W>::KMERS) {  // (i < w <= 49 for records this library cut)
-						A.kslot[anch][i] = (uint8_t)kslot;
+					} else {
+						if constexpr (ANCH)
+							if (anch < ANCHORS && i < AnchorTable<W>::KMERS) A.kslot[anch][i] = (uint8_t)kslot;  // (i < w <= 49 for records this library cut)
 					}
 				}
 				if (checked) {
