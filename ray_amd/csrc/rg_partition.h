@@ -725,12 +725,14 @@ __global__ __launch_bounds__(256) void k_superkmers_lanes(const uint64_t *__rest
 // 21.9-23.1 -> 21.0-22.3 ms on C2, same box; 3072 would leave one workgroup per CU)
 static constexpr int SCATTER_TILE = 2560;
 static constexpr int SCATTER_TILE_C = 3072;  // 20-byte records: the same 60 KB
+// (two-word keys: 2048 records of 40 bytes, one workgroup of 1024 threads per CU -- 7.4 ms for the three levels on C3's
+// shape against 7.6 with 2560 records and 512 threads)
 template <int W, bool C>
-constexpr int scatter_tile() { return (W == 1 && C) ? SCATTER_TILE_C : SCATTER_TILE; }
+constexpr int scatter_tile() { return (W == 1 && C) ? SCATTER_TILE_C : (W == 2 ? 2048 : SCATTER_TILE); }
 // threads of a k_scatter workgroup.  The 20-byte tile with 1024 (three records each, 32 wavefronts per CU): the three levels
 // on C2 19.8 -> 18.4 ms on a box where 512 threads are slow (boxes differ: 18.3-19.8 with 512), 768: 18.45
 template <int W, bool C>
-constexpr int scatter_threads() { return (W == 1 && C) ? 1024 : 512; }
+constexpr int scatter_threads() { return (W == 1 && C) || W == 2 ? 1024 : 512; }
 static constexpr int SCATTER_THREADS = 512;  // threads of a scatter workgroup: 4 records each (256 threads x 8: 23-25 ms for the three levels on C2, 512 x 4: 20.5-22)
 
 __device__ __forceinline__ uint32_t find_segment(const uint32_t *__restrict__ tile_first, uint32_t S, uint32_t tile) {
