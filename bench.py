@@ -316,6 +316,15 @@ def main():
             after["store hand-back records"] = n_rec
             after["store hand-back bytes"] = n_rec * rec.dtype.itemsize
             del rec
+            try:   # the same into page-locked host memory (what a glue that keeps its buffer registered would see)
+                pinned = torch.empty(n_rec * record_dtype(1 if k <= 31 else 2).itemsize, dtype=torch.uint8, pin_memory=True)
+                rec2 = pinned.numpy().view(record_dtype(1 if k <= 31 else 2))
+                tp = time.perf_counter()
+                b.export_into(rec2)
+                after["store hand-back into page-locked memory"] = (time.perf_counter() - tp) * 1e3
+                del rec2, pinned
+            except RuntimeError:
+                pass
         b.close()
         barrier()
 
