@@ -2518,8 +2518,14 @@ static int bloom_xor(rg_handle *h, Table &T, uint64_t m_bits, uint64_t keys, boo
 	} else
 	if (sparse) {
 		ProfScope ps(h, "k_xor_region");
-		hipLaunchKernelGGL((k_xor_region_sparse<14, 1024>), dim3((unsigned)std::min<uint64_t>(P, (uint64_t)n_cu)), dim3(1024), 0, h->stream, pk, d_begin, (uint32_t)P, R, K, planes,
-		                   plane_words, h->d_counters, (int)C_SETBITS, distinct_bits ? 1 : 0);
+		// a thread holds one key per stream: streams of up to 256 keys on average take 512 threads (fewer idle lanes, cheaper
+		// barriers: 4.96 -> 4.74 ms on C2, 190 keys per stream; 256 threads: 4.88), fuller ones 1024
+		if (keys / P <= 256)
+			hipLaunchKernelGGL((k_xor_region_sparse<14, 512>), dim3((unsigned)std::min<uint64_t>(P, (uint64_t)n_cu)), dim3(512), 0, h->stream, pk, d_begin, (uint32_t)P, R, K, planes,
+			                   plane_words, h->d_counters, (int)C_SETBITS, distinct_bits ? 1 : 0);
+		else
+			hipLaunchKernelGGL((k_xor_region_sparse<14, 1024>), dim3((unsigned)std::min<uint64_t>(P, (uint64_t)n_cu)), dim3(1024), 0, h->stream, pk, d_begin, (uint32_t)P, R, K, planes,
+			                   plane_words, h->d_counters, (int)C_SETBITS, distinct_bits ? 1 : 0);
 		XTRY(hipGetLastError());
 	} else {
 		ProfScope ps(h, "k_xor_region");
