@@ -1009,7 +1009,10 @@ static constexpr uint32_t AGG_TARGET = 64;  // distinct k-mers per bucket the pa
 static constexpr uint32_t AGG_FLUSH = 190;
 static constexpr uint32_t AGG_BIG_ABOVE = 80;   // expected k-mers per bucket above which the sweep takes the AGG_SLOTS_BIG tables
 static constexpr uint32_t RT_SLOTS = 128;
-static constexpr uint32_t RT_FLUSH = RT_SLOTS * 3 / 4 - 64;
+// distinct records the table may hold when a round of up to 64 new ones arrives: at most 15/16 full after it.  With 3/4 (32)
+// a bucket of C2, some 31 distinct records, was often expanded twice, the first time for a few records: 13.5 -> 12.6 ms
+// (7/8: 12.7)
+static constexpr uint32_t RT_FLUSH = RT_SLOTS * 15 / 16 - 64;
 static constexpr uint32_t LOG_CHUNK = 512;
 // wavefronts per workgroup (one per workgroup: 26 ms instead of 17).  Two-word keys have 16.1 KB of tables per wavefront,
 // 8 wavefronts per CU with four per workgroup; three per workgroup (9 per CU) changed nothing (C3 shape: 25.4 ms both), five
@@ -1571,7 +1574,7 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<
 				do {
 					bool owner = false;
 					if (pending) {
-						for (;;) {  // ends: the table is never more than 3/4 full
+						for (;;) {  // ends: the table is never more than 15/16 full
 							unsigned long long cur = R.fp[sl];
 							if (cur == 0) {
 								cur = atomicCAS(&R.fp[sl], 0ull, fp);
