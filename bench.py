@@ -26,8 +26,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="C2_100Mbp_60x_150bp_k31")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink genome and read count (development only)")
     ap.add_argument("--error", type=float, default=None, help="substitution error rate instead of the workload's own (sensitivity runs)")
