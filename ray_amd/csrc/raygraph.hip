@@ -479,31 +479,29 @@ __global__ __launch_bounds__(BLOCK) void k_purge(Slot *__restrict__ tab, uint64_
 		uint64_t K0, K1;
 		from_internal<W>(v.k0, v.k1, K0, K1);
 		uint32_t keep = e;
-		for (uint32_t c = 0; c < 4; ++c) {
-			if (e & (1u << c)) {  // parent: shift left one base, base c enters at position 0
-				uint64_t n0 = ((K0 << 2) | c) & mask0;
-				uint64_t n1 = (W == 2) ? (((K1 << 2) | (K0 >> 62)) & mask1) : 0;
-				uint64_t i0, i1;
-				bool rc;
-				canonical_internal<W>(n0, n1, k, i0, i1, rc);
-				const Slot *q = lookup<W>(tab, cap, i0, i1);
-				if (!q || (q->meta & COUNT_MASK) == 0) keep &= ~(1u << c);
-			}
-			if (e & (1u << (4 + c))) {  // child: shift right one base, base c enters at position k-1
-				uint64_t n0 = K0 >> 2, n1 = 0;
+		// a lane walks its own set bits (two on a linear stretch of the genome), so that the lanes of a wavefront look their
+		// j-th neighbours up together; a loop over the eight bits ran every look-up with a quarter of the lanes (14.5 ms on C2)
+		for (uint32_t rem = e; rem; rem &= rem - 1) {
+			const uint32_t bit = (uint32_t)__builtin_ctz(rem), c = bit & 3u;
+			uint64_t n0, n1 = 0;
+			if (bit < 4) {  // parent: shift left one base, base c enters at position 0
+				n0 = ((K0 << 2) | c) & mask0;
+				if (W == 2) n1 = ((K1 << 2) | (K0 >> 62)) & mask1;
+			} else {  // child: shift right one base, base c enters at position k-1
+				n0 = K0 >> 2;
 				if (W == 2) {
 					n0 |= K1 << 62;
 					n1 = K1 >> 2;
 				}
-				int pos = 2 * (k - 1);
+				const int pos = 2 * (k - 1);
 				if (pos < 64) n0 |= (uint64_t)c << pos;
 				else n1 |= (uint64_t)c << (pos - 64);
-				uint64_t i0, i1;
-				bool rc;
-				canonical_internal<W>(n0, n1, k, i0, i1, rc);
-				const Slot *q = lookup<W>(tab, cap, i0, i1);
-				if (!q || (q->meta & COUNT_MASK) == 0) keep &= ~(1u << (4 + c));
 			}
+			uint64_t i0, i1;
+			bool rc;
+			canonical_internal<W>(n0, n1, k, i0, i1, rc);
+			const Slot *q = lookup<W>(tab, cap, i0, i1);
+			if (!q || (q->meta & COUNT_MASK) == 0) keep &= ~(1u << bit);
 		}
 		if (keep != e) tab[i].meta = (v.meta & ~(0xFFull << PUB_SHIFT)) | ((uint64_t)keep << PUB_SHIFT);
 	}
