@@ -928,36 +928,84 @@ __device__ __forceinline__ void edge_neighbour(uint64_t K0, uint64_t K1, uint32_
 	canonical_internal<W>(n0, n1, k, i0, i1, rc);
 }
 
-// WRITE == false: counts[owner] += queries; WRITE == true: keys/origin written at cursors[owner]++
+// WRITE == false: counts[owner] += queries; WRITE == true: keys/origin written at cursors[owner]++.
+// Up to PURGE_LDS_RANKS ranks a workgroup counts its queries per owner in LDS first and claims its places with one global
+// atomic per owner and BLOCK slots (one per query would be 2e8 atomics on `size` addresses for C2's graph); a lane walks its
+// own set edge bits, so the lanes of a wavefront work on their j-th neighbours together.
+static constexpr uint32_t PURGE_LDS_RANKS = 1024;
 template <int W, bool WRITE>
 __global__ __launch_bounds__(BLOCK) void k_purge_queries(const Slot *__restrict__ tab, uint64_t cap, int k, uint32_t size,
                                                          unsigned long long *__restrict__ counts_or_cursors,
                                                          uint64_t *__restrict__ keys, uint64_t *__restrict__ origin) {
+	__shared__ uint32_t s_cnt[PURGE_LDS_RANKS];
+	__shared__ unsigned long long s_base[PURGE_LDS_RANKS];
+	const bool in_lds = size <= PURGE_LDS_RANKS;  // uniform
 	const uint64_t mask0 = (2 * k >= 64) ? ~0ull : ((1ull << (2 * k)) - 1);
 	const uint64_t mask1 = (k > 32) ? ((1ull << (2 * k - 64)) - 1) : 0ull;
-	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-	for (; i < cap; i += stride) {
-		const Slot v = tab[i];
-		if (v.k0 == EMPTY || (v.meta & COUNT_MASK) == 0) continue;
-		const uint32_t e = (uint32_t)(v.meta >> PUB_SHIFT) & 0xFFu;
-		if (!e) continue;
-		uint64_t K0, K1;
-		from_internal<W>(v.k0, v.k1, K0, K1);
-		for (uint32_t bit = 0; bit < 8; ++bit) {
-			if (!(e & (1u << bit))) continue;
-			uint64_t i0, i1;
-			edge_neighbour<W>(K0, K1, bit, k, mask0, mask1, i0, i1);
-			uint64_t N0, N1;
-			from_internal<W>(i0, i1, N0, N1);
-			const uint32_t owner = (uint32_t)(hash1<W>(N0, N1) % (uint64_t)size);
-			const unsigned long long pos = atomicAdd(&counts_or_cursors[owner], 1ull);
-			if (WRITE) {
-				keys[pos * W] = i0;
-				if (W == 2) keys[pos * W + 1] = i1;
-				origin[pos] = (i << 3) | bit;
+	if (in_lds)
+		for (uint32_t r = threadIdx.x; r < size; r += blockDim.x) s_cnt[r] = 0;
+	__syncthreads();
+	for (uint64_t i0s = (uint64_t)blockIdx.x * blockDim.x; i0s < cap; i0s += stride) {  // uniform bounds: barriers inside
+		const uint64_t i = i0s + threadIdx.x;
+		uint32_t e = 0;
+		uint64_t K0 = 0, K1 = 0;
+		if (i < cap) {
+			const Slot v = tab[i];
+			if (v.k0 != EMPTY && (v.meta & COUNT_MASK) != 0) {
+				e = (uint32_t)(v.meta >> PUB_SHIFT) & 0xFFu;
+				from_internal<W>(v.k0, v.k1, K0, K1);
 			}
 		}
+		auto owner_of = [&](uint32_t bit, uint64_t &q0, uint64_t &q1) -> uint32_t {
+			edge_neighbour<W>(K0, K1, bit, k, mask0, mask1, q0, q1);
+			uint64_t N0, N1;
+			from_internal<W>(q0, q1, N0, N1);
+			return (uint32_t)(hash1<W>(N0, N1) % (uint64_t)size);
+		};
+		if (!in_lds) {
+			for (uint32_t rem = e; rem; rem &= rem - 1) {
+				const uint32_t bit = (uint32_t)__builtin_ctz(rem);
+				uint64_t q0, q1;
+				const uint32_t owner = owner_of(bit, q0, q1);
+				const unsigned long long pos = atomicAdd(&counts_or_cursors[owner], 1ull);
+				if (WRITE) {
+					keys[pos * W] = q0;
+					if (W == 2) keys[pos * W + 1] = q1;
+					origin[pos] = (i << 3) | bit;
+				}
+			}
+			continue;
+		}
+		for (uint32_t rem = e; rem; rem &= rem - 1) {
+			uint64_t q0, q1;
+			atomicAdd(&s_cnt[owner_of((uint32_t)__builtin_ctz(rem), q0, q1)], 1u);
+		}
+		if (!WRITE) continue;  // counts: flushed once, below
+		__syncthreads();
+		for (uint32_t r = threadIdx.x; r < size; r += blockDim.x) {
+			const uint32_t c = s_cnt[r];
+			s_base[r] = c ? atomicAdd(&counts_or_cursors[r], (unsigned long long)c) : 0ull;
+			s_cnt[r] = 0;
+		}
+		__syncthreads();
+		for (uint32_t rem = e; rem; rem &= rem - 1) {
+			const uint32_t bit = (uint32_t)__builtin_ctz(rem);
+			uint64_t q0, q1;
+			const uint32_t owner = owner_of(bit, q0, q1);
+			const unsigned long long pos = s_base[owner] + atomicAdd(&s_cnt[owner], 1u);
+			keys[pos * W] = q0;
+			if (W == 2) keys[pos * W + 1] = q1;
+			origin[pos] = (i << 3) | bit;
+		}
+		__syncthreads();
+		for (uint32_t r = threadIdx.x; r < size; r += blockDim.x) s_cnt[r] = 0;
+		__syncthreads();
+	}
+	if (in_lds && !WRITE) {
+		__syncthreads();
+		for (uint32_t r = threadIdx.x; r < size; r += blockDim.x)
+			if (s_cnt[r]) atomicAdd(&counts_or_cursors[r], (unsigned long long)s_cnt[r]);
 	}
 }
 
