@@ -1515,7 +1515,10 @@ struct AggLaunch {
 	uint64_t key_limit() const { return wg ? KLIMIT : (big ? agg_limit<AGG_SLOTS_BIG>() : AGG_LIMIT); }       // keys a bucket attempt can hold
 	uint64_t slack(unsigned grid) const { return wg ? 0 : (uint64_t)grid * agg_waves<W>() * LOG_CHUNK; }  // log entries lost to open chunks
 	// occurrences a bucket should hold at most: its distinct k-mers must fit the LDS table at the coverage assemblies are run at
-	uint64_t occ_per_bucket() const { return wg ? (uint64_t)KS * 24 : 2048; }
+	// (4096: C2 at 2^21 buckets of some 48 distinct k-mers, three levels of 7 bits -- a level of 8 bits costs k_scatter 1.1 ms more
+	// than the aggregation gains from buckets half the size: 57.1 against 57.6 ms/step; diverse inputs get their finer partition
+	// from the record sample)
+	uint64_t occ_per_bucket() const { return wg ? (uint64_t)KS * 24 : 4096; }
 	unsigned grid_for_buckets(uint64_t n, int n_cu) const { return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n + per_group() - 1) / per_group(), (uint64_t)n_cu * occ)); }
 	void fast(rg_handle *h, unsigned grid, const RM *recs, const unsigned long long *begin, uint32_t nb, int k, Slot *log, uint64_t log_cap,
 	          uint32_t flag_unique, uint32_t *retry, int m, uint32_t rbits) const {
