@@ -1,8 +1,7 @@
 """ray_amd -- MI355X-native de Bruijn graph construction for the Ray assembler's hot path.
 
 Only what the path needs: csrc/ (HIP kernels + the C ABI of include/raygraph.h), the ctypes
-binding, the host-side mirror of Ray's three graph-construction plugins and the multi-GPU
-exchange.  Importing the package loads the in-tree HIP library and fails if it is not built.
+binding and the multi-GPU exchange.  Importing the package loads the in-tree HIP library and fails if it is not built.
 """
 from . import _lib
 
@@ -10,9 +9,6 @@ _lib.load()
 
 from .graph import (GraphBuilder, RayGraphError, count_sequences, coverage_distribution, pack_read, pack_reads,  # noqa: E402
                     write_coverage_checkpoint, write_genome_graph, write_graph_partition)
-from .plugins import (CoverageGatherer, GridTable, KmerAcademyBuilder, Parameters, VerticesExtractor,  # noqa: E402
-                      build_graph)
 
 __all__ = ["GraphBuilder", "RayGraphError", "coverage_distribution", "pack_read", "pack_reads", "count_sequences",
-           "write_coverage_checkpoint", "write_genome_graph", "write_graph_partition",
-           "KmerAcademyBuilder", "VerticesExtractor", "CoverageGatherer", "GridTable", "Parameters", "build_graph"]
+           "write_coverage_checkpoint", "write_genome_graph", "write_graph_partition"]

@@ -1,4 +1,4 @@
-"""Host-side mirror of Ray's three graph-construction plugins, for this path only.
+"""Test scaffolding: a host-side mirror of Ray's three graph-construction plugins, for this path only.
 
 Same names, argument meaning and completion behaviour as the reference's handlers, so the parity
 tests read like tests of Ray's own plugins:
@@ -17,8 +17,8 @@ import os
 
 import numpy as np
 
-from ._lib import RG_BLOOM_DEFAULT
-from .graph import GraphBuilder, coverage_distribution
+from ray_amd._lib import RG_BLOOM_DEFAULT
+from ray_amd.graph import GraphBuilder, coverage_distribution
 
 CONFIG_RAY_VERSION = "2.3.2-devel"
 
@@ -146,7 +146,7 @@ class CoverageGatherer:
 
     def writeKmers(self, path, append=False):
         """CoverageGatherer::writeKmers (CoverageGatherer.cpp:47-122); line order is table order"""
-        from .kmers_txt import write_kmers
+        from kmers_txt import write_kmers
         write_kmers(self.m_subgraph.builder, path, self.m_parameters, append=append)
 
 

@@ -142,15 +142,15 @@ def test_find_both_strands_and_kmers_txt(oracle, tmp_path):
     for q, c, e in zip(queries, cov, edges):
         found, wc, we = g.find(q)
         assert (int(c), int(e)) == ((wc, we) if found else (0, 0))
-    from ray_amd.kmers_txt import body_lines
+    from kmers_txt import body_lines
     got = sorted(body_lines(b.export(), 21))
     assert got == sorted(want["kmers_txt"].strip().split("\n"))
 
 
 def test_plugin_mirror_runs_the_master_mode_sequence(oracle, tmp_path):
-    import ray_amd
+    import plugin_mirror
     packed, offsets, lengths = make_reads_numpy(genome=5000, read_len=80, n_reads=3000, seed=44, error=0.01)
-    subgraph, (cov, cnt), values = ray_amd.build_graph(packed, offsets, lengths, k=22, prefix=str(tmp_path), write_kmers=True)
+    subgraph, (cov, cnt), values = plugin_mirror.build_graph(packed, offsets, lengths, k=22, prefix=str(tmp_path), write_kmers=True)
     want = oracle_run(oracle, packed, offsets, lengths, 21, purge=True)  # even k becomes k-1 (Parameters.cpp:892-907)
     assert subgraph.size() == want["size"]
     assert_records_equal(subgraph.export(), want["purged"], "plugin mirror")
