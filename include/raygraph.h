@@ -236,9 +236,15 @@ int rg_pack_reads_noalloc(rg_handle *h, const char *d_text, uint64_t text_bytes,
  *   -- all-to-all(v) of the keys; every rank answers what it received: --
  *   rg_markers_answer          coverage[i] = coverage of key i here, 0 if it is not stored (MessageProcessor.cpp:1224-1256)
  *   -- all-to-all(v) of the answers (4 bytes each) back, same order as the exported keys --
- *   rg_markers_apply           the marker rule of IndexerWorker.cpp:97-248 on the returned coverages */
+ *   rg_markers_apply           the marker rule of IndexerWorker.cpp:97-248 on the returned coverages
+ * rg_markers_query_counts_part(part, nparts) does this for reads [n*part/nparts, n*(part+1)/nparts) of every batch only (the
+ * slices of rg_records_local_part), so that the buffers of a round are bounded: per k-mer of the slice the caller holds a key
+ * and an answer, the library one 8-byte index; export / apply work on the slice the last counts call named, and apply writes
+ * the markers of that slice's reads only (d_forward / d_reverse are always the arrays of ALL reads of the handle).  Memory is
+ * per k-mer that exists: one very long read among short ones costs what its own k-mers cost. */
 int rg_read_markers(rg_handle *h, int32_t *d_forward, int32_t *d_reverse);
 int rg_markers_query_counts(rg_handle *h, uint64_t *counts);
+int rg_markers_query_counts_part(rg_handle *h, uint32_t part, uint32_t nparts, uint64_t *counts);
 int rg_markers_export_queries(rg_handle *h, void *d_queries, uint64_t cap_queries);
 int rg_markers_answer(rg_handle *h, const void *d_queries, uint64_t n, uint32_t *d_coverage);
 int rg_markers_apply(rg_handle *h, const uint32_t *d_coverage, uint64_t n, int32_t *d_forward, int32_t *d_reverse);
@@ -258,6 +264,16 @@ int rg_import_vertices(rg_handle *h, const void *records, uint64_t n_pairs);
 int rg_write_genome_graph(const void *records, uint64_t n_pairs, int k, int kmer_words, const char *path);
 int rg_write_coverage_checkpoint(const uint32_t *coverage, const uint64_t *count, uint64_t n, const char *path);
 int rg_write_graph_partition(const uint64_t *sizes, int nranks, const char *path);
+/* rg_write_coverage_analysis: <prefix>CoverageDistributionAnalysis.txt as call_RAY_MASTER_MODE_SEND_COVERAGE_VALUES writes it
+ * (MachineHelper/MachineHelper.cpp:283-327) from the merged histogram and the three values of rg_coverage_distribution;
+ * distribution_file = the path of CoverageDistribution.txt as it is printed on the last line (:325).
+ * rg_read_genome_graph: the reader of Rank<r>.Checkpoint.GenomeGraph.ray (MessageProcessor.cpp:596-655): entries of either
+ * strand with their parents and children as whole k-mers -> Vertex::dump records, one per pair (coverage from the lower
+ * key's entry, edge bits from both); the reader's assertions on the parents / children counts and the size (:633-641,650)
+ * are RG_ERR_ARG here.  records == NULL: *n_pairs only (the header's count / 2).  Feed the records to rg_import_vertices. */
+int rg_write_coverage_analysis(const uint32_t *coverage, const uint64_t *count, uint64_t n, int k, int32_t minimum, int32_t peak,
+                               int32_t repeat, const char *distribution_file, const char *path);
+int rg_read_genome_graph(const char *path, int k, int kmer_words, void *records, uint64_t cap_pairs, uint64_t *n_pairs);
 
 /* call_RAY_SLAVE_MODE_WRITE_KMERS degree table (MachineHelper/MachineHelper.cpp:548-578):
  * out[parents*5+children] over both strands of every stored vertex */
@@ -290,7 +306,26 @@ int rg_release_cached_memory(void);
 
 /* ---- test and experiment switches -------------------------------------------------------------- */
 /* Forces internal routes that the library otherwise chooses by itself; results never depend on them.  No counterpart
- * in the reference; a plugin leaves it alone.  Must be called before the counting starts.  flags: bits 0-7: 0 = automatic, 1 = force the partitioned sweep, 2 = force the direct sweep; bits 8-15: log2 of the bucket count of the partitioned sweep (0 = automatic); bit 4 / bit 5: force the partitioned / the dense Bloom resolution; bit 6: start with a one-chunk log (tests of the overflow path); bit 16: cut super-k-mer records with the wavefront-per-read kernel even where the lane-per-read one applies; bit 17: produce the Bloom items straight into their first partition level even from a sparse key array; bit 18: size the log from a sample of the buckets even on small inputs (tests); bit 19: rg_merge_entries never keeps received entries as a log (tests); bit 20: the partition levels' histograms read the records instead of the digit bytes the previous level left (tests); bit 21: aggregate with a workgroup per bucket of a two-level partition (k_aggregate_wg) instead of a wavefront per bucket of a three-level one (tests); bit 22 / bit 23: always / never build the vertex table range by range from partitioned entries (tests); bit 24: resolve a power-of-two Bloom filter by key partitions whatever its fill (tests); bit 25: pick the bucket count from a sample of the records even on small inputs (tests); bit 26: aggregate with the 512-slot k-mer tables that diverse inputs get (tests); bit 27: keep super-k-mer records in their 24-byte form where the 20-byte one applies (k <= 31; tests) */
+ * in the reference; a plugin leaves it alone.  Must be called before the counting starts.  flags:
+ *   bits 0-7   sweep: 0 = automatic, 1 = force the partitioned sweep, 2 = force the direct sweep
+ *   bit  4     force the Bloom resolution by (bit, key) items per Bloom region
+ *   bit  5     force the dense first-touch stamps
+ *   bit  6     start with a one-chunk log (tests of the overflow path)
+ *   bits 8-15  log2 of the bucket count of the partitioned sweep (0 = automatic)
+ *   bit  16    cut super-k-mer records with the wavefront-per-read kernel even where the lane-per-read one applies
+ *   bit  17    produce the Bloom items straight into their first partition level even from a sparse key array
+ *   bit  18    size the log from a sample of the buckets even on small inputs
+ *   bit  19    rg_merge_entries never keeps received entries as a log
+ *   bit  20    the partition levels' histograms read the records instead of the digit bytes the previous level left
+ *   bit  21    aggregate with a workgroup per bucket of a two-level partition (k_aggregate_wg) instead of a wavefront per
+ *              bucket of a three-level one
+ *   bit  22/23 always / never build the vertex table range by range from partitioned entries
+ *   bit  24    resolve a power-of-two Bloom filter by key partitions whatever its fill
+ *   bit  25    pick the bucket count from a sample of the records even on small inputs
+ *   bit  26    aggregate with the 512-slot k-mer tables that diverse inputs get
+ *   bit  27    keep super-k-mer records in their 24-byte form where the 20-byte one applies (k <= 31)
+ *   bit  28    key partitions: size the first level's ranges from a histogram pass instead of in advance
+ *   bit  29    key partitions: the dense region kernel even on a sparse filter */
 int rg_debug_set(rg_handle *h, uint32_t flags);
 
 /* ---- profiling (the reference's MACRO_COLLECT_PROFILING_INFORMATION probes,

@@ -1194,6 +1194,96 @@ int ro_graph_write_partition(const ro_graph *g, const char *path) {
 	return 0;
 }
 
+/* CoverageDistributionAnalysis.txt: call_RAY_MASTER_MODE_SEND_COVERAGE_VALUES (MachineHelper.cpp:283-327), statement by
+ * statement; distribution_file is what Parameters::getCoverageDistributionFile() returns (prefix + CoverageDistribution.txt).
+ * A C++ stream prints a double with 6 significant digits in general notation = %g. */
+int ro_write_coverage_analysis(const uint32_t *cov, const uint64_t *cnt, uint64_t n, int wordSize, int minimumCoverage, int peakCoverage,
+                               int repeatCoverage, const char *distribution_file, const char *path) {
+	uint64_t numberOfVertices = 0;
+	uint64_t verticesWith1Coverage = 0;
+	uint32_t lowestCoverage = 9999;
+	uint64_t genomeKmers = 0;
+	for (uint64_t i = 0; i < n; i++) { /* map<CoverageDepth,LargeCount>: ascending coverage */
+		uint32_t coverageValue = cov[i];
+		uint64_t vertices = cnt[i];
+		if (coverageValue < lowestCoverage) {
+			verticesWith1Coverage = vertices;
+			lowestCoverage = coverageValue;
+		}
+		if ((int64_t)coverageValue >= (int64_t)minimumCoverage) genomeKmers += vertices;
+		numberOfVertices += vertices;
+	}
+	double percentageSeenOnce = (0.0 + (double)verticesWith1Coverage) / (double)numberOfVertices * 100.00;
+	FILE *f = fopen(path, "w");
+	if (!f) return -1;
+	fprintf(f, "k-mer length:\t%d\n", wordSize);
+	fprintf(f, "Number of k-mers in the distributed de Bruijn graph: %llu\n", (unsigned long long)numberOfVertices);
+	fprintf(f, "Lowest coverage observed:\t%u\n", lowestCoverage);
+	fprintf(f, "MinimumCoverage:\t%d\n", minimumCoverage);
+	fprintf(f, "PeakCoverage:\t%d\n", peakCoverage);
+	fprintf(f, "RepeatCoverage:\t%d\n", repeatCoverage);
+	fprintf(f, "Number of k-mers with at least MinimumCoverage:\t%llu k-mers\n", (unsigned long long)genomeKmers);
+	fprintf(f, "Percentage of vertices with coverage %u:\t%g %%\n", lowestCoverage, percentageSeenOnce);
+	fprintf(f, "DistributionFile: %s\n", distribution_file);
+	fclose(f);
+	return 0;
+}
+
+/* The reader of the GenomeGraph checkpoint: call_RAY_MPI_TAG_START_INDEXING_SEQUENCES (MessageProcessor.cpp:596-655) into a
+ * fresh graph of one rank: per entry Kmer::read, int coverage, GridTable::insert, constructor + setCoverage when it was
+ * inserted (setCoverage only acts on the lower key, Vertex.cpp:80-92), then the parents through addIngoingEdge and the
+ * children through addOutgoingEdge; the CONFIG_ASSERT checks of :633-641,650 are returned as errors (-2 parents, -3
+ * children, -4 size).  The graph must have been created with the file's k and be empty. */
+int ro_graph_read_genome_graph(ro_graph *g, const char *path) {
+	FILE *f = fopen(path, "rb");
+	if (!f) return -1;
+	int W = g->W, k = g->k;
+	ro_table *subgraph = &g->tables[0];
+	uint64_t n = 0;
+	if (fread(&n, sizeof(uint64_t), 1, f) != 1) {
+		fclose(f);
+		return -1;
+	}
+	int status = 0;
+	for (uint64_t i = 0; i < n && status == 0; i++) {
+		uint64_t kmer[2] = {0, 0};
+		int coverage = 0;
+		if (fread(kmer, sizeof(uint64_t), (size_t)W, f) != (size_t)W || fread(&coverage, sizeof(int), 1, f) != 1) {
+			status = -1;
+			break;
+		}
+		ro_vertex *tmp = grid_insert(subgraph, kmer, k, W);
+		if (subgraph->inserted) {
+			tmp->coverage = 0; /* Vertex::constructor */
+			tmp->edges = 0;
+			vertex_set_coverage(tmp, kmer, (uint32_t)coverage, W);
+		}
+		int parents = 0;
+		if (fread(&parents, sizeof(int), 1, f) != 1) status = -1;
+		for (int j = 0; j < parents && status == 0; j++) {
+			uint64_t parent[2] = {0, 0};
+			if (fread(parent, sizeof(uint64_t), (size_t)W, f) != (size_t)W) status = -1;
+			else tmp->edges = ro_add_ingoing_edge(tmp->edges, kmer, parent, k, W);
+		}
+		int children = 0;
+		if (status == 0 && fread(&children, sizeof(int), 1, f) != 1) status = -1;
+		for (int j = 0; j < children && status == 0; j++) {
+			uint64_t child[2] = {0, 0};
+			if (fread(child, sizeof(uint64_t), (size_t)W, f) != (size_t)W) status = -1;
+			else tmp->edges = ro_add_outgoing_edge(tmp->edges, kmer, child, k, W);
+		}
+		if (status == 0) {
+			uint64_t nb[4][2];
+			uint8_t e = vertex_get_edges(tmp->edges, tmp->key, kmer, W);
+			if (ro_ingoing_edges(kmer, e, k, W, nb) != parents) status = -2;
+			else if (ro_outgoing_edges(kmer, e, k, W, nb) != children) status = -3;
+		}
+	}
+	fclose(f);
+	if (status == 0 && subgraph->size != n) status = -4;
+	return status;
+}
+
 /* ------------------------------------------------------------------ next row: read ingest */
 
 /* FastqLoader::loadWithPeriod (FastqLoader.cpp:84-119): line 1 of every 4 is the sequence; FastaLoader::load

@@ -104,6 +104,12 @@ int ro_graph_write_partition(const ro_graph *g, const char *path);              
 uint64_t ro_load_sequences(const char *path, int is_fastq, uint8_t *packed, uint64_t packed_cap, uint64_t *offsets,
                            uint32_t *lengths, uint64_t cap_reads, uint64_t *packed_bytes); /* FastqLoader.cpp:84-119, FastaLoader.cpp:26-64 */
 int ro_graph_read_markers(const ro_graph *g, int32_t *forward, int32_t *reverse);    /* SequencesIndexer/IndexerWorker.cpp:67-248,328-362 */
+int ro_write_coverage_analysis(const uint32_t *cov, const uint64_t *cnt, uint64_t n, int wordSize, int minimumCoverage, int peakCoverage,
+                               int repeatCoverage, const char *distribution_file, const char *path); /* MachineHelper.cpp:283-327 */
+int ro_graph_read_genome_graph(ro_graph *g, const char *path);                        /* MessageProcessor.cpp:596-655 */
+/* the counter-based generator of synthetic reads (ro_synth.c; device twin: tools/rg_synth.hip) */
+int ro_synth_generate(uint8_t *packed, uint64_t *offsets, uint32_t *lengths, uint64_t n, uint64_t r0, uint64_t genome, uint32_t L, uint64_t seed,
+                      double error);
 
 #ifdef __cplusplus
 }

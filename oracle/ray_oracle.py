@@ -16,8 +16,8 @@ BLOOM_DEFAULT = (1 << 64) - 1
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "ray_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    newest = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("ray_oracle.c", "ro_synth.c", "ray_oracle.h"))
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < newest:
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
 
@@ -100,6 +100,12 @@ def lib():
         L.ro_load_sequences.restype = C.c_uint64
         L.ro_graph_read_markers.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.ro_graph_read_markers.restype = C.c_int
+        L.ro_write_coverage_analysis.argtypes = [u32p, u64p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p]
+        L.ro_write_coverage_analysis.restype = C.c_int
+        L.ro_graph_read_genome_graph.argtypes = [C.c_void_p, C.c_char_p]
+        L.ro_graph_read_genome_graph.restype = C.c_int
+        L.ro_synth_generate.argtypes = [u8p, u64p, u32p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_double]
+        L.ro_synth_generate.restype = C.c_int
         _lib = L
     return _lib
 
@@ -274,6 +280,11 @@ class Graph:
     def write_genome_graph(self, rank, path):
         assert lib().ro_graph_write_genome_graph(self._g, rank, path.encode()) == 0
 
+    def read_genome_graph(self, path):
+        """the reference's checkpoint reader (MessageProcessor.cpp:596-655) into this (empty, one-rank) graph; 0 = ok,
+        -2 / -3 / -4 = the reader's parents / children / size assertion (:633-641,650) would have failed"""
+        return lib().ro_graph_read_genome_graph(self._g, path.encode())
+
     def write_partition(self, path):
         assert lib().ro_graph_write_partition(self._g, path.encode()) == 0
 
@@ -298,6 +309,14 @@ def write_coverage_checkpoint(cov, cnt, path):
                                               len(cov), path.encode()) == 0
 
 
+def write_coverage_analysis(cov, cnt, k, minimum, peak, repeat, distribution_file, path):
+    """CoverageDistributionAnalysis.txt (MachineHelper.cpp:283-327)"""
+    cov = np.ascontiguousarray(cov, dtype=np.uint32)
+    cnt = np.ascontiguousarray(cnt, dtype=np.uint64)
+    assert lib().ro_write_coverage_analysis(cov.ctypes.data_as(C.POINTER(C.c_uint32)), cnt.ctypes.data_as(C.POINTER(C.c_uint64)), len(cov),
+                                            k, minimum, peak, repeat, distribution_file.encode(), path.encode()) == 0
+
+
 def load_sequences(path, is_fastq):
     """(packed, offsets, lengths) of a FASTA / FASTQ file as the reference's loaders build them"""
     used = C.c_uint64()
@@ -309,6 +328,20 @@ def load_sequences(path, is_fastq):
                             offsets.ctypes.data_as(C.POINTER(C.c_uint64)), lengths.ctypes.data_as(C.POINTER(C.c_uint32)),
                             n, C.byref(used))
     return packed[: used.value], offsets[:n], lengths[:n]
+
+
+def synth_generate(n, genome, read_len, seed, error=0.0, first=0):
+    """reads first .. first+n-1 of the counter-based generator (oracle/ro_synth.c = tools/rg_synth.hip on the device)
+    -> (packed, offsets, lengths)"""
+    bpr = (read_len + 3) // 4
+    packed = np.zeros(max(1, n * bpr), dtype=np.uint8)
+    offsets = np.zeros(max(1, n), dtype=np.uint64)
+    lengths = np.zeros(max(1, n), dtype=np.uint32)
+    rc = lib().ro_synth_generate(packed.ctypes.data_as(C.POINTER(C.c_uint8)), offsets.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                 lengths.ctypes.data_as(C.POINTER(C.c_uint32)), n, first, genome, read_len, seed, error)
+    if rc != 0:
+        raise ValueError("ro_synth_generate rc=%d" % rc)
+    return packed[: n * bpr], offsets[:n], lengths[:n]
 
 
 def record_dtype(W):

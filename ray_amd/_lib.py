@@ -34,8 +34,8 @@ SYMBOLS = ["rg_create", "rg_destroy", "rg_last_error", "rg_add_reads", "rg_add_r
            "rg_count_local", "rg_records_local", "rg_records_local_part", "rg_record_counts", "rg_export_records", "rg_count_records", "rg_owner_counts", "rg_export_owner_buckets", "rg_merge_entries",
            "rg_resolve_admission", "rg_histogram", "rg_add_edges", "rg_purge_edges", "rg_purge_query_counts",
            "rg_purge_export_queries", "rg_purge_answer", "rg_purge_apply", "rg_size", "rg_export",
-           "rg_find", "rg_add_reads_text", "rg_count_sequences", "rg_load_sequences", "rg_get_reads", "rg_pack_reads_noalloc", "rg_release_local", "rg_adopt_entries", "rg_check_hashes", "rg_hash_kmers", "rg_read_markers", "rg_markers_query_counts", "rg_markers_export_queries", "rg_markers_answer", "rg_markers_apply",
-           "rg_import_vertices", "rg_write_kmers_txt", "rg_write_genome_graph", "rg_write_coverage_checkpoint", "rg_write_graph_partition", "rg_degree_distribution", "rg_get_stats", "rg_set_profiling", "rg_debug_set", "rg_get_kernel_profile", "rg_release_cached_memory", "rg_coverage_distribution", "rg_pack_read",
+           "rg_find", "rg_add_reads_text", "rg_count_sequences", "rg_load_sequences", "rg_get_reads", "rg_pack_reads_noalloc", "rg_release_local", "rg_adopt_entries", "rg_check_hashes", "rg_hash_kmers", "rg_read_markers", "rg_markers_query_counts", "rg_markers_query_counts_part", "rg_markers_export_queries", "rg_markers_answer", "rg_markers_apply",
+           "rg_import_vertices", "rg_write_kmers_txt", "rg_write_genome_graph", "rg_write_coverage_checkpoint", "rg_write_graph_partition", "rg_write_coverage_analysis", "rg_read_genome_graph", "rg_degree_distribution", "rg_get_stats", "rg_set_profiling", "rg_debug_set", "rg_get_kernel_profile", "rg_release_cached_memory", "rg_coverage_distribution", "rg_pack_read",
            "rg_version"]
 
 _lib = None
@@ -99,6 +99,7 @@ def load():
         "rg_check_hashes": ([vp, HASH_FN, HASH_FN, vp, C.c_uint32], C.c_int),
         "rg_hash_kmers": ([vp, u64p, u64, u64p, u64p], C.c_int),
         "rg_markers_query_counts": ([vp, u64p], C.c_int),
+        "rg_markers_query_counts_part": ([vp, C.c_uint32, C.c_uint32, u64p], C.c_int),
         "rg_markers_export_queries": ([vp, vp, u64], C.c_int),
         "rg_markers_answer": ([vp, vp, u64, vp], C.c_int),
         "rg_markers_apply": ([vp, vp, u64, vp, vp], C.c_int),
@@ -107,6 +108,8 @@ def load():
         "rg_write_genome_graph": ([vp, u64, C.c_int, C.c_int, C.c_char_p], C.c_int),
         "rg_write_coverage_checkpoint": ([u32p, u64p, u64, C.c_char_p], C.c_int),
         "rg_write_graph_partition": ([u64p, C.c_int, C.c_char_p], C.c_int),
+        "rg_write_coverage_analysis": ([u32p, u64p, u64, C.c_int, C.c_int32, C.c_int32, C.c_int32, C.c_char_p, C.c_char_p], C.c_int),
+        "rg_read_genome_graph": ([C.c_char_p, C.c_int, C.c_int, vp, u64, u64p], C.c_int),
         "rg_get_stats": ([vp, C.POINTER(RgStats)], C.c_int),
         "rg_release_cached_memory": ([], C.c_int),
         "rg_set_profiling": ([vp, C.c_int], C.c_int),

@@ -235,6 +235,144 @@ int rg_write_coverage_checkpoint(const uint32_t *coverage, const uint64_t *count
 	return RG_OK;
 }
 
+// CoverageDistributionAnalysis.txt (MachineHelper.cpp:283-327): written by the master right after CoverageDistribution.txt.
+// Lowest coverage = the smallest key below 9999 (the loop's start value, :285,295-298); the percentage is a double printed
+// by a C++ stream = %g.
+int rg_write_coverage_analysis(const uint32_t *coverage, const uint64_t *count, uint64_t n, int k, int32_t minimum, int32_t peak,
+                               int32_t repeat, const char *distribution_file, const char *path) {
+	if ((n && (!coverage || !count)) || !distribution_file || !path) return RG_ERR_ARG;
+	uint64_t vertices = 0, lowest_count = 0, at_least_minimum = 0;
+	uint32_t lowest = 9999;
+	for (uint64_t i = 0; i < n; ++i) {
+		if (coverage[i] < lowest) {
+			lowest = coverage[i];
+			lowest_count = count[i];
+		}
+		if ((int64_t)coverage[i] >= (int64_t)minimum) at_least_minimum += count[i];
+		vertices += count[i];
+	}
+	FILE *f = fopen(path, "w");
+	if (!f) return RG_ERR_ARG;
+	fprintf(f, "k-mer length:\t%d\n", k);
+	fprintf(f, "Number of k-mers in the distributed de Bruijn graph: %llu\n", (unsigned long long)vertices);
+	fprintf(f, "Lowest coverage observed:\t%u\n", lowest);
+	fprintf(f, "MinimumCoverage:\t%d\nPeakCoverage:\t%d\nRepeatCoverage:\t%d\n", minimum, peak, repeat);
+	fprintf(f, "Number of k-mers with at least MinimumCoverage:\t%llu k-mers\n", (unsigned long long)at_least_minimum);
+	fprintf(f, "Percentage of vertices with coverage %u:\t%g %%\n", lowest, (0.0 + (double)lowest_count) / (double)vertices * 100.00);
+	fprintf(f, "DistributionFile: %s\n", distribution_file);
+	fclose(f);
+	return RG_OK;
+}
+
+// The reader of Rank<r>.Checkpoint.GenomeGraph.ray, shaped like the reference's (MessageProcessor.cpp:596-655): every entry is
+// a k-mer of either strand with its coverage, its parents and its children as whole k-mers.  The reference inserts the
+// k-mer's lower key, takes the coverage only from the entry that creates the vertex and only if that entry IS the lower key
+// (Vertex::setCoverage, Vertex.cpp:80-92: the writer emits the lower key first, GridTableIterator.cpp:41-54), and adds one
+// edge bit per parent / child through Vertex::addIngoingEdge / addOutgoingEdge (first base of the parent, last base of the
+// child, in the entry's orientation, converted to the lower key's).  Output: Vertex::dump records (what rg_import_vertices
+// and Vertex::load take), one per vertex pair, in the order the pairs first appear.  The CONFIG_ASSERT checks of :633-641,650
+// are errors here: a parent / child that is not a neighbour of its k-mer, or a count that is not 2 per pair -> RG_ERR_ARG.
+// records == NULL: *n_pairs = the header's count / 2, nothing else is read.
+int rg_read_genome_graph(const char *path, int k, int kmer_words, void *records, uint64_t cap_pairs, uint64_t *n_pairs) {
+	if (!path || !n_pairs || k < 1 || k > 64 || (kmer_words != 1 && kmer_words != 2) || (kmer_words == 1 && k > 32)) return RG_ERR_ARG;
+	FILE *f = fopen(path, "rb");
+	if (!f) return RG_ERR_ARG;
+	const int W = kmer_words;
+	const size_t rec = (size_t)W * 8 + 5;
+	uint64_t n = 0;
+	if (fread(&n, sizeof n, 1, f) != 1 || (n & 1)) {
+		fclose(f);
+		return RG_ERR_ARG;
+	}
+	*n_pairs = n / 2;
+	if (!records) {
+		fclose(f);
+		return RG_OK;
+	}
+	if (cap_pairs < n / 2) {
+		fclose(f);
+		return RG_ERR_CAPACITY;
+	}
+	std::vector<char> iobuf(4u << 20);
+	setvbuf(f, iobuf.data(), _IOFBF, iobuf.size());
+	auto less = [&](const K2 &a, const K2 &b) { return a.w[0] != b.w[0] ? a.w[0] < b.w[0] : a.w[1] < b.w[1]; };  // Kmer::operator< (Kmer.cpp:38-47)
+	auto same = [&](const K2 &a, const K2 &b) { return a.w[0] == b.w[0] && a.w[1] == b.w[1]; };
+	auto read_kmer = [&](K2 *out) {
+		out->w[0] = out->w[1] = 0;
+		return fread(out->w, 8, (size_t)W, f) == (size_t)W;
+	};
+	uint8_t *out = (uint8_t *)records;
+	uint64_t made = 0;
+	std::map<std::pair<uint64_t, uint64_t>, uint64_t> seen;  // lower key -> record index, only for pairs that do not arrive back to back
+	K2 last_lower{{~0ull, ~0ull}};
+	uint64_t last_index = 0;
+	bool have_last = false, ok = true;
+	for (uint64_t i = 0; i < n && ok; ++i) {
+		K2 kmer;
+		int coverage = 0, parents = 0, children = 0;
+		if (!read_kmer(&kmer) || fread(&coverage, sizeof(int), 1, f) != 1) {
+			ok = false;
+			break;
+		}
+		const K2 rc = revcomp_host(kmer, k, W);
+		const bool is_lower = !less(rc, kmer);
+		const K2 lower = is_lower ? kmer : rc;
+		uint64_t idx;
+		bool inserted = false;
+		if (have_last && same(lower, last_lower)) idx = last_index;
+		else {
+			auto it = seen.find({lower.w[0], lower.w[1]});
+			if (it != seen.end()) idx = it->second;
+			else {
+				if (made >= cap_pairs) {  // more than count / 2 distinct pairs: the header lies (the reader's size assertion, :650)
+					ok = false;
+					break;
+				}
+				if (have_last) seen[{last_lower.w[0], last_lower.w[1]}] = last_index;
+				idx = made++;
+				inserted = true;
+				uint8_t *p = out + idx * rec;
+				memcpy(p, lower.w, (size_t)W * 8);
+				memset(p + W * 8, 0, 5);
+			}
+		}
+		last_lower = lower;
+		last_index = idx;
+		have_last = true;
+		uint8_t *p = out + idx * rec;
+		if (inserted && is_lower) {  // tmp->constructor(); tmp->setCoverage(&kmer, coverage)
+			const uint32_t c = (uint32_t)coverage;
+			memcpy(p + W * 8, &c, 4);
+		}
+		uint8_t e = 0;  // in the entry's orientation
+		if (fread(&parents, sizeof(int), 1, f) != 1 || parents < 0 || parents > 4) ok = false;
+		for (int j = 0; j < parents && ok; ++j) {
+			K2 nb;
+			if (!read_kmer(&nb)) ok = false;
+			else {
+				const int c = (int)(nb.w[0] & 3);  // Kmer::getFirstSegmentFirstCode (Kmer.cpp:155-163)
+				if (!same(parent_of(kmer, c, k, W), nb) || ((e >> c) & 1)) ok = false;  // :633-639
+				e |= (uint8_t)(1u << c);
+			}
+		}
+		if (ok && (fread(&children, sizeof(int), 1, f) != 1 || children < 0 || children > 4)) ok = false;
+		for (int j = 0; j < children && ok; ++j) {
+			K2 nb;
+			if (!read_kmer(&nb)) ok = false;
+			else {
+				const int pos = 2 * (k - 1);
+				const int c = (int)((nb.w[pos / 64] >> (pos % 64)) & 3);  // Kmer::getSecondSegmentLastCode (Kmer.cpp:145-153)
+				if (!same(child_of(kmer, c, k, W), nb) || ((e >> (4 + c)) & 1)) ok = false;  // :640
+				e |= (uint8_t)(1u << (4 + c));
+			}
+		}
+		if (ok) p[W * 8 + 4] |= is_lower ? e : convert_bitmap_host(e);
+	}
+	fclose(f);
+	if (!ok || made * 2 != n) return RG_ERR_ARG;
+	return RG_OK;
+}
+
 // EdgePurger::writeGraphPartition (EdgePurger.cpp:172-217): sizes[r] = GridTable::size() of rank r
 int rg_write_graph_partition(const uint64_t *sizes, int nranks, const char *path) {
 	if (!sizes || nranks < 1 || !path) return RG_ERR_ARG;

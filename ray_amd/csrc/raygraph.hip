@@ -516,12 +516,17 @@ __device__ __forceinline__ bool is_acgt_any_case(uint8_t c) {
 __global__ __launch_bounds__(BLOCK) void k_trim_reads(const uint8_t *__restrict__ text, const uint64_t *__restrict__ starts,
                                                       const uint32_t *__restrict__ raw_len, uint64_t n,
                                                       uint64_t *__restrict__ tstart, uint32_t *__restrict__ tlen,
-                                                      unsigned long long *__restrict__ nbytes) {
+                                                      unsigned long long *__restrict__ nbytes, uint64_t text_bytes) {
 	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
 	for (; i < n; i += stride) {
-		const uint8_t *p = text + starts[i];
-		const uint32_t len = raw_len[i];
+		// a sequence that does not lie inside the text, or is too long to store (uint16_t m_length), is read as empty:
+		// nothing outside [text, text + text_bytes) is ever touched (rg_add_reads_text rejects such input on the host;
+		// rg_pack_reads_noalloc, whose arrays live on the device, relies on this)
+		const uint64_t st = starts[i];
+		const bool inside = raw_len[i] < 65535u && st <= text_bytes && (uint64_t)raw_len[i] <= text_bytes - st;
+		const uint8_t *p = text + (inside ? st : 0);
+		const uint32_t len = inside ? raw_len[i] : 0u;
 		uint32_t first = 0;
 		while (first < len && !is_acgt_any_case(p[first])) first++;
 		uint32_t last = first;  // one past the last ACGT symbol
@@ -530,7 +535,7 @@ __global__ __launch_bounds__(BLOCK) void k_trim_reads(const uint8_t *__restrict_
 				last = j;
 				break;
 			}
-		tstart[i] = starts[i] + first;
+		tstart[i] = (inside ? st : 0) + first;
 		tlen[i] = last - first;
 		nbytes[i] = (last - first + 3) / 4;  // Read::getRequiredBytes (Read.cpp:206-220)
 	}
@@ -655,12 +660,13 @@ __global__ __launch_bounds__(256) void k_read_markers(const uint64_t *__restrict
 
 // ---- markers across ranks: the coverage requests of IndexerWorker.cpp:76-96 in bulk ---------------------
 // WRITE == false: counts[owner] += k-mers of the local reads that owner must answer for; WRITE == true: canonical keys
-// (internal form) written at cursors[owner]++, origin = (read index in the handle << 16) | position
+// (internal form) written at cursors[owner]++, and qidx[kprefix[read] + position] = where that k-mer's query went
+// (kprefix = exclusive scan of the reads' k-mer counts: memory is per k-mer that exists, not per read x longest read)
 template <int W, bool WRITE>
 __global__ __launch_bounds__(256) void k_marker_queries(const uint64_t *__restrict__ P, const uint64_t *__restrict__ offsets,
-                                                        const uint32_t *__restrict__ lengths, uint64_t nreads, uint64_t read0, int k, uint32_t size,
+                                                        const uint32_t *__restrict__ lengths, uint64_t nreads, int k, uint32_t size,
                                                         unsigned long long *__restrict__ counts_or_cursors, uint64_t *__restrict__ keys,
-                                                        uint64_t *__restrict__ origin) {
+                                                        const unsigned long long *__restrict__ kprefix, uint64_t *__restrict__ qidx) {
 	extern __shared__ unsigned long long s_dyn[];  // [size] global bases (WRITE), then [size] u32 counts
 	unsigned long long *s_base = s_dyn;
 	uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_dyn + size);
@@ -709,7 +715,7 @@ __global__ __launch_bounds__(256) void k_marker_queries(const uint64_t *__restri
 					const unsigned long long pos = s_base[owner] + rank;
 					keys[pos * W] = i0;
 					if (W == 2) keys[pos * W + 1] = i1;
-					origin[pos] = ((read0 + r) << 16) | p;
+					qidx[kprefix[r] + p] = pos;
 				}
 				__syncthreads();
 				for (uint32_t j = threadIdx.x; j < size; j += 256) s_cnt[j] = 0;
@@ -740,20 +746,21 @@ __global__ __launch_bounds__(BLOCK) void k_marker_answer(const Slot *__restrict_
 	}
 }
 
-// answers back in the order the keys were exported -> coverage of (read, position): cov2d[read * maxn + position]
-__global__ __launch_bounds__(BLOCK) void k_marker_place(const uint64_t *__restrict__ origin, const uint32_t *__restrict__ answers, uint64_t n,
-                                                        uint32_t *__restrict__ cov2d, uint64_t maxn) {
-	uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// k-mers of every read (0 for reads shorter than k), the input of the scan that gives kprefix
+__global__ __launch_bounds__(BLOCK) void k_marker_kmer_counts(const uint32_t *__restrict__ lengths, uint64_t n, int k, unsigned long long *__restrict__ out) {
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-	for (; q < n; q += stride) {
-		const uint64_t o = origin[q];
-		cov2d[(o >> 16) * maxn + (o & 0xFFFFu)] = answers[q];
+	for (; i < n; i += stride) {
+		const uint32_t L = lengths[i];
+		out[i] = (L >= (uint32_t)k) ? (unsigned long long)(L - (uint32_t)k + 1) : 0ull;
 	}
 }
 
 // k_read_markers with the coverages given (one wavefront per read; see there for the rule)
-__global__ __launch_bounds__(256) void k_markers_from_coverage(const uint32_t *__restrict__ lengths, uint64_t nreads, uint64_t read0, int k,
-                                                               const uint32_t *__restrict__ cov2d, uint64_t maxn, int32_t *__restrict__ forward,
+// answers[qidx[kprefix[r] + p]] = coverage of k-mer p of read r, as the owners returned it
+__global__ __launch_bounds__(256) void k_markers_from_coverage(const uint32_t *__restrict__ lengths, uint64_t nreads, int k,
+                                                               const uint32_t *__restrict__ answers, const unsigned long long *__restrict__ kprefix,
+                                                               const uint64_t *__restrict__ qidx, int32_t *__restrict__ forward,
                                                                int32_t *__restrict__ reverse) {
 	__shared__ uint32_t s_le[4][10], s_ge[4][10], s_first[4][10], s_last[4][10];
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -778,7 +785,7 @@ __global__ __launch_bounds__(256) void k_markers_from_coverage(const uint32_t *_
 			last1[v] = 0;
 		}
 		for (uint32_t p = lane; p < n; p += 64) {
-			const int cov = (int)cov2d[(read0 + r) * maxn + p];  // the reference compares the coverage as an int (IndexerWorker.cpp:92)
+			const int cov = (int)answers[qidx[kprefix[r] + p]];  // the reference compares the coverage as an int (IndexerWorker.cpp:92)
 #pragma unroll
 			for (int v = 0; v < 10; ++v) {
 				if (cov <= v + 1) le[v]++;
@@ -1149,6 +1156,7 @@ __global__ __launch_bounds__(BLOCK) void k_export_write(const Slot *__restrict__
 // instead of going back to the driver: releasing tens of GiB of touched VRAM costs hundreds of
 // milliseconds per call on this stack, and a graph build allocates the same few sizes every time.
 // rg_release_cached_memory() returns everything to the driver.
+#include <atomic>
 #include <map>
 #include <mutex>
 namespace {
@@ -1250,6 +1258,20 @@ static __device__ __align__(256) unsigned char scratch[NOALLOC_BYTES];
 namespace {
 std::mutex g_noalloc_mu;
 void *g_noalloc_ptr[64] = {nullptr};
+hipEvent_t g_noalloc_done[64] = {nullptr};        // recorded after the last kernel a call queued (created once, at set-up)
+hipStream_t g_noalloc_last_stream[64] = {nullptr}; // the stream that call was queued on
+std::atomic<int> g_noalloc_busy[64];              // 1 while a host thread is inside rg_pack_reads_noalloc on that GPU
+struct NoallocGuard {
+	int dev;
+	bool ok;
+	explicit NoallocGuard(int d) : dev(d) {
+		int expected = 0;
+		ok = g_noalloc_busy[d].compare_exchange_strong(expected, 1);
+	}
+	~NoallocGuard() {
+		if (ok) g_noalloc_busy[dev].store(0);
+	}
+};
 // once per device, with that device current
 hipError_t noalloc_init(int device) {
 	if (device < 0 || device >= 64) return hipErrorInvalidDevice;
@@ -1259,6 +1281,8 @@ hipError_t noalloc_init(int device) {
 	hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
 	if (e != hipSuccess) return e;
 	if (!ptr) return hipErrorInvalidSymbol;
+	e = hipEventCreateWithFlags(&g_noalloc_done[device], hipEventDisableTiming);
+	if (e != hipSuccess) return e;
 	g_noalloc_ptr[device] = ptr;
 	return hipSuccess;
 }
@@ -1315,7 +1339,10 @@ struct rg_handle {
 	uint64_t rec_slots = 0;              // slots of rec_buf in use (holes included)
 	std::vector<uint64_t> rec_counts;    // valid records per destination rank
 	const char *prof_alias = nullptr;     // set: every kernel is profiled under this name (the sample's sweep inside the sweep)
-	uint64_t *d_marker_origin = nullptr;  // rg_markers_export_queries .. rg_markers_apply: (read << 16 | position) per query
+	uint64_t *d_marker_qidx = nullptr;    // rg_markers_export_queries .. rg_markers_apply: where the query of (read, position) went
+	unsigned long long *d_marker_kprefix = nullptr;  // rg_markers_query_counts ..: exclusive scan of the slice's k-mers per read
+	uint32_t marker_part = 0, marker_nparts = 1;     // the slice of the reads the pending marker queries cover
+	uint64_t marker_slice_reads = 0;
 	uint64_t marker_total = 0;
 	std::vector<uint64_t> marker_counts;
 	uint64_t *d_purge_origin = nullptr;  // rg_purge_export_queries .. rg_purge_apply: (slot << 3 | edge bit) per query
@@ -2336,24 +2363,21 @@ static int bloom_partitioned(rg_handle *h, Table &T, uint64_t m_bits, uint64_t k
 // counted: the first level's ranges come from a histogram pass (k_xor_hist) instead of being sized in advance.
 static int bloom_xor(rg_handle *h, Table &T, uint64_t m_bits, uint64_t keys, bool *ok, uint8_t **keep_lost = nullptr, bool counted = false) {
 	*ok = false;
-	if (getenv("RG_XOR_COUNTED")) counted = true;
+	if (h->dbg & 0x10000000u) counted = true;  // rg_debug_set bit 28 (tests)
 	const int dev = h->cfg.device;
 	if (m_bits == 0 || (m_bits & (m_bits - 1)) || T.cap >= (1ull << 32) || keys == 0) return RG_OK;
 	int B = 0;
 	while ((1ull << B) < m_bits) B++;
 	// region size: 2^14 bits, one workgroup of 1024 threads per CU (C2 with 1 % errors: k_xor_region 58 ms; 2^13 bits x 2
-	// workgroups of 512: 73 ms; 2^12 x 4 of 256: 77 ms -- RG_XOR_R selects them for experiments)
+	// workgroups of 512: 73 ms; 2^12 x 4 of 256: 77 ms)
 	int rmax = 14;
-	if (const char *ev = getenv("RG_XOR_R")) rmax = std::max(12, std::min(XOR_REGION_LOG2_MAX, atoi(ev)));
 	// Dense filters: a region's eight streams stay in registers between the two passes while each holds at most
 	// 1024 x XOR_SPER keys; beyond that the streams would be read twice (C5's share per GPU: 5370 keys per stream at 2^14
 	// bits), so the regions are halved instead -- the workgroup stays at 1024 threads, one per CU
 	bool dense_small = false;
-	if (!getenv("RG_XOR_R")) {
-		while (rmax > 12 && B > rmax && (double)keys / (double)(1ull << (B - rmax)) > 0.85 * 1024 * XOR_SPER) {
-			rmax--;
-			dense_small = true;
-		}
+	while (rmax > 12 && B > rmax && (double)keys / (double)(1ull << (B - rmax)) > 0.85 * 1024 * XOR_SPER) {
+		rmax--;
+		dense_small = true;
 	}
 	const int R = std::min(B, rmax);
 	const int PB = B - R;  // partition bits
@@ -2556,7 +2580,7 @@ static int bloom_xor(rg_handle *h, Table &T, uint64_t m_bits, uint64_t keys, boo
 	for (int i = 0; i < 8; ++i)
 		for (int j = i + 1; j < 8; ++j)
 			if ((MAGIC[i] & m_mask) == (MAGIC[j] & m_mask)) distinct_bits = false;
-	const bool sparse = rmax == 14 && keys / P <= 512 && !getenv("RG_XOR_DENSE");
+	const bool sparse = rmax == 14 && keys / P <= 512 && !(h->dbg & 0x20000000u);  // rg_debug_set bit 29: the dense kernel on a sparse filter (tests)
 	if (!sparse && dense_small) {
 		ProfScope ps(h, "k_xor_region");
 		if (rmax == 13)
@@ -2974,7 +2998,8 @@ int rg_destroy(rg_handle *h) {
 	if (h->h_counters) (void)hipHostFree(h->h_counters);
 	if (h->d_owner) pool_free(h->cfg.device, h->d_owner);
 	if (h->d_purge_origin) pool_free(h->cfg.device, h->d_purge_origin);
-	if (h->d_marker_origin) pool_free(h->cfg.device, h->d_marker_origin);
+	if (h->d_marker_qidx) pool_free(h->cfg.device, h->d_marker_qidx);
+	if (h->d_marker_kprefix) pool_free(h->cfg.device, h->d_marker_kprefix);
 	if (h->rec_buf) pool_free(h->cfg.device, h->rec_buf);
 	if (h->pending_log) pool_free(h->cfg.device, h->pending_log);
 	if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -3340,6 +3365,12 @@ int rg_adopt_entries(rg_handle *h, void *d_entries, uint64_t n_entries) {
 	// in place only where rg_merge_entries would keep a copy as the log: first and only delivery, every entry a distinct key
 	bool in_place = n_entries > 0 && !h->tab.slots && !h->pending_log && !h->merge_started && n_entries < (1ull << 32) && !(h->dbg & 0x80000) &&
 	                (h->cfg.size > 1 || h->local.slots || h->phase == PH_MERGING);
+	if (in_place) {  // entries of the entry route carry no mark: one look at the first spares them a pass over the buffer
+		Slot first;
+		HIP_TRY(h, hipMemcpyAsync(&first, d_entries, sizeof(Slot), hipMemcpyDeviceToHost, h->stream));
+		HIP_TRY(h, hipStreamSynchronize(h->stream));
+		in_place = (first.meta & LOG_UNIQUE) != 0;
+	}
 	if (in_place) {
 		hipError_t e = hipMemsetAsync(h->d_counters + C_ADOPT_BAD, 0, sizeof(unsigned long long), h->stream);
 		if (e == hipSuccess) {
@@ -3823,7 +3854,7 @@ int rg_add_reads_text(rg_handle *h, const char *text, uint64_t text_bytes, const
 	unsigned long long total = 0;
 	if (e == hipSuccess) {
 		ProfScope ps(h, "k_trim_reads");
-		hipLaunchKernelGGL(k_trim_reads, dim3(grid_for(n_reads)), dim3(BLOCK), 0, h->stream, d_text, d_starts, d_raw, n_reads, d_tstart, d_tlen, d_nbytes);
+		hipLaunchKernelGGL(k_trim_reads, dim3(grid_for(n_reads)), dim3(BLOCK), 0, h->stream, d_text, d_starts, d_raw, n_reads, d_tstart, d_tlen, d_nbytes, text_bytes);
 		hipLaunchKernelGGL(k_scan_local, dim3(nblk), dim3(256), 0, h->stream, d_nbytes, d_off, n_reads, d_sums);
 		hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(64), 0, h->stream, d_sums, nblk, d_sums + nblk);
 		hipLaunchKernelGGL(k_scan_add, dim3(nblk), dim3(256), 0, h->stream, d_off, n_reads, d_sums, d_sums + nblk, (unsigned long long *)nullptr);
@@ -3874,10 +3905,16 @@ int rg_pack_reads_noalloc(rg_handle *h, const char *d_text, uint64_t text_bytes,
 		            (unsigned long long)NOALLOC_MAX_READS);
 	if (!d_byte_offsets) return fail(h, RG_ERR_ARG, "null offsets array");
 	if (n_reads && (!d_text || !d_starts || !d_raw_lengths || !d_lengths || (!d_packed && packed_cap))) return fail(h, RG_ERR_ARG, "null read arrays");
-	(void)text_bytes;  // the device arrays are the caller's: sequence i must lie inside d_text
 	const int dev = h->cfg.device;
 	HIP_TRY(h, hipSetDevice(dev));
 	HIP_TRY(h, noalloc_init(dev));
+	// One scratch array per GPU: a call made while another thread is inside this function, or while the work an earlier
+	// call queued on ANOTHER stream has not finished, is refused instead of racing (same stream: stream order serialises).
+	NoallocGuard guard(dev);
+	if (!guard.ok) return fail(h, RG_ERR_STATE, "rg_pack_reads_noalloc: another call is using this GPU's scratch");
+	if (g_noalloc_last_stream[dev] && g_noalloc_last_stream[dev] != h->stream && hipEventQuery(g_noalloc_done[dev]) == hipErrorNotReady)
+		return fail(h, RG_ERR_STATE, "rg_pack_reads_noalloc: the previous call's work (another stream) still uses this GPU's scratch");
+	(void)hipGetLastError();
 	unsigned long long *base = (unsigned long long *)g_noalloc_ptr[dev];
 	uint64_t *s_tstart = (uint64_t *)base;
 	unsigned long long *s_nbytes = base + NOALLOC_MAX_READS;
@@ -3889,13 +3926,15 @@ int rg_pack_reads_noalloc(rg_handle *h, const char *d_text, uint64_t text_bytes,
 	}
 	const uint32_t nblk = (uint32_t)((n_reads + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK);
 	hipLaunchKernelGGL(k_trim_reads, dim3(grid_for(n_reads)), dim3(BLOCK), 0, h->stream, (const uint8_t *)d_text, d_starts, d_raw_lengths, n_reads, s_tstart,
-	                   d_lengths, s_nbytes);
+	                   d_lengths, s_nbytes, text_bytes);
 	hipLaunchKernelGGL(k_scan_local, dim3(nblk), dim3(256), 0, h->stream, s_nbytes, off, n_reads, s_sums);
 	hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(64), 0, h->stream, s_sums, nblk, s_sums + nblk);
 	hipLaunchKernelGGL(k_scan_add, dim3(nblk), dim3(256), 0, h->stream, off, n_reads, s_sums, s_sums + nblk, (unsigned long long *)nullptr);
 	hipLaunchKernelGGL(k_pack_reads, dim3((unsigned)((n_reads + 63) / 64)), dim3(BLOCK), 0, h->stream, (const uint8_t *)d_text, s_tstart, d_lengths, off, n_reads,
 	                   d_packed, packed_cap);
 	HIP_TRY(h, hipGetLastError());
+	HIP_TRY(h, hipEventRecord(g_noalloc_done[dev], h->stream));  // the event was created at set-up: nothing is allocated here
+	g_noalloc_last_stream[dev] = h->stream;
 	return RG_OK;
 }
 
@@ -4006,21 +4045,68 @@ int rg_check_hashes(rg_handle *h, rg_hash_fn hash1_fn, rg_hash_fn hash2_fn, void
 	return RG_OK;
 }
 
-int rg_markers_query_counts(rg_handle *h, uint64_t *counts) {
+// reads [b.n * part / nparts, b.n * (part + 1) / nparts) of a batch: the slice of rg_records_local_part
+static inline void batch_slice(const ReadBatch &b, uint32_t part, uint32_t nparts, uint64_t *lo, uint64_t *hi) {
+	*lo = (uint64_t)((unsigned __int128)b.n * part / nparts);
+	*hi = (uint64_t)((unsigned __int128)b.n * (part + 1) / nparts);
+}
+
+static void markers_free(rg_handle *h) {
+	if (h->d_marker_qidx) pool_free(h->cfg.device, h->d_marker_qidx);
+	if (h->d_marker_kprefix) pool_free(h->cfg.device, h->d_marker_kprefix);
+	h->d_marker_qidx = nullptr;
+	h->d_marker_kprefix = nullptr;
+	h->marker_counts.clear();
+}
+
+int rg_markers_query_counts_part(rg_handle *h, uint32_t part, uint32_t nparts, uint64_t *counts) {
 	if (!h || !counts) return RG_ERR_ARG;
+	if (nparts == 0 || part >= nparts) return fail(h, RG_ERR_ARG, "part %u of %u", part, nparts);
 	if (h->phase < PH_RESOLVED) return fail(h, RG_ERR_STATE, "rg_markers_query_counts needs the k-mer count first");
-	HIP_TRY(h, hipSetDevice(h->cfg.device));
+	const int dev = h->cfg.device;
+	HIP_TRY(h, hipSetDevice(dev));
 	const uint32_t size = (uint32_t)h->cfg.size;
+	markers_free(h);
+	h->marker_part = part;
+	h->marker_nparts = nparts;
+	// k-mers per read of the slice -> exclusive scan: k-mer p of slice read r lives at kprefix[r] + p
+	uint64_t n_slice = 0;
+	for (const ReadBatch &b : h->reads) {
+		uint64_t lo, hi;
+		batch_slice(b, part, nparts, &lo, &hi);
+		n_slice += hi - lo;
+	}
+	h->marker_slice_reads = n_slice;
+	const uint32_t nblk = (uint32_t)((std::max<uint64_t>(1, n_slice) + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK);
+	PoolBlock nk(dev), sums(dev);
+	HIP_TRY(h, nk.alloc(std::max<uint64_t>(1, n_slice) * sizeof(unsigned long long)));
+	HIP_TRY(h, sums.alloc(((size_t)nblk + 1) * sizeof(unsigned long long)));
+	if (pool_alloc(dev, (void **)&h->d_marker_kprefix, (n_slice + 1) * sizeof(unsigned long long)) != hipSuccess) {
+		(void)hipGetLastError();
+		return fail(h, RG_ERR_NOMEM, "rg_markers_query_counts: out of device memory");
+	}
 	HIP_TRY(h, hipMemsetAsync(h->d_owner, 0, sizeof(unsigned long long) * 2 * size, h->stream));
 	uint64_t done = 0;
 	for (const ReadBatch &b : h->reads) {
-		if (b.n == 0) continue;
+		uint64_t lo, hi;
+		batch_slice(b, part, nparts, &lo, &hi);
+		if (hi == lo) continue;
 		ProfScope ps(h, "k_marker_queries");
-		const unsigned grid = (unsigned)std::min<uint64_t>((b.n + 3) / 4, 65536);
-		if (h->W == 1) hipLaunchKernelGGL((k_marker_queries<1, false>), dim3(grid), dim3(256), size * 12, h->stream, b.d_packed, b.d_off, b.d_len, b.n, done, h->cfg.k, size, h->d_owner, (uint64_t *)nullptr, (uint64_t *)nullptr);
-		else hipLaunchKernelGGL((k_marker_queries<2, false>), dim3(grid), dim3(256), size * 12, h->stream, b.d_packed, b.d_off, b.d_len, b.n, done, h->cfg.k, size, h->d_owner, (uint64_t *)nullptr, (uint64_t *)nullptr);
+		const uint64_t n = hi - lo;
+		hipLaunchKernelGGL(k_marker_kmer_counts, dim3(grid_for(n)), dim3(BLOCK), 0, h->stream, b.d_len + lo, n, h->cfg.k, nk.as<unsigned long long>() + done);
+		const unsigned grid = (unsigned)std::min<uint64_t>((n + 3) / 4, 65536);
+		if (h->W == 1) hipLaunchKernelGGL((k_marker_queries<1, false>), dim3(grid), dim3(256), size * 12, h->stream, b.d_packed, b.d_off + lo, b.d_len + lo, n, h->cfg.k, size, h->d_owner, (uint64_t *)nullptr, (const unsigned long long *)nullptr, (uint64_t *)nullptr);
+		else hipLaunchKernelGGL((k_marker_queries<2, false>), dim3(grid), dim3(256), size * 12, h->stream, b.d_packed, b.d_off + lo, b.d_len + lo, n, h->cfg.k, size, h->d_owner, (uint64_t *)nullptr, (const unsigned long long *)nullptr, (uint64_t *)nullptr);
 		HIP_TRY(h, hipGetLastError());
-		done += b.n;
+		done += n;
+	}
+	if (n_slice) {
+		hipLaunchKernelGGL(k_scan_local, dim3(nblk), dim3(256), 0, h->stream, nk.as<unsigned long long>(), h->d_marker_kprefix, n_slice, sums.as<unsigned long long>());
+		hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(64), 0, h->stream, sums.as<unsigned long long>(), nblk, sums.as<unsigned long long>() + nblk);
+		hipLaunchKernelGGL(k_scan_add, dim3(nblk), dim3(256), 0, h->stream, h->d_marker_kprefix, n_slice, sums.as<unsigned long long>(), sums.as<unsigned long long>() + nblk, (unsigned long long *)nullptr);
+		HIP_TRY(h, hipGetLastError());
+	} else {
+		HIP_TRY(h, hipMemsetAsync(h->d_marker_kprefix, 0, sizeof(unsigned long long), h->stream));
 	}
 	std::vector<unsigned long long> tmp(size);
 	HIP_TRY(h, hipMemcpyAsync(tmp.data(), h->d_owner, sizeof(unsigned long long) * size, hipMemcpyDeviceToHost, h->stream));
@@ -4034,17 +4120,19 @@ int rg_markers_query_counts(rg_handle *h, uint64_t *counts) {
 	return RG_OK;
 }
 
+int rg_markers_query_counts(rg_handle *h, uint64_t *counts) { return rg_markers_query_counts_part(h, 0, 1, counts); }
+
 int rg_markers_export_queries(rg_handle *h, void *d_queries, uint64_t cap_queries) {
-	if (!h || !d_queries) return RG_ERR_ARG;
-	if (h->phase < PH_RESOLVED || h->marker_counts.size() != (size_t)h->cfg.size) return fail(h, RG_ERR_STATE, "rg_markers_export_queries needs rg_markers_query_counts first");
+	if (!h || (!d_queries && cap_queries)) return RG_ERR_ARG;
+	if (h->phase < PH_RESOLVED || h->marker_counts.size() != (size_t)h->cfg.size || !h->d_marker_kprefix) return fail(h, RG_ERR_STATE, "rg_markers_export_queries needs rg_markers_query_counts first");
 	if (cap_queries < h->marker_total) return fail(h, RG_ERR_CAPACITY, "query buffer holds %llu keys, %llu needed", (unsigned long long)cap_queries, (unsigned long long)h->marker_total);
 	HIP_TRY(h, hipSetDevice(h->cfg.device));
 	const uint32_t size = (uint32_t)h->cfg.size;
-	if (h->d_marker_origin) {
-		pool_free(h->cfg.device, h->d_marker_origin);
-		h->d_marker_origin = nullptr;
+	if (h->d_marker_qidx) {
+		pool_free(h->cfg.device, h->d_marker_qidx);
+		h->d_marker_qidx = nullptr;
 	}
-	if (pool_alloc(h->cfg.device, (void **)&h->d_marker_origin, sizeof(uint64_t) * std::max<uint64_t>(1, h->marker_total)) != hipSuccess) {
+	if (pool_alloc(h->cfg.device, (void **)&h->d_marker_qidx, sizeof(uint64_t) * std::max<uint64_t>(1, h->marker_total)) != hipSuccess) {
 		(void)hipGetLastError();
 		return fail(h, RG_ERR_NOMEM, "rg_markers_export_queries: out of device memory");
 	}
@@ -4057,13 +4145,16 @@ int rg_markers_export_queries(rg_handle *h, void *d_queries, uint64_t cap_querie
 	HIP_TRY(h, hipMemcpyAsync(h->d_owner + size, cursors.data(), sizeof(unsigned long long) * size, hipMemcpyHostToDevice, h->stream));
 	uint64_t done = 0;
 	for (const ReadBatch &b : h->reads) {
-		if (b.n == 0) continue;
+		uint64_t lo, hi;
+		batch_slice(b, h->marker_part, h->marker_nparts, &lo, &hi);
+		if (hi == lo) continue;
+		const uint64_t n = hi - lo;
 		ProfScope ps(h, "k_marker_queries");
-		const unsigned grid = (unsigned)std::min<uint64_t>((b.n + 3) / 4, 65536);
-		if (h->W == 1) hipLaunchKernelGGL((k_marker_queries<1, true>), dim3(grid), dim3(256), size * 12, h->stream, b.d_packed, b.d_off, b.d_len, b.n, done, h->cfg.k, size, h->d_owner + size, (uint64_t *)d_queries, h->d_marker_origin);
-		else hipLaunchKernelGGL((k_marker_queries<2, true>), dim3(grid), dim3(256), size * 12, h->stream, b.d_packed, b.d_off, b.d_len, b.n, done, h->cfg.k, size, h->d_owner + size, (uint64_t *)d_queries, h->d_marker_origin);
+		const unsigned grid = (unsigned)std::min<uint64_t>((n + 3) / 4, 65536);
+		if (h->W == 1) hipLaunchKernelGGL((k_marker_queries<1, true>), dim3(grid), dim3(256), size * 12, h->stream, b.d_packed, b.d_off + lo, b.d_len + lo, n, h->cfg.k, size, h->d_owner + size, (uint64_t *)d_queries, h->d_marker_kprefix + done, h->d_marker_qidx);
+		else hipLaunchKernelGGL((k_marker_queries<2, true>), dim3(grid), dim3(256), size * 12, h->stream, b.d_packed, b.d_off + lo, b.d_len + lo, n, h->cfg.k, size, h->d_owner + size, (uint64_t *)d_queries, h->d_marker_kprefix + done, h->d_marker_qidx);
 		HIP_TRY(h, hipGetLastError());
-		done += b.n;
+		done += n;
 	}
 	HIP_TRY(h, hipStreamSynchronize(h->stream));
 	return RG_OK;
@@ -4086,38 +4177,28 @@ int rg_markers_answer(rg_handle *h, const void *d_queries, uint64_t n, uint32_t 
 
 int rg_markers_apply(rg_handle *h, const uint32_t *d_coverage, uint64_t n, int32_t *d_forward, int32_t *d_reverse) {
 	if (!h || (n && !d_coverage) || ((!d_forward || !d_reverse) && h->n_reads)) return RG_ERR_ARG;
-	if (!h->d_marker_origin) return fail(h, RG_ERR_STATE, "rg_markers_apply needs rg_markers_export_queries first");
+	if (!h->d_marker_qidx || !h->d_marker_kprefix) return fail(h, RG_ERR_STATE, "rg_markers_apply needs rg_markers_export_queries first");
 	if (n != h->marker_total) return fail(h, RG_ERR_ARG, "rg_markers_apply: %llu answers for %llu queries", (unsigned long long)n, (unsigned long long)h->marker_total);
 	const int dev = h->cfg.device;
 	HIP_TRY(h, hipSetDevice(dev));
-	uint64_t maxn = 1;
-	for (const ReadBatch &b : h->reads)
-		if (b.maxlen >= (uint32_t)h->cfg.k) maxn = std::max<uint64_t>(maxn, (uint64_t)b.maxlen - h->cfg.k + 1);
-	uint32_t *cov2d = nullptr;
-	if (pool_alloc(dev, (void **)&cov2d, std::max<uint64_t>(1, h->n_reads) * maxn * sizeof(uint32_t)) != hipSuccess) {
-		(void)hipGetLastError();
-		return fail(h, RG_ERR_NOMEM, "rg_markers_apply: out of device memory");
-	}
 	hipError_t e = hipSuccess;
-	if (n) {
-		ProfScope ps(h, "k_marker_place");
-		hipLaunchKernelGGL(k_marker_place, dim3(grid_for(n)), dim3(BLOCK), 0, h->stream, h->d_marker_origin, d_coverage, n, cov2d, maxn);
-		e = hipGetLastError();
-	}
-	uint64_t done = 0;
+	uint64_t done = 0, before = 0;  // reads of the slice done; reads of the batches before this one
 	for (const ReadBatch &b : h->reads) {
-		if (b.n == 0 || e != hipSuccess) continue;
-		ProfScope ps(h, "k_markers_from_coverage");
-		const unsigned grid = (unsigned)std::min<uint64_t>((b.n + 3) / 4, 65536);
-		hipLaunchKernelGGL(k_markers_from_coverage, dim3(grid), dim3(256), 0, h->stream, b.d_len, b.n, done, h->cfg.k, cov2d, maxn, d_forward + done, d_reverse + done);
-		e = hipGetLastError();
-		done += b.n;
+		uint64_t lo, hi;
+		batch_slice(b, h->marker_part, h->marker_nparts, &lo, &hi);
+		if (hi > lo && e == hipSuccess) {
+			ProfScope ps(h, "k_markers_from_coverage");
+			const uint64_t nr = hi - lo;
+			const unsigned grid = (unsigned)std::min<uint64_t>((nr + 3) / 4, 65536);
+			hipLaunchKernelGGL(k_markers_from_coverage, dim3(grid), dim3(256), 0, h->stream, b.d_len + lo, nr, h->cfg.k, d_coverage, h->d_marker_kprefix + done,
+			                   h->d_marker_qidx, d_forward + before + lo, d_reverse + before + lo);
+			e = hipGetLastError();
+			done += nr;
+		}
+		before += b.n;
 	}
 	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-	pool_free(dev, cov2d);
-	pool_free(dev, h->d_marker_origin);
-	h->d_marker_origin = nullptr;
-	h->marker_counts.clear();
+	markers_free(h);
 	if (e != hipSuccess) return fail(h, RG_ERR_HIP, "rg_markers_apply: %s", hipGetErrorString(e));
 	return RG_OK;
 }

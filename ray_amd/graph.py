@@ -86,6 +86,31 @@ def write_coverage_checkpoint(coverage, count, path):
         raise RayGraphError(rc, "cannot write %s" % path)
 
 
+def write_coverage_analysis(coverage, count, k, minimum, peak, repeat, distribution_file, path):
+    """<prefix>CoverageDistributionAnalysis.txt (MachineHelper.cpp:283-327)"""
+    cov = np.ascontiguousarray(coverage, dtype=np.uint32)
+    cnt = np.ascontiguousarray(count, dtype=np.uint64)
+    rc = _lib.load().rg_write_coverage_analysis(cov.ctypes.data_as(C.POINTER(C.c_uint32)), cnt.ctypes.data_as(C.POINTER(C.c_uint64)), len(cov),
+                                                k, minimum, peak, repeat, os.fsencode(distribution_file), os.fsencode(path))
+    if rc:
+        raise RayGraphError(rc, "cannot write %s" % path)
+
+
+def read_genome_graph(path, k, kmer_words=0):
+    """Rank<r>.Checkpoint.GenomeGraph.ray -> Vertex::dump records, as the reference's reader builds its GridTable
+    (MessageProcessor.cpp:596-655); raises when the reader's assertions would fail"""
+    W = kmer_words if kmer_words else (1 if k <= 31 else 2)
+    n = C.c_uint64()
+    rc = _lib.load().rg_read_genome_graph(os.fsencode(path), k, W, None, 0, C.byref(n))
+    if rc:
+        raise RayGraphError(rc, "cannot read %s" % path)
+    buf = np.zeros(max(1, n.value), dtype=record_dtype(W))
+    rc = _lib.load().rg_read_genome_graph(os.fsencode(path), k, W, buf.ctypes.data, n.value, C.byref(n))
+    if rc:
+        raise RayGraphError(rc, "%s is not a consistent GenomeGraph checkpoint" % path)
+    return buf[: n.value]
+
+
 def write_graph_partition(sizes, path):
     """<prefix>GraphPartition.txt (EdgePurger.cpp:172-217); sizes[r] = GridTable size of rank r"""
     a = (C.c_uint64 * len(sizes))(*[int(x) for x in sizes])
@@ -296,9 +321,10 @@ class GraphBuilder:
         return h1, h2
 
     # -- markers across ranks (exchange.read_markers_distributed drives these)
-    def markers_query_counts(self):
+    def markers_query_counts(self, part=0, nparts=1):
+        """k-mers of the reads' slice `part` of `nparts` per owner rank (the slices of records_local)"""
         out = (C.c_uint64 * self.size)()
-        self._check(self._L.rg_markers_query_counts(self._h, out))
+        self._check(self._L.rg_markers_query_counts_part(self._h, part, nparts, out))
         return [int(x) for x in out]
 
     def markers_export_queries(self, device_ptr, capacity_queries):

@@ -140,3 +140,34 @@ def make_reads_torch(genome, read_len, n_reads, seed, error=0.0, device="cuda", 
     offsets = torch.arange(n_reads, device=device, dtype=torch.int64) * bpr
     lengths = torch.full((n_reads,), read_len, dtype=torch.int32, device=device)
     return packed, offsets, lengths
+
+
+_synth_lib = None
+
+
+def make_reads_device(genome, read_len, n_reads, seed, error=0.0, first=0, device="cuda"):
+    """The counter-based generator (tools/rg_synth.hip; its host twin is oracle/ro_synth.c): reads first .. first+n_reads-1,
+    made in HBM, bit for bit the reads the oracle is run on -- every value is a pure function of (seed, index).
+    -> (packed u8 tensor padded by 32 bytes, offsets int64 tensor, lengths int32 tensor), as make_reads_torch"""
+    import ctypes as C
+    import os
+    import torch
+    global _synth_lib
+    if _synth_lib is None:
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "librg_synth.so")
+        if not os.path.exists(path):
+            raise ImportError("%s is missing: build it with `make -C tools` (or __graft_entry__.build())" % path)
+        _synth_lib = C.CDLL(path)
+        _synth_lib.rgs_generate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64,
+                                            C.c_double, C.c_void_p]
+        _synth_lib.rgs_generate.restype = C.c_int
+    bpr = (read_len + 3) // 4
+    packed = torch.zeros(n_reads * bpr + 32, dtype=torch.uint8, device=device)
+    offsets = torch.empty(max(1, n_reads), dtype=torch.int64, device=device)
+    lengths = torch.empty(max(1, n_reads), dtype=torch.int32, device=device)
+    torch.cuda.synchronize()
+    with torch.cuda.device(packed.device):
+        rc = _synth_lib.rgs_generate(packed.data_ptr(), offsets.data_ptr(), lengths.data_ptr(), n_reads, first, genome, read_len, seed, error, None)
+    if rc != 0:
+        raise RuntimeError("rgs_generate failed (%d)" % rc)
+    return packed, offsets[:n_reads], lengths[:n_reads]

@@ -97,3 +97,96 @@ def test_sequence_file_counts(tmp_path):
     assert ray_amd.count_sequences(str(fa)) == 3 and ray_amd.count_sequences(str(fq)) == 2
     with pytest.raises(ray_amd.RayGraphError):
         ray_amd.count_sequences(str(tmp_path / "x.sff"))
+
+
+@pytest.mark.parametrize("k,W", [(21, 1), (31, 2), (63, 2)])
+def test_genome_graph_checkpoint_round_trip(oracle, tmp_path, k, W):
+    """the written checkpoint through two readers: the oracle's restatement of the reference's reader
+    (MessageProcessor.cpp:596-655, with its parents / children / size assertions :633-641,650) rebuilds the graph it was
+    written from, and the product's reader (rg_read_genome_graph) returns the same records"""
+    import ray_amd
+    packed, offsets, lengths = make_reads_numpy(genome=4000, read_len=90, n_reads=900, seed=50 + k, error=0.02)
+    g = oracle.Graph(k, nranks=1, bloom_bits=40000, W=W)
+    g.set_reads(packed, offsets, lengths)
+    g.count_kmers()
+    g.add_edges()
+    g.purge_edges()
+    rec = g.export()
+    path = str(tmp_path / "Rank0.Checkpoint.GenomeGraph.ray")
+    ray_amd.write_genome_graph(rec, k, path)
+    # the reference's reader, restated
+    g2 = oracle.Graph(k, nranks=1, bloom_bits=0, W=W)
+    assert g2.read_genome_graph(path) == 0, "the reader's assertions (MessageProcessor.cpp:633-641,650) fail on the written file"
+    back = g2.export()
+    assert g2.size() == g.size() and back.tobytes() == rec.tobytes()
+    # the product's reader: same records, in file order (the writer's = sorted here)
+    got = ray_amd.read_genome_graph(path, k, W)
+    assert got.tobytes() == rec.tobytes()
+    # entries in another order, reverse-complement strand first: the reference takes the coverage from the entry that
+    # creates the vertex only when that entry is the lower key (Vertex::setCoverage, Vertex.cpp:80-92) -- both readers agree
+    entries = read_genome_graph(path, W)
+    swapped = str(tmp_path / "swapped.ray")
+    with open(swapped, "wb") as f:
+        f.write(struct.pack("<Q", len(entries)))
+        order = list(range(0, len(entries), 2))[::-1]
+        for i in order:
+            for key, cov, parents, children in (entries[i + 1], entries[i]) if i % 4 == 0 else (entries[i], entries[i + 1]):
+                f.write(struct.pack("<%dQ" % W, *key) + struct.pack("<ii", cov, len(parents)))
+                for nb in parents:
+                    f.write(struct.pack("<%dQ" % W, *nb))
+                f.write(struct.pack("<i", len(children)))
+                for nb in children:
+                    f.write(struct.pack("<%dQ" % W, *nb))
+    g3 = oracle.Graph(k, nranks=1, bloom_bits=0, W=W)
+    assert g3.read_genome_graph(swapped) == 0
+    want3 = g3.export()
+    got3 = ray_amd.read_genome_graph(swapped, k, W)
+    got3 = got3[np.lexsort(tuple(got3["key"][:, j] for j in reversed(range(W))))]
+    assert got3.tobytes() == want3.tobytes()
+    assert (want3["coverage"] == 0).sum() > 0 and (want3["coverage"] > 0).sum() > 0   # both cases occurred
+    assert np.array_equal(want3["edges"], rec["edges"])
+    # a corrupted file: a parent that is not a neighbour, a wrong count
+    data = bytearray(open(path, "rb").read())
+    first_with_parent = next(i for i, e in enumerate(entries) if e[2])
+    pos = 8
+    for e in entries[:first_with_parent]:
+        pos += 8 * W + 8 + 8 * W * len(e[2]) + 4 + 8 * W * len(e[3])
+    pos += 8 * W + 8     # first parent of that entry
+    data[pos + 1] ^= 0x40
+    bad = str(tmp_path / "bad.ray")
+    open(bad, "wb").write(bytes(data))
+    with pytest.raises(ray_amd.RayGraphError):
+        ray_amd.read_genome_graph(bad, k, W)
+    data = bytearray(open(path, "rb").read())
+    data[0:8] = struct.pack("<Q", len(entries) + 2)
+    open(bad, "wb").write(bytes(data))
+    with pytest.raises(ray_amd.RayGraphError):
+        ray_amd.read_genome_graph(bad, k, W)
+
+
+def test_coverage_distribution_analysis_file(oracle, tmp_path):
+    """CoverageDistributionAnalysis.txt (MachineHelper.cpp:283-327): the product's writer against the oracle's, byte for byte"""
+    import ray_amd
+    rng = np.random.default_rng(7)
+    cases = []
+    packed, offsets, lengths = make_reads_numpy(genome=20000, read_len=100, n_reads=8000, seed=3, error=0.01)
+    g = oracle.Graph(31, nranks=1)
+    g.set_reads(packed, offsets, lengths)
+    g.count_kmers()
+    cases.append(g.histogram())
+    for _ in range(30):
+        n = int(rng.integers(1, 300))
+        cov = np.sort(rng.choice(np.arange(1, 20000), size=n, replace=False)).astype(np.uint32)
+        cnt = (rng.integers(1, 1 << int(rng.integers(2, 40)), size=n) * 2).astype(np.uint64)
+        cases.append((cov, cnt))
+    cases.append((np.array([12000, 13000], dtype=np.uint32), np.array([2, 4], dtype=np.uint64)))   # nothing below the loop's 9999
+    for i, (cov, cnt) in enumerate(cases):
+        mn, pk, rp = oracle.coverage_distribution(cov, cnt)
+        assert ray_amd.coverage_distribution(cov, cnt) == (mn, pk, rp)
+        a, b = str(tmp_path / "a.txt"), str(tmp_path / "b.txt")
+        oracle.write_coverage_analysis(cov, cnt, 31, mn, pk, rp, "RayOutput/CoverageDistribution.txt", a)
+        ray_amd.write_coverage_analysis(cov, cnt, 31, mn, pk, rp, "RayOutput/CoverageDistribution.txt", b)
+        assert open(a, "rb").read() == open(b, "rb").read(), "case %d" % i
+    text = open(b).read().splitlines()
+    assert text[0] == "k-mer length:\t31" and text[2] == "Lowest coverage observed:\t9999" and text[-1] == "DistributionFile: RayOutput/CoverageDistribution.txt"
+    assert text[7] == "Percentage of vertices with coverage 9999:\t0 %"

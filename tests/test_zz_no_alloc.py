@@ -39,9 +39,11 @@ def _no_alloc(b, text, starts, lens, cap_reads, out):
     d_lens = torch.from_numpy(lens.astype(np.int32)).cuda()
     torch.cuda.synchronize()
     d_packed, d_off, d_len = out
+    free_before = torch.cuda.mem_get_info()[0]        # hipMemGetInfo: what the driver has left on the device
     b.pack_reads_noalloc(d_text.data_ptr(), len(text), d_starts.data_ptr(), d_lens.data_ptr(), n, d_packed.data_ptr(),
                          d_packed.numel(), d_off.data_ptr(), d_len.data_ptr())
     torch.cuda.synchronize()                          # the builder runs on its own stream
+    assert torch.cuda.mem_get_info()[0] == free_before, "rg_pack_reads_noalloc changed the device's free memory"
     h_off = d_off.cpu().numpy().astype(np.uint64)
     total = int(h_off[n])
     return d_packed.cpu().numpy()[:total], h_off[:n], d_len.cpu().numpy().astype(np.uint32)[:n], total
@@ -81,6 +83,22 @@ def test_no_alloc_ingest_matches_add_reads_text_twice():
         h = d_packed.cpu().numpy()
         assert int(d_off[len(lens)].item()) == len(want_p)
         assert np.array_equal(h[:cut], want_p[:cut]) and (h[cut:cut + 64] == 0xEE).all()
+        # a start or a length that leaves the text (the arrays are device memory, so the check is the kernel's): read as an
+        # empty sequence, nothing outside the text is touched; the others are unaffected
+        bad_starts, bad_lens = starts.copy(), lens.copy()
+        victims = [i for i in range(5, len(lens), 97) if lens[i] > 0][:6]
+        bad_starts[victims[0]] = len(text) + 12345            # start beyond the text
+        bad_starts[victims[1]] = (1 << 62)                    # absurd start
+        bad_lens[victims[2]] = 70000                          # longer than a Read can store
+        bad_starts[victims[3]] = len(text) - 3                # starts inside, ends outside
+        bad_lens[victims[3]] = 50
+        fixed_lens = lens.copy()
+        fixed_lens[victims[:4]] = 0
+        want_p, want_o, want_l = _existing_entry_point(text, starts, fixed_lens)
+        d_packed.fill_(0xEE)
+        got_p, got_o, got_l, total = _no_alloc(b, text, bad_starts, bad_lens, cap_reads, (d_packed, d_off, d_len))
+        assert total == len(want_p) and np.array_equal(got_l, want_l) and np.array_equal(got_o, want_o) and np.array_equal(got_p, want_p)
+        assert (got_l[victims[:4]] == 0).all()
         # beyond the scratch's stated maximum: a clear error, nothing queued
         with pytest.raises(ray_amd.RayGraphError) as e:
             b.pack_reads_noalloc(0, 0, 0, 0, RG_NOALLOC_MAX_READS + 1, 0, 0, d_off.data_ptr(), 0)
