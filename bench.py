@@ -133,9 +133,13 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
+    comm = None   # rg_comm: the exchanges inside the library, RCCL over xGMI (RAYGRAPH_BENCH_EXCHANGE=torch: driven from Python instead)
     if world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device(dev))
+            if os.environ.get("RAYGRAPH_BENCH_EXCHANGE", "library") != "torch":
+                from ray_amd.exchange import create_comm
+                comm = create_comm(rank, world, local_rank)
         else:
             dist.init_process_group(backend)
 
@@ -234,6 +238,10 @@ def main():
                 b.resolve_admission()
             else:
                 b.count_kmers()                  # RAY_SLAVE_MODE_ADD_VERTICES
+        elif comm is not None:
+            # records: super-k-mer records to the rank that aggregates their bucket, then the aggregated entries to the rank
+            # vertexRank names; entries: every rank aggregates its own reads first.  One call, all inside the library.
+            b.count_kmers_exchange(comm, route=route, parts=args.parts, local_reads=n_reads)
         else:
             if route == "records":
                 exchange_records(b, device=dev, parts=args.parts)  # super-k-mer records to the rank that aggregates their bucket
@@ -246,9 +254,12 @@ def main():
         if profile:          # every call above returns with its stream drained, so wall time per call is the phase's time
             phase("K-mer counting", tp)
         tp = time.perf_counter()
-        cov, cnt = b.histogram()                 # RAY_SLAVE_MODE_SEND_DISTRIBUTION
-        if world > 1:
-            cov, cnt = reduce_histogram(cov, cnt, device=dev, size=world)
+        if comm is not None:
+            cov, cnt = b.histogram_exchange(comm)    # RAY_SLAVE_MODE_SEND_DISTRIBUTION, merged on every rank
+        else:
+            cov, cnt = b.histogram()                 # RAY_SLAVE_MODE_SEND_DISTRIBUTION
+            if world > 1:
+                cov, cnt = reduce_histogram(cov, cnt, device=dev, size=world)
         mark("histogram")
         if profile:
             phase("Coverage distribution analysis", tp)
@@ -303,7 +314,10 @@ def main():
         _, _, b = one_step(keep=True)
         barrier()
         tp = time.perf_counter()
-        purge_edges_distributed(b, device=dev)
+        if comm is not None:
+            b.purge_edges_exchange(comm)
+        else:
+            purge_edges_distributed(b, device=dev)
         torch.cuda.synchronize()
         after["Null edge purging"] = (time.perf_counter() - tp) * 1e3
         if world == 1 and emu == 1:

@@ -28,6 +28,7 @@ extern "C" {
 #define RG_ERR_STATE (-4)    /* call made in the wrong phase */
 #define RG_ERR_CAPACITY (-5) /* caller buffer too small / internal limit hit */
 #define RG_ERR_HASH (-6)     /* rg_check_hashes: the library's k-mer hashes are not the caller's */
+#define RG_ERR_COMM (-7)     /* a collective between ranks failed (RCCL, or the caller's transport); rg_last_error() has the text */
 
 /* bloom_bits: size the filter like VerticesExtractor::getDefaultNumberOfBitsForBloomFilter
  * (VerticesExtractor/VerticesExtractor.cpp:276-320): 16*k*localReads capped at 2^33 */
@@ -181,6 +182,72 @@ int rg_purge_query_counts(rg_handle *h, uint64_t *counts);
 int rg_purge_export_queries(rg_handle *h, void *d_queries, uint64_t cap_queries);
 int rg_purge_answer(rg_handle *h, const void *d_queries, uint64_t n, uint8_t *d_answers);
 int rg_purge_apply(rg_handle *h, const uint8_t *d_answers, uint64_t n);
+
+/* ---- multi-GPU exchange: one rank per GPU, the all-to-all(v) between them ------------------------------------------
+ * Replaces RayPlatform's per-message MPI point-to-point traffic for this path -- RAY_MPI_TAG_VERTICES_DATA (sender
+ * KmerAcademyBuilder.cpp:187-196, receiver MessageProcessor.cpp:692-809), OUT_/IN_EDGES_DATA (VerticesExtractor.cpp:175-251),
+ * REQUEST_VERTEX_COVERAGE (EdgePurgerWorker.cpp:38-47, IndexerWorker.cpp:76-96, served by MessageProcessor.cpp:1224-1256),
+ * COVERAGE_DATA (CoverageGatherer.cpp:164-181 -> MessageProcessor.cpp:1048-1061) -- by a few all-to-all(v) per pass.  The
+ * rg_*_exchange entry points below drive the step-wise entry points above (counts, export, answer, apply ...) and move what
+ * they export through a communicator:
+ *   rg_comm_create_rccl       RCCL over xGMI (librccl.so.1 is opened at run time; nothing links against it).  Rank 0 calls
+ *                             rg_comm_unique_id and sends the RG_COMM_ID_BYTES it returns to the other ranks -- one Ray
+ *                             message, a pipe, a file --; then EVERY rank calls rg_comm_create_rccl(id, rank, size, device)
+ *                             (a collective: it returns when all ranks have joined).  One rank per GPU.
+ *   rg_comm_create_transport  the caller's own collectives, e.g. MPI_Alltoall / MPI_Alltoallv of the GPU-aware MPI Ray
+ *                             already runs on: alltoall_u64 moves n words per rank between HOST arrays (send[r*n ..] goes to
+ *                             rank r, recv[r*n ..] comes from it); alltoallv moves send_counts[r] items of unit_bytes to rank
+ *                             r out of d_send (grouped in rank order) and recv_counts[r] items from rank r into d_recv, both
+ *                             DEVICE memory, and returns when d_recv is complete.  Both return 0 on success.
+ * A communicator belongs to one rank of one job, outlives the handles it is used with (create it once per Ray run) and may
+ * be NULL when size == 1 (everything then stays on the device).  One host thread per communicator.  Errors of a
+ * collective are RG_ERR_COMM with the text in rg_last_error(h). */
+typedef struct rg_comm rg_comm;
+#define RG_COMM_ID_BYTES 256
+typedef struct rg_transport {
+	void *user;
+	int (*alltoall_u64)(void *user, const uint64_t *send, uint64_t *recv, uint32_t n_per_rank);
+	int (*alltoallv)(void *user, const void *d_send, const uint64_t *send_counts, void *d_recv, const uint64_t *recv_counts,
+	                 uint32_t unit_bytes);
+} rg_transport;
+int rg_comm_unique_id(void *id_out /* RG_COMM_ID_BYTES */);
+int rg_comm_create_rccl(const void *id, int rank, int size, int device, rg_comm **out);
+int rg_comm_create_transport(const rg_transport *t, int rank, int size, int device, rg_comm **out);
+int rg_comm_destroy(rg_comm *c);
+/* text of the communicator's last error; c may be NULL for failures of rg_comm_unique_id / rg_comm_create_* */
+const char *rg_comm_last_error(const rg_comm *c);
+/* payload bytes this rank sent to / received from OTHER ranks, payload collectives issued, seconds the host waited for them */
+typedef struct rg_comm_stats {
+	uint64_t bytes_sent, bytes_received, collectives;
+	double wait_seconds;
+} rg_comm_stats;
+int rg_comm_get_stats(rg_comm *c, rg_comm_stats *out);
+
+/* RAY_SLAVE_MODE_ADD_VERTICES across ranks (KmerAcademyBuilder.cpp:43-211 + MessageProcessor.cpp:692-809):
+ *   rg_exchange_records        record route, first exchange: rg_records_local_part / rg_record_counts / rg_export_records per
+ *                              slice of the reads, all-to-all(v) of the records (the transfer of slice p runs while the
+ *                              kernels of slice p + 1 produce theirs; parts = 0 -> 1), then rg_count_records on what arrived
+ *   rg_exchange_owner_buckets  both routes: rg_owner_counts / rg_export_owner_buckets / rg_release_local, all-to-all(v) of the
+ *                              32-byte entries to the ranks vertexRank names, ONE rg_adopt_entries of everything received
+ *                              (admitted in the receive buffer, which the library owns).  Call rg_resolve_admission next.
+ *   rg_count_kmers_exchange    the whole pass: RG_ROUTE_RECORDS = rg_exchange_records, RG_ROUTE_ENTRIES = rg_count_local; then
+ *                              rg_exchange_owner_buckets and rg_resolve_admission(local_reads_for_bloom).  Which route:
+ *                              entries when one rank's reads cover a k-mer ~16 times or more (2 ranks), records otherwise.
+ * RAY_SLAVE_MODE_SEND_DISTRIBUTION: rg_histogram_exchange = rg_histogram of every rank merged as rank 0 merges
+ *   RAY_MPI_TAG_COVERAGE_DATA (MessageProcessor.cpp:1048-1061), on every rank (same calling convention as rg_histogram).
+ * RAY_SLAVE_MODE_PURGE_NULL_EDGES: rg_purge_edges_exchange = rg_purge_query_counts .. rg_purge_apply with the two all-to-all(v).
+ * SequencesIndexer: rg_read_markers_exchange = rg_markers_query_counts_part .. rg_markers_apply per slice of the reads
+ *   (parts = 0 -> 1) with the two all-to-all(v); d_forward / d_reverse as rg_read_markers.
+ * rg_allgather_u64: one word from every rank into out[size] (GridTable sizes for GraphPartition.txt, EdgePurger.cpp:172-217). */
+#define RG_ROUTE_RECORDS 1
+#define RG_ROUTE_ENTRIES 2
+int rg_exchange_records(rg_handle *h, rg_comm *c, uint32_t parts);
+int rg_exchange_owner_buckets(rg_handle *h, rg_comm *c);
+int rg_count_kmers_exchange(rg_handle *h, rg_comm *c, int route, uint32_t parts, uint64_t local_reads_for_bloom);
+int rg_histogram_exchange(rg_handle *h, rg_comm *c, uint32_t *coverage, uint64_t *count, uint64_t cap, uint64_t *n);
+int rg_purge_edges_exchange(rg_handle *h, rg_comm *c);
+int rg_read_markers_exchange(rg_handle *h, rg_comm *c, uint32_t parts, int32_t *d_forward, int32_t *d_reverse);
+int rg_allgather_u64(rg_handle *h, rg_comm *c, uint64_t value, uint64_t *out);
 
 /* ---- the store: GridTable / Vertex ---------------------------------------------------------- */
 /* GridTable::size (GridTable.cpp:80-82): 2 per stored pair */

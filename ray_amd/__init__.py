@@ -7,10 +7,10 @@ from . import _lib
 
 _lib.load()
 
-from .graph import (GraphBuilder, RayGraphError, count_sequences, coverage_distribution, pack_read, pack_reads,  # noqa: E402
+from .graph import (Comm, GraphBuilder, RayGraphError, count_sequences, coverage_distribution, pack_read, pack_reads,  # noqa: E402
                     read_genome_graph, write_coverage_analysis, write_coverage_checkpoint, write_genome_graph,
                     write_graph_partition)
 
-__all__ = ["GraphBuilder", "RayGraphError", "coverage_distribution", "pack_read", "pack_reads", "count_sequences",
+__all__ = ["GraphBuilder", "Comm", "RayGraphError", "coverage_distribution", "pack_read", "pack_reads", "count_sequences",
            "write_coverage_checkpoint", "write_genome_graph", "write_graph_partition", "write_coverage_analysis",
            "read_genome_graph"]

@@ -10,7 +10,19 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libraygraph.so")
 
 RG_OK = 0
-RG_ERR_ARG, RG_ERR_HIP, RG_ERR_NOMEM, RG_ERR_STATE, RG_ERR_CAPACITY, RG_ERR_HASH = -1, -2, -3, -4, -5, -6
+RG_ERR_ARG, RG_ERR_HIP, RG_ERR_NOMEM, RG_ERR_STATE, RG_ERR_CAPACITY, RG_ERR_HASH, RG_ERR_COMM = -1, -2, -3, -4, -5, -6, -7
+RG_COMM_ID_BYTES = 256
+RG_ROUTE_RECORDS, RG_ROUTE_ENTRIES = 1, 2
+ALLTOALL_U64_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_uint32)
+ALLTOALLV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32)
+
+
+class RgTransport(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("alltoall_u64", ALLTOALL_U64_FN), ("alltoallv", ALLTOALLV_FN)]
+
+
+class RgCommStats(C.Structure):
+    _fields_ = [("bytes_sent", C.c_uint64), ("bytes_received", C.c_uint64), ("collectives", C.c_uint64), ("wait_seconds", C.c_double)]
 HASH_FN = C.CFUNCTYPE(C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p)   # rg_hash_fn
 RG_BLOOM_DEFAULT = (1 << 64) - 1
 RG_ENTRY_BYTES = 32
@@ -36,6 +48,9 @@ SYMBOLS = ["rg_create", "rg_destroy", "rg_last_error", "rg_add_reads", "rg_add_r
            "rg_purge_export_queries", "rg_purge_answer", "rg_purge_apply", "rg_size", "rg_export",
            "rg_find", "rg_add_reads_text", "rg_count_sequences", "rg_load_sequences", "rg_get_reads", "rg_pack_reads_noalloc", "rg_release_local", "rg_adopt_entries", "rg_check_hashes", "rg_hash_kmers", "rg_read_markers", "rg_markers_query_counts", "rg_markers_query_counts_part", "rg_markers_export_queries", "rg_markers_answer", "rg_markers_apply",
            "rg_import_vertices", "rg_write_kmers_txt", "rg_write_genome_graph", "rg_write_coverage_checkpoint", "rg_write_graph_partition", "rg_write_coverage_analysis", "rg_read_genome_graph", "rg_degree_distribution", "rg_get_stats", "rg_set_profiling", "rg_debug_set", "rg_get_kernel_profile", "rg_release_cached_memory", "rg_coverage_distribution", "rg_pack_read",
+           "rg_comm_unique_id", "rg_comm_create_rccl", "rg_comm_create_transport", "rg_comm_destroy", "rg_comm_last_error", "rg_comm_get_stats",
+           "rg_exchange_records", "rg_exchange_owner_buckets", "rg_count_kmers_exchange", "rg_histogram_exchange", "rg_purge_edges_exchange",
+           "rg_read_markers_exchange", "rg_allgather_u64",
            "rg_version"]
 
 _lib = None
@@ -117,6 +132,19 @@ def load():
         "rg_get_kernel_profile": ([vp, C.c_char_p, u64], C.c_int),
         "rg_coverage_distribution": ([u32p, u64p, u64, C.c_char_p, i32p, i32p, i32p], C.c_int),
         "rg_pack_read": ([C.c_char_p, C.c_int, u8p], C.c_int),
+        "rg_comm_unique_id": ([vp], C.c_int),
+        "rg_comm_create_rccl": ([vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)], C.c_int),
+        "rg_comm_create_transport": ([C.POINTER(RgTransport), C.c_int, C.c_int, C.c_int, C.POINTER(vp)], C.c_int),
+        "rg_comm_destroy": ([vp], C.c_int),
+        "rg_comm_last_error": ([vp], C.c_char_p),
+        "rg_comm_get_stats": ([vp, C.POINTER(RgCommStats)], C.c_int),
+        "rg_exchange_records": ([vp, vp, C.c_uint32], C.c_int),
+        "rg_exchange_owner_buckets": ([vp, vp], C.c_int),
+        "rg_count_kmers_exchange": ([vp, vp, C.c_int, C.c_uint32, u64], C.c_int),
+        "rg_histogram_exchange": ([vp, vp, u32p, u64p, u64, u64p], C.c_int),
+        "rg_purge_edges_exchange": ([vp, vp], C.c_int),
+        "rg_read_markers_exchange": ([vp, vp, C.c_uint32, vp, vp], C.c_int),
+        "rg_allgather_u64": ([vp, vp, u64, u64p], C.c_int),
         "rg_version": ([], C.c_char_p),
     }
     for name in SYMBOLS:

@@ -2929,6 +2929,34 @@ struct PoolBlock {
 	}
 };
 
+// ---- hooks for rg_comm.cpp (rg_internal.h) ---------------------------------------------------------------------
+#include "rg_internal.h"
+namespace rgi {
+int fail(rg_handle *h, int code, const char *fmt, ...) {
+	char buf[512];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof buf, fmt, ap);
+	va_end(ap);
+	return ::fail(h, code, "%s", buf);
+}
+hipStream_t stream_of(rg_handle *h) { return h->stream; }
+int device_of(const rg_handle *h) { return h->cfg.device; }
+int rank_of(const rg_handle *h) { return h->cfg.rank; }
+int size_of(const rg_handle *h) { return h->cfg.size; }
+int kmer_words_of(const rg_handle *h) { return h->W; }
+uint64_t reads_of(const rg_handle *h) { return h->n_reads; }
+bool has_local(const rg_handle *h) { return h->local.slots != nullptr; }
+hipError_t pool_get(int device, void **p, uint64_t bytes) { return pool_alloc(device, p, bytes); }
+void pool_put(int device, void *p) { pool_free(device, p); }
+int adopt_pool_block(rg_handle *h, void *d_entries, uint64_t n_entries, bool *adopted) {
+	*adopted = false;
+	const int rc = rg_adopt_entries(h, d_entries, n_entries);
+	if (rc == RG_OK) *adopted = n_entries > 0 && h->pending_log == (Slot *)d_entries;
+	return rc;
+}
+}  // namespace rgi
+
 extern "C" {
 
 const char *rg_version(void) { return "raygraph-mi355x 0.1 (gfx950)"; }

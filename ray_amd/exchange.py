@@ -4,8 +4,14 @@ Replaces RayPlatform's per-message RAY_MPI_TAG_VERTICES_DATA / OUT_EDGES_DATA / 
 point-to-point traffic (KmerAcademyBuilder.cpp:187-196, VerticesExtractor.cpp:175-251) with one
 all-to-all(v) of per-owner buckets: every rank aggregates its own reads per canonical k-mer,
 groups the 32-byte entries by owner = hash1(lower) % size (Kmer.cpp:165-170), and the owners merge
-what they receive.  torch.distributed is plumbing only (backend "nccl" = RCCL over xGMI on the GPU
-box, "gloo" in the CPU tests); the entries are produced and consumed by the HIP library.
+what they receive.
+
+On the GPU box the exchanges run INSIDE the library (rg_comm_* / rg_exchange_*: grouped ncclSend / ncclRecv over xGMI on
+RCCL's own stream, ray_amd/csrc/rg_comm.cpp): `create_comm` makes this rank's communicator -- torch.distributed only carries
+the 256-byte id from rank 0 to the others, as one Ray message would -- and GraphBuilder.count_kmers_exchange /
+histogram_exchange / purge_edges_exchange / read_markers_exchange take it.  The functions below it are the same exchanges
+driven step by step from Python over torch.distributed collectives: the "gloo" route of the CPU tests and of rehearsals
+with more ranks than GPUs (host-staged), where RCCL cannot be used.
 
 `engine` is anything with the GraphBuilder exchange surface: size, owner_counts(),
 export_owner_buckets(ptr, capacity), merge_entries(ptr, n).
@@ -14,6 +20,16 @@ import torch
 import torch.distributed as dist
 
 from ._lib import RG_ENTRY_BYTES
+
+
+def create_comm(rank, size, device_index, group=None):
+    """this rank's rg_comm over RCCL: rank 0 makes the id (rg_comm_unique_id), the process group carries it, every rank
+    joins (rg_comm_create_rccl is a collective)"""
+    from .graph import Comm
+    ids = [Comm.unique_id() if rank == 0 else None]
+    if size > 1:
+        dist.broadcast_object_list(ids, src=0, group=group)
+    return Comm.rccl(ids[0], rank, size, device_index)
 
 
 def partition_reads(total_reads, rank, size):

@@ -119,6 +119,89 @@ def write_graph_partition(sizes, path):
         raise RayGraphError(rc, "cannot write %s" % path)
 
 
+class Comm:
+    """rg_comm: this rank's end of the all-to-all(v) between the ranks of a job (include/raygraph.h, "multi-GPU exchange").
+    Comm.rccl(id, rank, size, device): RCCL over xGMI, `id` = Comm.unique_id() made on rank 0 and sent to the others;
+    Comm.transport(alltoall_u64, alltoallv, rank, size, device): the caller's collectives (callables, see rg_transport)."""
+
+    def __init__(self, handle, keep=None):
+        self._L = _lib.load()
+        self._c = handle
+        self._keep = keep
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(_lib.RG_COMM_ID_BYTES)
+        L = _lib.load()
+        rc = L.rg_comm_unique_id(buf)
+        if rc:
+            raise RayGraphError(rc, L.rg_comm_last_error(None).decode())
+        return buf.raw
+
+    @classmethod
+    def rccl(cls, unique_id, rank, size, device=0):
+        L = _lib.load()
+        c = C.c_void_p()
+        rc = L.rg_comm_create_rccl(C.c_char_p(bytes(unique_id)), rank, size, device, C.byref(c))
+        if rc:
+            raise RayGraphError(rc, L.rg_comm_last_error(None).decode())
+        return cls(c)
+
+    @classmethod
+    def transport(cls, alltoall_u64, alltoallv, rank, size, device=0):
+        """alltoall_u64(send: list of size*n ints, n) -> list of size*n ints; alltoallv(d_send, send_counts, d_recv, recv_counts,
+        unit_bytes) -> None (device pointers as ints, counts as lists)"""
+        L = _lib.load()
+
+        def _a2a(user, send, recv, n):
+            try:
+                got = alltoall_u64([int(send[i]) for i in range(size * n)], n)
+                for i in range(size * n):
+                    recv[i] = int(got[i])
+                return 0
+            except Exception:  # noqa: BLE001  (must not propagate into C)
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        def _a2av(user, d_send, scount, d_recv, rcount, unit):
+            try:
+                alltoallv(d_send or 0, [int(scount[r]) for r in range(size)], d_recv or 0, [int(rcount[r]) for r in range(size)], unit)
+                return 0
+            except Exception:  # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        t = _lib.RgTransport(None, _lib.ALLTOALL_U64_FN(_a2a), _lib.ALLTOALLV_FN(_a2av))
+        c = C.c_void_p()
+        rc = L.rg_comm_create_transport(C.byref(t), rank, size, device, C.byref(c))
+        if rc:
+            raise RayGraphError(rc, L.rg_comm_last_error(None).decode())
+        return cls(c, keep=t)
+
+    def stats(self):
+        s = _lib.RgCommStats()
+        self._L.rg_comm_get_stats(self._c, C.byref(s))
+        return {"bytes_sent": int(s.bytes_sent), "bytes_received": int(s.bytes_received), "collectives": int(s.collectives),
+                "wait_seconds": float(s.wait_seconds)}
+
+    def close(self):
+        if getattr(self, "_c", None):
+            self._L.rg_comm_destroy(self._c)
+            self._c = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _comm_handle(comm):
+    return comm._c if comm is not None else None
+
+
 class GraphBuilder:
     """One rank's share of the distributed de Bruijn graph on one GPU."""
 
@@ -270,6 +353,49 @@ class GraphBuilder:
         self._check(self._L.rg_resolve_admission(self._h, local_reads))
         self._borrowed = None
 
+    # -- the exchanges between ranks, inside the library (rg_comm; comm may be None on one rank)
+    def exchange_records(self, comm, parts=1):
+        self._check(self._L.rg_exchange_records(self._h, _comm_handle(comm), parts))
+
+    def exchange_owner_buckets(self, comm):
+        self._check(self._L.rg_exchange_owner_buckets(self._h, _comm_handle(comm)))
+
+    def count_kmers_exchange(self, comm, route="records", parts=4, local_reads=UINT64_MAX):
+        """RAY_SLAVE_MODE_ADD_VERTICES across ranks in one call"""
+        r = {"records": _lib.RG_ROUTE_RECORDS, "entries": _lib.RG_ROUTE_ENTRIES}[route]
+        self._check(self._L.rg_count_kmers_exchange(self._h, _comm_handle(comm), r, parts, local_reads))
+
+    def histogram_exchange(self, comm):
+        """the ranks' histograms merged (MessageProcessor.cpp:1048-1061), on every rank"""
+        n = C.c_uint64()
+        # the merged histogram has at most as many bins as all ranks hold together; ask with room for them
+        cap = 1 << 16
+        while True:
+            cov = np.zeros(cap, dtype=np.uint32)
+            cnt = np.zeros(cap, dtype=np.uint64)
+            self._check(self._L.rg_histogram_exchange(self._h, _comm_handle(comm), cov.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                      cnt.ctypes.data_as(C.POINTER(C.c_uint64)), cap, C.byref(n)))
+            if n.value <= cap:
+                return cov[: n.value], cnt[: n.value]
+            cap = int(n.value)
+
+    def purge_edges_exchange(self, comm):
+        self._check(self._L.rg_purge_edges_exchange(self._h, _comm_handle(comm)))
+
+    def read_markers_exchange(self, comm, n_reads, parts=1):
+        import torch
+        dev = "cuda:%d" % self.device
+        fwd = torch.empty(max(1, n_reads), dtype=torch.int32, device=dev)
+        rev = torch.empty(max(1, n_reads), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        self._check(self._L.rg_read_markers_exchange(self._h, _comm_handle(comm), parts, fwd.data_ptr(), rev.data_ptr()))
+        return fwd[:n_reads].cpu().numpy(), rev[:n_reads].cpu().numpy()
+
+    def allgather_u64(self, comm, value):
+        out = (C.c_uint64 * self.size)()
+        self._check(self._L.rg_allgather_u64(self._h, _comm_handle(comm), int(value), out))
+        return [int(x) for x in out]
+
     # -- histogram / pass 2 / purge
     def histogram(self):
         n = C.c_uint64()
@@ -397,5 +523,5 @@ class GraphBuilder:
         return {n: int(getattr(s, n)) for n, _ in RgStats._fields_}
 
 
-__all__ = ["GraphBuilder", "RayGraphError", "record_dtype", "pack_read", "pack_reads", "coverage_distribution",
+__all__ = ["GraphBuilder", "Comm", "RayGraphError", "record_dtype", "pack_read", "pack_reads", "coverage_distribution",
            "RG_BLOOM_DEFAULT", "RG_ENTRY_BYTES"]

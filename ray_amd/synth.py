@@ -146,8 +146,8 @@ _synth_lib = None
 
 
 def make_reads_device(genome, read_len, n_reads, seed, error=0.0, first=0, device="cuda"):
-    """The counter-based generator (tools/rg_synth.hip; its host twin is oracle/ro_synth.c): reads first .. first+n_reads-1,
-    made in HBM, bit for bit the reads the oracle is run on -- every value is a pure function of (seed, index).
+    """The counter-based generator (tools/rg_synth.hip; the tests hold a host twin of it): reads first .. first+n_reads-1,
+    made in HBM -- every value is a pure function of (seed, index), so the same reads can be made anywhere.
     -> (packed u8 tensor padded by 32 bytes, offsets int64 tensor, lengths int32 tensor), as make_reads_torch"""
     import ctypes as C
     import os

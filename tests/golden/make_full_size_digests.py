@@ -52,6 +52,9 @@ def main(which):
         path = os.path.join(d, "CoverageDistribution.txt")
         out["minimum_peak_repeat"] = list(ro.coverage_distribution(cov, cnt, path))
         out["sha256_CoverageDistribution_txt"] = hashlib.sha256(open(path, "rb").read()).hexdigest()
+    dst = os.path.join(HERE, "full_size_%s.json" % which)
+    with open(dst, "w") as f:   # pass 1 is the headline metric: kept even if the run is cut short before the edges are done
+        json.dump(dict(out, _partial="pass 1 only: the run was still going"), f, indent=1)
     t0 = time.time()
     g.add_edges()
     print("add_edges %.0f s" % (time.time() - t0), flush=True)
@@ -61,7 +64,6 @@ def main(which):
     print("purge_edges %.0f s" % (time.time() - t0), flush=True)
     out["sha256_sorted_records_after_purge"] = digest_records(g.export())
     out["degree_distribution"] = g.degree_distribution().reshape(-1).tolist()
-    dst = os.path.join(HERE, "full_size_%s.json" % which)
     with open(dst, "w") as f:
         json.dump(out, f, indent=1)
     print("wrote", dst, flush=True)
