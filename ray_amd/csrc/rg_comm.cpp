@@ -133,7 +133,7 @@ double now_s() {
 // ---- the two primitives every exchange is made of ----------------------------------------------------------------
 // counts: n words for every rank out, n words from every rank in (host memory; returns with `in` filled)
 int comm_alltoall_u64(rg_comm *c, int size, const uint64_t *out, uint64_t *in, uint32_t n) {
-	if (size == 1 || !c) {
+	if (!c) {  // one rank without a communicator (one with a communicator goes through it: RCCL sends to itself)
 		memcpy(in, out, sizeof(uint64_t) * n);
 		return RG_OK;
 	}
@@ -170,7 +170,7 @@ struct Pending {
 int comm_alltoallv_start(rg_comm *c, int size, hipStream_t local_stream, const void *d_send, const uint64_t *scount, void *d_recv,
                          const uint64_t *rcount, uint32_t unit, Pending *p) {
 	p->active = false;
-	if (size == 1 || !c) {  // one rank: what it sends to itself
+	if (!c) {  // one rank without a communicator: what it sends to itself
 		if (scount[0] != rcount[0]) return cfail(c, RG_ERR_ARG, "one rank sends itself %llu items and expects %llu", (unsigned long long)scount[0], (unsigned long long)rcount[0]);
 		if (scount[0]) {
 			hipError_t e = hipMemcpyAsync(d_recv, d_send, scount[0] * unit, hipMemcpyDeviceToDevice, local_stream);
@@ -518,7 +518,7 @@ int rg_histogram_exchange(rg_handle *h, rg_comm *c, uint32_t *coverage, uint64_t
 	std::vector<uint64_t> cnt(mine ? mine : 1);
 	H_TRY(rg_histogram(h, cov.data(), cnt.data(), mine, &mine));
 	std::map<uint32_t, uint64_t> merged;
-	if (size == 1) {
+	if (!c) {
 		for (uint64_t i = 0; i < mine; ++i) merged[cov[i]] += cnt[i];
 	} else {
 		// every rank sends its (coverage, count) pairs to every rank: a few thousand pairs of 16 bytes

@@ -162,19 +162,19 @@ def test_c_exchange_with_ranks_that_have_no_reads(oracle):
 
 def test_markers_one_very_long_read_among_short_ones(oracle):
     """the multi-rank marker route holds memory per k-mer that exists (an exclusive scan of the reads' k-mer counts), not
-    per read x longest read: one 60 000-base read among 4000 reads of 60 (a dense matrix would be 4001 x 59 980
+    per read x longest read: one 60 000-base read among 20 000 reads of 60 (a dense matrix would be 20 001 x 59 980
     cells here, and 10 TB at 40 M reads); slices bound the buffers further"""
     rng = np.random.default_rng(11)
     genome = rng.integers(0, 4, size=70000, dtype=np.uint8)
     from ray_amd.synth import pack_codes
-    short_starts = rng.integers(0, 70000 - 60, size=4000)
-    lengths = np.full(4001, 60, dtype=np.uint32)
-    lengths[1234] = 60000
-    codes = np.zeros((4001, 60000), dtype=np.uint8)
-    for i, s in enumerate(short_starts):
-        codes[i if i < 1234 else i + 1, :60] = genome[s:s + 60]
-    codes[1234, :60000] = genome[5000:65000]
-    packed, offsets, lengths = pack_codes(codes, lengths)
+    short_starts = rng.integers(0, 70000 - 60, size=20000)
+    sp, so, sl = pack_codes(genome[short_starts[:, None] + np.arange(60)[None, :]], np.full(20000, 60, dtype=np.uint32))
+    lp, _, ll = pack_codes(genome[None, 5000:65000], np.array([60000], dtype=np.uint32))
+    at = 1234                                        # the long read sits between short ones
+    cut = int(so[at])
+    packed = np.concatenate([sp[:cut], lp, sp[cut:]])
+    offsets = np.concatenate([so[:at], [cut], so[at:] + len(lp)]).astype(np.uint64)
+    lengths = np.concatenate([sl[:at], ll, sl[at:]]).astype(np.uint32)
     k, nranks = 21, 2
     want = oracle_run(oracle, packed, offsets, lengths, k, nranks, 0)
     want["markers"] = want["graph"].read_markers()

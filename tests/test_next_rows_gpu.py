@@ -170,6 +170,50 @@ def test_standalone_driver_writes_rays_files(oracle, tmp_path):
     want_cc = str(tmp_path / "want_cc")
     oracle.write_coverage_checkpoint(cov, cnt, want_cc)
     assert open(ck / "Rank0.Checkpoint.CoverageDistribution.ray", "rb").read() == open(want_cc, "rb").read()
+    # CoverageDistributionAnalysis.txt (MachineHelper.cpp:283-327), last line = the distribution file's path as given
+    want_an = str(tmp_path / "want_an.txt")
+    oracle.write_coverage_analysis(cov, cnt, 31, mpr[0], mpr[1], mpr[2], out + "CoverageDistribution.txt", want_an)
+    assert open(out + "CoverageDistributionAnalysis.txt", "rb").read() == open(want_an, "rb").read()
+
+    # ---- the same job on G ranks, one process each (here: sharing the one GPU, bytes through host shared memory; on a node
+    # -transport rccl), as `mpiexec -n G Ray` lays it out: per-rank checkpoints against the G-rank oracle's
+    for G, route in ((2, "auto"), (3, "records")):
+        outg = str(tmp_path) + "/out%d_" % G
+        ckg = tmp_path / ("ck%d" % G)
+        ckg.mkdir()
+        res = subprocess.run([exe, "-k", "31", "-p", files[0], files[1], "-s", files[2], "-o", outg, "-write-kmers", "-write-checkpoints", str(ckg),
+                              "-bloom-filter-bits", "400000", "-gpus", str(G), "-devices", "0", "-transport", "shm", "-route", route, "-parts", "2"],
+                             capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0, res.stdout + res.stderr
+        gg = oracle.Graph(31, nranks=G, bloom_bits=400000)
+        gg.set_reads(packed, offsets, lengths)
+        gg.count_kmers()
+        covg, cntg = gg.histogram()
+        oracle.coverage_distribution(covg, cntg, want_dist)
+        assert open(outg + "CoverageDistribution.txt", "rb").read() == open(want_dist, "rb").read()
+        gg.add_edges()
+        gg.purge_edges()
+        for r in range(G):
+            gg.write_genome_graph(r, want_gg)
+            got = read_genome_graph(str(ckg / ("Rank%d.Checkpoint.GenomeGraph.ray" % r)), 1)
+            want = read_genome_graph(want_gg, 1)
+            assert len(got) == len(want) > 100 and sorted(got) == sorted(want), "rank %d of %d" % (r, G)
+            assert "Rank %d : partition is" % r in res.stdout
+        gg.write_partition(want_part)
+        assert open(outg + "GraphPartition.txt").read() == open(want_part).read()
+        lines = open(outg + "kmers.txt").read().splitlines()
+        assert lines[0].startswith("# Generated by Ray") and len([l for l in lines if l.startswith("#")]) == 13
+        assert sorted(l for l in lines if not l.startswith("#")) == sorted(gg.kmers_txt().strip().split("\n"))
+        deg = [int(l.split("\t")[2]) for l in open(outg + "degreeDistribution.txt").read().splitlines() if not l.startswith("#")]
+        assert deg == [int(x) for x in gg.degree_distribution().reshape(-1)]
+        # and back: every rank loads its own checkpoint the way the reference's reader does; same files again
+        outr = str(tmp_path) + "/back%d_" % G
+        res = subprocess.run([exe, "-k", "31", "-read-checkpoints", str(ckg), "-o", outr, "-write-kmers", "-gpus", str(G), "-devices", "0", "-transport", "shm"],
+                             capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0, res.stdout + res.stderr
+        assert open(outr + "CoverageDistribution.txt", "rb").read() == open(want_dist, "rb").read()
+        assert sorted(open(outr + "kmers.txt").read().splitlines()) == sorted(lines)
+        assert open(outr + "GraphPartition.txt").read() == open(want_part).read()
 
 
 @pytest.mark.parametrize("k", [31, 63])
