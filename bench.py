@@ -19,7 +19,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PMC_SUMMARY = "profiles/r02_v18_c2_pmc.json"
+PMC_SUMMARY = "profiles/c2_pmc_current.json"   # written by tools/summarize_profile.py together with the hash of the kernel sources it profiled
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
@@ -46,6 +46,7 @@ def parse():
                          "once a rank's own reads hold most k-mers only a few times)")
     ap.add_argument("--parts", type=int, default=4, help="records route: slices of the reads whose record transfers overlap the next slice's kernels")
     ap.add_argument("--sweep", type=lambda x: int(x, 0), default=0, help="rg_debug_set flags (development: forces a sweep / bucket bits)")
+    ap.add_argument("--no-error-record", action="store_true", help="skip the extra steps on the workload with 1 %% errors (the error_1pct sub-record)")
     ap.add_argument("--no-after", action="store_true", help="skip the purge and the store hand-back that are measured after the timed steps")
     ap.add_argument("--breakdown", action="store_true", help="print per-call wall times of the last step to stderr")
     return ap.parse_args()
@@ -162,9 +163,14 @@ def main():
         species, genome, n_reads = (sp_len, sp_cov), int(sp_len.sum()), n_all // (world * (emu if route == "entries" else 1))
     error = cfg["error"] if args.error is None else args.error
     t0 = time.perf_counter()
-    # same genome on every rank (same seed), different reads per rank
-    packed, offsets, lengths = synth.make_reads_torch(genome, cfg["read_len"], n_reads, cfg["seed"], error,
-                                                      device=dev, read_seed=cfg["seed"] * 1000 + rank, species=species)
+    # same genome on every rank (same seed), different reads per rank.  Single genomes: the counter-based generator
+    # (tools/rg_synth.hip) -- rank r makes reads [r * n, (r + 1) * n) of the job; at N = 1 these are exactly the reads the
+    # full-size oracle digests of tests/golden/ were computed on.  The metagenome (C4) keeps the torch generator.
+    if species is None:
+        packed, offsets, lengths = synth.make_reads_device(genome, cfg["read_len"], n_reads, cfg["seed"], error, first=rank * n_reads, device=dev)
+    else:
+        packed, offsets, lengths = synth.make_reads_torch(genome, cfg["read_len"], n_reads, cfg["seed"], error,
+                                                          device=dev, read_seed=cfg["seed"] * 1000 + rank, species=species)
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
     gen_s = time.perf_counter() - t0
@@ -329,18 +335,61 @@ def main():
             after["store hand-back (rg_export to host memory)"] = (time.perf_counter() - tp) * 1e3
             after["store hand-back records"] = n_rec
             after["store hand-back bytes"] = n_rec * rec.dtype.itemsize
-            del rec
+            try:   # the hand-back as a stream (rg_export_stream) with a stand-in for the glue's insert loop that touches every record
+                import ctypes as C
+                tl = C.CDLL(os.path.join(ROOT, "tools", "librg_synth.so"))
+                state = (C.c_uint64 * 3)(0, 0, rec.dtype.itemsize)
+                tp = time.perf_counter()
+                tl.rgs_touch_records(C.cast(state, C.c_void_p), C.c_void_p(rec.ctypes.data), C.c_uint64(n_rec))
+                after["stand-in consumer alone (touches every record, one host thread)"] = (time.perf_counter() - tp) * 1e3
+                want_sum = state[0]
+                state = (C.c_uint64 * 3)(0, 0, rec.dtype.itemsize)
+                b.export_stream(C.cast(tl.rgs_touch_records, C.c_void_p), 0, C.cast(state, C.c_void_p))   # warm: allocates the page-locked staging
+                state = (C.c_uint64 * 3)(0, 0, rec.dtype.itemsize)
+                tp = time.perf_counter()
+                b.export_stream(C.cast(tl.rgs_touch_records, C.c_void_p), 0, C.cast(state, C.c_void_p))
+                after["store hand-back as a stream with that consumer (rg_export_stream: copy and consumer overlap)"] = (time.perf_counter() - tp) * 1e3
+                assert state[1] == n_rec and state[0] == want_sum, "rg_export_stream handed over other records than rg_export"
+            except OSError:
+                pass
             try:   # the same into page-locked host memory (what a glue that keeps its buffer registered would see)
                 pinned = torch.empty(n_rec * record_dtype(1 if k <= 31 else 2).itemsize, dtype=torch.uint8, pin_memory=True)
                 rec2 = pinned.numpy().view(record_dtype(1 if k <= 31 else 2))
                 tp = time.perf_counter()
                 b.export_into(rec2)
                 after["store hand-back into page-locked memory"] = (time.perf_counter() - tp) * 1e3
-                del rec2, pinned
+                del rec2, pinned, rec
             except RuntimeError:
                 pass
         b.close()
         barrier()
+
+    # The same workload with 1 % substitution errors, one warm step + two timed ones after everything else (not part of `value`):
+    # error-rich reads are what the 8-GPU configurations are made of, and they are 3x further from the roofline.
+    error_record = None
+    if world == 1 and emu == 1 and species is None and args.error is None and error == 0.0 and not args.no_error_record:
+        del packed, offsets, lengths
+        torch.cuda.empty_cache()
+        ray_amd._lib.load().rg_release_cached_memory()
+        packed, offsets, lengths = synth.make_reads_device(genome, cfg["read_len"], n_reads, cfg["seed"], 0.01, first=0, device=dev)
+        torch.cuda.synchronize()
+        one_step()
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        for _ in range(2):
+            st_e, _, _ = one_step()
+        torch.cuda.synchronize()
+        ms_e = (time.perf_counter() - tp) / 2 * 1e3
+        bpo = cfg["read_len"] / (4.0 * (cfg["read_len"] - k + 1)) + 8 + 8 * (1 if k <= 31 else 2) + 8
+        error_record = {"substitution_error_rate": 0.01, "ms_per_step": ms_e, "steps": 2, "kmer_occurrences": st_e["occurrences"],
+                        "distinct_candidates": st_e["candidates"], "vertices_stored": st_e["stored_pairs"],
+                        "occurrences_per_s": st_e["occurrences"] / (ms_e / 1e3), "distinct_kmers_per_s": st_e["stored_pairs"] / (ms_e / 1e3),
+                        "frac_step": bpo * st_e["occurrences"] / (ms_e / 1e3) / 1e9 / HBM_PEAK_GBS}
+        # the CPU baseline below samples the workload's own (error-free) reads again
+        del packed, offsets, lengths
+        torch.cuda.empty_cache()
+        packed, offsets, lengths = synth.make_reads_device(genome, cfg["read_len"], min(n_reads, 16 * args.cpu_sample_reads), cfg["seed"], error, first=0, device=dev)
+        torch.cuda.synchronize()
 
     if rank == 0 and args.breakdown:
         for (n0, t0_), (n1, t1_) in zip(marks, marks[1:]):
@@ -409,18 +458,28 @@ def main():
         # (tools/profile_c2.sh; FETCH_SIZE and WRITE_SIZE in separate runs).  FETCH_SIZE is doubled as
         # MI355X_MICROARCH.md prescribes for gfx950 (checked here on k_scatter / k_level_hist / k_init_table,
         # whose byte counts are known exactly).
+        # The summary is quoted only when it was made from the very sources this library is built from (sha256 over
+        # ray_amd/csrc, tools/csrc_hash.py) and shows the launches this run makes; otherwise traffic is null.
         traffic = traffic_step = None
+        traffic_note = "no PMC summary for this workload"
         try:
             if args.workload.startswith("C2") and args.scale == 1.0 and world == 1 and dom and error == 0.0:
-                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), PMC_SUMMARY)) as fh:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                from csrc_hash import csrc_sha256
+                with open(os.path.join(ROOT, PMC_SUMMARY)) as fh:
                     pmc = json.load(fh)
                 pm = pmc.get(dom)
-                if pm and pm.get("launches"):   # per launch of this run's count: the profiled step's extra launches (the record sample's) move next to nothing
-                    traffic = (2.0 * pm.get("FETCH_SIZE_bytes", 0.0) + pm.get("WRITE_SIZE_bytes", 0.0)) / max(1.0, kprof[dom][1] / args.steps)
-                if pmc.get("_steps"):   # all kernels of the profiled run / its steps
+                launches_now = kprof[dom][1] / args.steps
+                if pmc.get("_csrc_sha256") != csrc_sha256():
+                    traffic_note = "the stored PMC summary was made from other kernel sources: not quoted (regenerate with tools/profile_c2.sh)"
+                elif not pm or not pm.get("launches") or abs(pm["launches"] - launches_now) > 2:   # (the profiled step's record sample adds up to two small launches)
+                    traffic_note = "the stored PMC summary shows %s launches of %s per step, this run %.1f: not quoted" % (pm.get("launches") if pm else None, dom, launches_now)
+                else:
+                    traffic = (2.0 * pm.get("FETCH_SIZE_bytes", 0.0) + pm.get("WRITE_SIZE_bytes", 0.0)) / max(1.0, launches_now)
                     traffic_step = sum(2.0 * v.get("FETCH_SIZE_bytes", 0.0) + v.get("WRITE_SIZE_bytes", 0.0)
-                                       for kn, v in pmc.items() if isinstance(v, dict)) / pmc["_steps"]
-        except (OSError, ValueError):
+                                       for kn, v in pmc.items() if isinstance(v, dict)) / max(1, pmc.get("_steps", 1))
+                    traffic_note = "bytes per launch, rocprofv3 PMC passes of the same command and the same kernel sources (%s, sha256 %s)" % (PMC_SUMMARY, pmc["_csrc_sha256"][:12])
+        except (OSError, ValueError, ImportError):
             traffic = traffic_step = None
         launches_dom = (kprof[dom][1] / args.steps) if dom else 0
         step_gbs = pass1_bytes_per_occ * occ0 / per_step / 1e9
@@ -445,7 +504,7 @@ def main():
                          "frac_kernel": (achieved / HBM_PEAK_GBS) if achieved else None,
                          "achieved_step": step_gbs, "step_bytes_per_occurrence": pass1_bytes_per_occ,
                          "traffic": traffic, "traffic_step": traffic_step,
-                         "traffic_unit": "bytes per launch (rocprofv3 PMC, %s)" % PMC_SUMMARY,
+                         "traffic_unit": traffic_note,
                          "algorithmic_bytes_per_launch": (alg_bytes[dom] / launches_dom) if dom in alg_bytes and launches_dom else None,
                          "kernel": dom, "bytes_per_occurrence": bytes_per_occ,
                          "kernel_ms_per_step": kernel_s * 1e3 if sweep_ms else None,
@@ -456,6 +515,7 @@ def main():
                                   "frac_of_hbm_peak": pass1_bytes_per_occ * occ0 / per_step / 1e9 / HBM_PEAK_GBS},
             "phases_ms_per_step": {name: sec / args.steps * 1e3 for name, sec in phases.items()},
             "after_the_timed_step_ms": after,
+            "error_1pct": error_record,
             "setup_s": gen_s,
         }
         if not args.no_cpu_baseline and world == 1:

@@ -256,6 +256,14 @@ int rg_size(rg_handle *h, uint64_t *size);
  * 4 bytes coverage, 1 byte edge bitmap = 13 or 21 bytes each, in table order.  host_buf holds
  * cap_records records; *n_records = records available. */
 int rg_export(rg_handle *h, void *host_buf, uint64_t cap_records, uint64_t *n_records);
+/* The same hand-back as a stream, for the glue's insert loop (GridTable::insert + Vertex::constructor + Vertex::load per
+ * record: GridTable.cpp:111-134, Vertex.cpp:41-51,422-436): `consume` is called on the calling thread with chunk after chunk
+ * of records (same layout and order as rg_export; valid during the call only) in page-locked memory of the library's, and
+ * while it works through one chunk the copy of the next is running: wall time = max(copy, consumer), not their sum, and no
+ * host buffer of the whole store is needed.  chunk_records = 0: 4 M records per chunk.  A non-zero return of `consume`
+ * stops the export (RG_ERR_STATE). */
+typedef int (*rg_export_fn)(void *user, const void *records, uint64_t n_records);
+int rg_export_stream(rg_handle *h, uint64_t chunk_records, rg_export_fn consume, void *user);
 /* bulk GridTable::find (GridTable.cpp:84-109) + Vertex::getCoverage/getEdges (Vertex.cpp:98-100,
  * 169-173): kmers = n * kmer_words words, either strand; coverage 0 = absent; edges in the
  * orientation of the queried k-mer.  Host pointers. */

@@ -13,6 +13,7 @@ RG_OK = 0
 RG_ERR_ARG, RG_ERR_HIP, RG_ERR_NOMEM, RG_ERR_STATE, RG_ERR_CAPACITY, RG_ERR_HASH, RG_ERR_COMM = -1, -2, -3, -4, -5, -6, -7
 RG_COMM_ID_BYTES = 256
 RG_ROUTE_RECORDS, RG_ROUTE_ENTRIES = 1, 2
+EXPORT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64)   # rg_export_fn
 ALLTOALL_U64_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_uint32)
 ALLTOALLV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32)
 
@@ -45,7 +46,7 @@ class RgStats(C.Structure):
 SYMBOLS = ["rg_create", "rg_destroy", "rg_last_error", "rg_add_reads", "rg_add_reads_device", "rg_count_kmers",
            "rg_count_local", "rg_records_local", "rg_records_local_part", "rg_record_counts", "rg_export_records", "rg_count_records", "rg_owner_counts", "rg_export_owner_buckets", "rg_merge_entries",
            "rg_resolve_admission", "rg_histogram", "rg_add_edges", "rg_purge_edges", "rg_purge_query_counts",
-           "rg_purge_export_queries", "rg_purge_answer", "rg_purge_apply", "rg_size", "rg_export",
+           "rg_purge_export_queries", "rg_purge_answer", "rg_purge_apply", "rg_size", "rg_export", "rg_export_stream",
            "rg_find", "rg_add_reads_text", "rg_count_sequences", "rg_load_sequences", "rg_get_reads", "rg_pack_reads_noalloc", "rg_release_local", "rg_adopt_entries", "rg_check_hashes", "rg_hash_kmers", "rg_read_markers", "rg_markers_query_counts", "rg_markers_query_counts_part", "rg_markers_export_queries", "rg_markers_answer", "rg_markers_apply",
            "rg_import_vertices", "rg_write_kmers_txt", "rg_write_genome_graph", "rg_write_coverage_checkpoint", "rg_write_graph_partition", "rg_write_coverage_analysis", "rg_read_genome_graph", "rg_degree_distribution", "rg_get_stats", "rg_set_profiling", "rg_debug_set", "rg_get_kernel_profile", "rg_release_cached_memory", "rg_coverage_distribution", "rg_pack_read",
            "rg_comm_unique_id", "rg_comm_create_rccl", "rg_comm_create_transport", "rg_comm_destroy", "rg_comm_last_error", "rg_comm_get_stats",
@@ -101,6 +102,7 @@ def load():
         "rg_purge_apply": ([vp, vp, u64], C.c_int),
         "rg_size": ([vp, u64p], C.c_int),
         "rg_export": ([vp, vp, u64, u64p], C.c_int),
+        "rg_export_stream": ([vp, u64, C.c_void_p, vp], C.c_int),
         "rg_find": ([vp, u64p, u64, u32p, u8p], C.c_int),
         "rg_degree_distribution": ([vp, u64p], C.c_int),
         "rg_add_reads_text": ([vp, vp, u64, vp, vp, u64], C.c_int),

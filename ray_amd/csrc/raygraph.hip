@@ -1352,6 +1352,8 @@ struct rg_handle {
 	uint32_t *d_hist_ovf = nullptr;
 	bool hist_valid = false;
 	std::vector<std::pair<uint32_t, uint64_t>> hist_cache;  // (coverage, stored pairs)
+	void *export_stage[2] = {nullptr, nullptr};  // rg_export_stream: page-locked staging, kept for the next call
+	uint64_t export_stage_bytes = 0;
 };
 
 // brackets the launches issued during its lifetime with two HIP events on the handle's stream
@@ -3030,6 +3032,8 @@ int rg_destroy(rg_handle *h) {
 	if (h->d_marker_kprefix) pool_free(h->cfg.device, h->d_marker_kprefix);
 	if (h->rec_buf) pool_free(h->cfg.device, h->rec_buf);
 	if (h->pending_log) pool_free(h->cfg.device, h->pending_log);
+	for (int i = 0; i < 2; ++i)
+		if (h->export_stage[i]) (void)hipHostFree(h->export_stage[i]);
 	if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
 	delete h;
 	return RG_OK;
@@ -3767,14 +3771,10 @@ int rg_size(rg_handle *h, uint64_t *size) {
 	return RG_OK;
 }
 
-int rg_export(rg_handle *h, void *host_buf, uint64_t cap_records, uint64_t *n_records) {
-	if (!h || !n_records) return RG_ERR_ARG;
-	if (h->phase < PH_RESOLVED) return fail(h, RG_ERR_STATE, "rg_export needs the k-mer count first");
+// the stored vertices as Vertex::dump records in a device buffer (slot order, deterministic); *d_out is a pool block the caller frees
+static int export_to_device(rg_handle *h, uint8_t **d_out_p) {
+	*d_out_p = nullptr;
 	const uint64_t n = h->stats.stored_pairs;
-	*n_records = n;
-	if (!host_buf || cap_records == 0 || n == 0) return RG_OK;
-	if (cap_records < n) return fail(h, RG_ERR_CAPACITY, "export buffer holds %llu records, need %llu", (unsigned long long)cap_records, (unsigned long long)n);
-	HIP_TRY(h, hipSetDevice(h->cfg.device));
 	const uint64_t rec = (uint64_t)h->W * 8 + 5;
 	const uint64_t cap = h->tab.cap;
 	uint64_t nchunks = std::min<uint64_t>(2048, (cap + BLOCK - 1) / BLOCK);
@@ -3800,10 +3800,81 @@ int rg_export(rg_handle *h, void *host_buf, uint64_t cap_records, uint64_t *n_re
 	HIP_TRY(h, hipMemcpyAsync(d_chunk, hc.data(), nchunks * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
 	if (h->W == 1) hipLaunchKernelGGL(k_export_write<1>, dim3((int)nchunks), dim3(BLOCK), 0, h->stream, h->tab.slots, cap, chunk, d_chunk, d_out, h->phase >= PH_EDGES ? 0xFFu : 0u);
 	else hipLaunchKernelGGL(k_export_write<2>, dim3((int)nchunks), dim3(BLOCK), 0, h->stream, h->tab.slots, cap, chunk, d_chunk, d_out, h->phase >= PH_EDGES ? 0xFFu : 0u);
-	hipError_t e = hipGetLastError();
-	if (e == hipSuccess) e = hipMemcpyAsync(host_buf, d_out, n * rec, hipMemcpyDeviceToHost, h->stream);
+	HIP_TRY(h, hipGetLastError());
+	HIP_TRY(h, hipStreamSynchronize(h->stream));  // d_chunk goes back to the pool with this scope
+	*d_out_p = (uint8_t *)g_out.release();
+	return RG_OK;
+}
+
+int rg_export(rg_handle *h, void *host_buf, uint64_t cap_records, uint64_t *n_records) {
+	if (!h || !n_records) return RG_ERR_ARG;
+	if (h->phase < PH_RESOLVED) return fail(h, RG_ERR_STATE, "rg_export needs the k-mer count first");
+	const uint64_t n = h->stats.stored_pairs;
+	*n_records = n;
+	if (!host_buf || cap_records == 0 || n == 0) return RG_OK;
+	if (cap_records < n) return fail(h, RG_ERR_CAPACITY, "export buffer holds %llu records, need %llu", (unsigned long long)cap_records, (unsigned long long)n);
+	HIP_TRY(h, hipSetDevice(h->cfg.device));
+	const uint64_t rec = (uint64_t)h->W * 8 + 5;
+	uint8_t *d_out = nullptr;
+	if (int rc = export_to_device(h, &d_out)) return rc;
+	hipError_t e = hipMemcpyAsync(host_buf, d_out, n * rec, hipMemcpyDeviceToHost, h->stream);
 	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+	pool_free(h->cfg.device, d_out);
 	if (e != hipSuccess) return fail(h, RG_ERR_HIP, "export failed: %s", hipGetErrorString(e));
+	return RG_OK;
+}
+
+// The hand-back as a stream: the records reach the caller chunk by chunk in page-locked staging memory of the library's own
+// (two buffers), and while the caller's function works through one chunk -- GridTable::insert + Vertex::load per record in
+// Ray's glue -- the copy of the next one is already running.  Wall time = max(copy, consumer) instead of their sum, and the
+// caller needs no buffer of the whole store (1.3 GB for C2's 1e8 vertices).
+int rg_export_stream(rg_handle *h, uint64_t chunk_records, rg_export_fn consume, void *user) {
+	if (!h || !consume) return RG_ERR_ARG;
+	if (h->phase < PH_RESOLVED) return fail(h, RG_ERR_STATE, "rg_export_stream needs the k-mer count first");
+	const uint64_t n = h->stats.stored_pairs;
+	if (n == 0) return RG_OK;
+	HIP_TRY(h, hipSetDevice(h->cfg.device));
+	const uint64_t rec = (uint64_t)h->W * 8 + 5;
+	if (chunk_records == 0) chunk_records = 1ull << 22;  // 4 M records: 55 / 88 MB per staging buffer
+	chunk_records = std::min(chunk_records, n);
+	if (h->export_stage_bytes < chunk_records * rec) {  // the staging buffers stay with the handle
+		for (int i = 0; i < 2; ++i) {
+			if (h->export_stage[i]) (void)hipHostFree(h->export_stage[i]);
+			h->export_stage[i] = nullptr;
+		}
+		h->export_stage_bytes = 0;
+		for (int i = 0; i < 2; ++i)
+			if (hipHostMalloc(&h->export_stage[i], chunk_records * rec) != hipSuccess) {
+				(void)hipGetLastError();
+				return fail(h, RG_ERR_NOMEM, "rg_export_stream: no page-locked memory for two chunks of %llu records", (unsigned long long)chunk_records);
+			}
+		h->export_stage_bytes = chunk_records * rec;
+	}
+	uint8_t *d_out = nullptr;
+	if (int rc = export_to_device(h, &d_out)) return rc;
+	hipEvent_t done[2] = {nullptr, nullptr};
+	hipError_t e = hipEventCreateWithFlags(&done[0], hipEventDisableTiming);
+	if (e == hipSuccess) e = hipEventCreateWithFlags(&done[1], hipEventDisableTiming);
+	const uint64_t nchunks = (n + chunk_records - 1) / chunk_records;
+	auto issue = [&](uint64_t c) {
+		const uint64_t lo = c * chunk_records, cnt = std::min(chunk_records, n - lo);
+		hipError_t x = hipMemcpyAsync(h->export_stage[c & 1], d_out + lo * rec, cnt * rec, hipMemcpyDeviceToHost, h->stream);
+		if (x == hipSuccess) x = hipEventRecord(done[c & 1], h->stream);
+		return x;
+	};
+	int stop = 0;
+	if (e == hipSuccess) e = issue(0);
+	for (uint64_t c = 0; c < nchunks && e == hipSuccess && !stop; ++c) {
+		e = hipEventSynchronize(done[c & 1]);
+		if (e == hipSuccess && c + 1 < nchunks) e = issue(c + 1);  // the other buffer: the consumer finished with it one round ago
+		if (e == hipSuccess) stop = consume(user, h->export_stage[c & 1], std::min(chunk_records, n - c * chunk_records));
+	}
+	(void)hipStreamSynchronize(h->stream);
+	for (int i = 0; i < 2; ++i)
+		if (done[i]) (void)hipEventDestroy(done[i]);
+	pool_free(h->cfg.device, d_out);
+	if (e != hipSuccess) return fail(h, RG_ERR_HIP, "rg_export_stream: %s", hipGetErrorString(e));
+	if (stop) return fail(h, RG_ERR_STATE, "rg_export_stream: the consumer stopped the export (returned %d)", stop);
 	return RG_OK;
 }
 

@@ -474,6 +474,25 @@ class GraphBuilder:
         self._check(self._L.rg_export(self._h, buf.ctypes.data, len(buf), C.byref(m)))
         return int(m.value)
 
+    def export_stream(self, consume, chunk_records=0, user=None):
+        """rg_export_stream: `consume` is a callable(records: structured numpy array, valid during the call) or a C function
+        pointer of type rg_export_fn (then `user` is passed through)"""
+        if callable(consume) and not isinstance(consume, (C._CFuncPtr, C.c_void_p)):
+            dt = record_dtype(self.kmer_words)
+
+            def _cb(_user, ptr, n):
+                try:
+                    buf = (C.c_uint8 * (n * dt.itemsize)).from_address(ptr)
+                    return int(consume(np.frombuffer(buf, dtype=dt, count=n)) or 0)
+                except Exception:  # noqa: BLE001  (must not propagate into C)
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            fn = _lib.EXPORT_FN(_cb)
+        else:
+            fn = consume
+        self._check(self._L.rg_export_stream(self._h, chunk_records, fn if isinstance(fn, C.c_void_p) else C.cast(fn, C.c_void_p), user))
+
     def export(self, sort=True):
         """stored vertices as a structured array (key, coverage, edges); sorted by key if asked."""
         n = C.c_uint64()

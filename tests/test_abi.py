@@ -124,6 +124,27 @@ int glue(const uint8_t *packed, uint64_t nbytes, const uint64_t *off, const uint
 	rg_markers_answer(m_gpuGraph,d_buf,counts[0],(uint32_t*)d_buf); rg_markers_apply(m_gpuGraph,(const uint32_t*)d_buf,counts[0],(int32_t*)d_buf,(int32_t*)d_buf);
 	return rg_destroy(m_gpuGraph);
 }
+/* size > 1: the communicator and the exchanges, as INTEGRATION.md's glue calls them */
+static rg_comm *m_gpuComm;
+static int a2a(void *u,const uint64_t *s,uint64_t *r,uint32_t n){ (void)u;(void)s;(void)r;(void)n; return 0; }
+static int a2av(void *u,const void *ds,const uint64_t *sc,void *dr,const uint64_t *rc,uint32_t unit){ (void)u;(void)ds;(void)sc;(void)dr;(void)rc;(void)unit; return 0; }
+int glue_ranks(int rank,int size,int device,uint64_t myReads,int32_t *d_fwd,int32_t *d_rev){
+	unsigned char id[RG_COMM_ID_BYTES];
+	uint64_t nh=0, sizes[64];
+	rg_transport t; rg_comm_stats cs;
+	if(rank==0 && rg_comm_unique_id(id)!=RG_OK) return 1;
+	if(rg_comm_create_rccl(id,rank,size,device,&m_gpuComm)!=RG_OK){ (void)rg_comm_last_error(NULL); return 2; }
+	t.user=NULL; t.alltoall_u64=a2a; t.alltoallv=a2av;
+	if(rg_comm_create_transport(&t,rank,size,device,&m_gpuComm)!=RG_OK) return 3;
+	if(rg_count_kmers_exchange(m_gpuGraph,m_gpuComm,size==2?RG_ROUTE_ENTRIES:RG_ROUTE_RECORDS,4,myReads)==RG_ERR_COMM) return 4;
+	rg_exchange_records(m_gpuGraph,m_gpuComm,4); rg_exchange_owner_buckets(m_gpuGraph,m_gpuComm); rg_resolve_admission(m_gpuGraph,myReads);
+	rg_histogram_exchange(m_gpuGraph,m_gpuComm,NULL,NULL,0,&nh);
+	rg_purge_edges_exchange(m_gpuGraph,m_gpuComm);
+	rg_read_markers_exchange(m_gpuGraph,m_gpuComm,4,d_fwd,d_rev);
+	rg_allgather_u64(m_gpuGraph,m_gpuComm,nh,sizes);
+	rg_comm_get_stats(m_gpuComm,&cs);
+	return rg_comm_destroy(m_gpuComm);
+}
 """)
     for compiler, std in (("gcc", "-std=c99"), ("g++", "-std=c++98")):
         res = subprocess.run([compiler, std, "-Wall", "-Werror", "-fsyntax-only", "-x", "c" if compiler == "gcc" else "c++", "-I", inc, str(src)],

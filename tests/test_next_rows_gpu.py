@@ -175,6 +175,16 @@ def test_standalone_driver_writes_rays_files(oracle, tmp_path):
     oracle.write_coverage_analysis(cov, cnt, 31, mpr[0], mpr[1], mpr[2], out + "CoverageDistribution.txt", want_an)
     assert open(out + "CoverageDistributionAnalysis.txt", "rb").read() == open(want_an, "rb").read()
 
+    # one rank with a communicator all the same: RCCL initialised by the C++ driver, every exchange a send to itself
+    out1 = str(tmp_path) + "/rccl1_"
+    res = subprocess.run([exe, "-k", "31", "-p", files[0], files[1], "-s", files[2], "-o", out1, "-write-kmers", "-bloom-filter-bits", "400000",
+                          "-gpus", "1", "-transport", "rccl", "-route", "records", "-parts", "3"], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "collectives" in res.stdout
+    for name in ("CoverageDistribution.txt", "GraphPartition.txt", "degreeDistribution.txt"):
+        assert open(out1 + name, "rb").read() == open(out + name, "rb").read(), name
+    assert sorted(open(out1 + "kmers.txt").read().splitlines()) == sorted(open(out + "kmers.txt").read().splitlines())
+
     # ---- the same job on G ranks, one process each (here: sharing the one GPU, bytes through host shared memory; on a node
     # -transport rccl), as `mpiexec -n G Ray` lays it out: per-rank checkpoints against the G-rank oracle's
     for G, route in ((2, "auto"), (3, "records")):

@@ -270,3 +270,26 @@ def test_hashes_are_checked_against_the_callers(oracle, k):
         h1, h2 = b.hash_kmers(np.array([[0x24e4e4e4e4e4e4e4]], dtype=np.uint64))
         assert (int(h1[0]), int(h2[0])) == (0x14605c73bf1f7ba9, 0x2a0e90af81ed09a8)
     b.close()
+
+
+def test_export_stream_hands_over_the_same_records_chunk_by_chunk(oracle):
+    """rg_export_stream against rg_export: same bytes in the same order, whatever the chunk size; the consumer can stop it"""
+    import ray_amd
+    packed, offsets, lengths = make_reads_numpy(genome=30000, read_len=100, n_reads=12000, seed=8, error=0.01)
+    for k in (31, 63):
+        b = ray_amd.GraphBuilder(k)
+        b.add_reads(packed, offsets, lengths)
+        b.count_kmers()
+        b.add_edges()
+        whole = b.export(sort=False)
+        assert len(whole) > 20000
+        for chunk in (0, 1000, 4097, len(whole), 10 * len(whole)):
+            got = []
+            b.export_stream(lambda rec: got.append(rec.copy()), chunk_records=chunk)   # the staging memory is only valid during the call
+            assert len(got) == (1 if chunk == 0 or chunk >= len(whole) else -(-len(whole) // chunk))
+            assert np.concatenate(got).tobytes() == whole.tobytes(), "k=%d chunk=%d" % (k, chunk)
+        seen = []
+        with pytest.raises(ray_amd.RayGraphError) as e:
+            b.export_stream(lambda rec: seen.append(len(rec)) or (len(seen) == 3), chunk_records=500)
+        assert e.value.code == -4 and len(seen) == 3
+        b.close()

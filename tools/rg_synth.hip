@@ -66,3 +66,24 @@ extern "C" int rgs_generate(void *d_packed, void *d_offsets, void *d_lengths, ui
 	if (hipGetLastError() != hipSuccess) return -2;
 	return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? 0 : -2;
 }
+
+// A stand-in for the host consumer of the store hand-back (Ray's GridTable::insert + Vertex::load loop): touches every
+// byte of every record.  user -> {checksum, records seen, bytes per record}.  Type: rg_export_fn (include/raygraph.h).
+struct rgs_consumer {
+	uint64_t checksum, records, record_bytes;
+};
+extern "C" int rgs_touch_records(void *user, const void *records, uint64_t n) {
+	rgs_consumer *c = (rgs_consumer *)user;
+	const unsigned char *p = (const unsigned char *)records;
+	const uint64_t bytes = n * c->record_bytes;
+	uint64_t sum = c->checksum, i = 0;
+	for (; i + 8 <= bytes; i += 8) {
+		uint64_t w;
+		__builtin_memcpy(&w, p + i, 8);
+		sum = (sum ^ w) * 0x9E3779B97F4A7C15ull;
+	}
+	for (; i < bytes; ++i) sum = (sum ^ p[i]) * 0x9E3779B97F4A7C15ull;
+	c->checksum = sum;
+	c->records += n;
+	return 0;
+}

@@ -7,8 +7,11 @@ raw as rocprofv3 reports them (KB * 1024) -- MI355X_MICROARCH.md: on gfx950 FETC
 coalesced reads by 2x, other access widths are uncalibrated; from the l2 / atomic passes, when present, the raw
 counts TCC_HIT / TCC_MISS / TCC_REQ / TCC_ATOMIC / TCC_EA0_ATOMIC / TCC_READ / TCC_WRITE / TCP_TOTAL_ATOMIC_* and
 L2_hit_rate = TCC_HIT / (TCC_HIT + TCC_MISS); "_steps" = bench steps per pass)."""
-import csv, glob, json, re, shutil, sys
+import csv, glob, json, os, re, shutil, sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from csrc_hash import csrc_sha256  # noqa: E402
 
 tag, outprefix = sys.argv[1], sys.argv[2]
 
@@ -45,7 +48,11 @@ for k, v in pmc.items():
     if v.get("TCC_HIT", 0) + v.get("TCC_MISS", 0) > 0:
         v["L2_hit_rate"] = v["TCC_HIT"] / (v["TCC_HIT"] + v["TCC_MISS"])
 pmc["_steps"] = 1
+pmc["_csrc_sha256"] = csrc_sha256()   # the kernels these counters belong to: bench.py quotes the traffic only for the same sources
+pmc["_bench_args"] = os.environ.get("BENCH_ARGS", "")
 json.dump(pmc, open(outprefix + "_pmc.json", "w"), indent=1, sort_keys=True)
+if not pmc["_bench_args"]:   # the default workload's summary is also the one bench.py reads
+    json.dump(pmc, open(os.path.join(os.path.dirname(outprefix) or ".", "c2_pmc_current.json"), "w"), indent=1, sort_keys=True)
 tot = 0.0
 for k, v in sorted(((k, v) for k, v in pmc.items() if isinstance(v, dict)), key=lambda kv: -kv[1].get("FETCH_SIZE_bytes", 0)):
     tot += 2 * v.get("FETCH_SIZE_bytes", 0) + v.get("WRITE_SIZE_bytes", 0)
