@@ -1480,6 +1480,7 @@ struct SuperkmerLaunch {
 	int grid_wave = 1, grid_lane = 0;
 	size_t lds_lane = 0;
 	bool wide = false;  // k_superkmers_lanes<W, true, C>: 6-byte window slots, windows of up to 64 m-mers
+	bool unrolled = false;  // k_superkmers_lanes_s<17, C>: one-word keys, window of 17 m-mers (k = 31), blocks unrolled
 	int grid_max() const { return grid_wave > grid_lane ? grid_wave : grid_lane; }
 	void plan(rg_handle *h, int n_cu, int k, int m, uint64_t total_reads) {
 		const int w = k - m + 1;
@@ -1487,11 +1488,19 @@ struct SuperkmerLaunch {
 		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (k_superkmers<W, C>), 256, 0) != hipSuccess || occ < 1) occ = 4;
 		grid_wave = (int)std::min<uint64_t>((uint64_t)n_cu * occ, std::max<uint64_t>(1, (total_reads + 255) / 256));
 		grid_lane = 0;
-		if (w <= SKL_HOST_MAX_W && w <= SKL_MAX_W && !(h->dbg & 0x10000)) {
+		if (w <= SKL_HOST_MAX_W && w <= SKL_MAX_W && !(h->dbg & 0x10000) && !getenv("RG_EXP_SKL_WIDE")) {
 			lds_lane = (size_t)4 * w * 64 * sizeof(unsigned long long);
 			int occl = 0;
 			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occl, (k_superkmers_lanes<W, false, C>), 256, lds_lane) == hipSuccess && occl >= 1)
 				grid_lane = (int)std::min<uint64_t>((uint64_t)n_cu * occl, std::max<uint64_t>(1, (total_reads + 255) / 256));
+			if constexpr (W == 1) {  // rg_debug_set bit 30 keeps the generic kernel (tests)
+				int occs = 0;
+				if (w == 17 && grid_lane > 0 && !(h->dbg & 0x40000000u) && !getenv("RG_EXP_SKL_GENERIC") &&
+				    hipOccupancyMaxActiveBlocksPerMultiprocessor(&occs, (k_superkmers_lanes_s<17, C>), 256, lds_lane) == hipSuccess && occs >= 1) {
+					grid_lane = (int)std::min<uint64_t>((uint64_t)n_cu * occs, std::max<uint64_t>(1, (total_reads + 255) / 256));
+					unrolled = true;
+				}
+			}
 		} else if (w <= SKL_MAX_W_WIDE && !(h->dbg & 0x10000)) {
 			lds_lane = (size_t)4 * w * 64 * 6;
 			int occl = 0;
@@ -1507,6 +1516,13 @@ struct SuperkmerLaunch {
 	const char *name(const ReadBatch &b) const { return lanes(b) ? "k_superkmers_lanes" : "k_superkmers"; }
 	void launch(rg_handle *h, const ReadBatch &b, uint64_t lo, uint64_t n, int k, int m, RM *buf, uint64_t rec_cap,
 	            unsigned long long *d_hist, uint32_t modulo, uint32_t hist_shift, RM *sample = nullptr, uint64_t sample_cap = 0) const {
+		if constexpr (W == 1) {
+			if (lanes(b) && unrolled) {
+				hipLaunchKernelGGL((k_superkmers_lanes_s<17, C>), dim3(grid_lane), dim3(256), lds_lane, h->stream, b.d_packed, b.d_off + lo, b.d_len + lo, n,
+				                   b.first_id + lo, k, m, buf, rec_cap, h->d_counters, d_hist, modulo, hist_shift, sample, sample_cap);
+				return;
+			}
+		}
 		if (lanes(b) && wide)
 			hipLaunchKernelGGL((k_superkmers_lanes<W, true, C>), dim3(grid_lane), dim3(256), lds_lane, h->stream, b.d_packed, b.d_off + lo, b.d_len + lo, n,
 			                   b.first_id + lo, k, m, buf, rec_cap, h->d_counters, d_hist, modulo, hist_shift, sample, sample_cap);

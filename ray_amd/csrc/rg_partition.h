@@ -717,6 +717,264 @@ __global__ __launch_bounds__(256) void k_superkmers_lanes(const uint64_t *__rest
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_superkmers_lanes for one-word keys with the window length known at compile time (WS = k - m + 1: 17 for k = 31, the
+// length every BASELINE configuration but one is run at).  Same algorithm, same records; what changes is what the step
+// costs.  The generic kernel spends as many scalar as vector instructions per step -- a CU has ONE scalar unit for its
+// four SIMDs, and on C2 both units are about 60 % busy, which is why more wavefronts per CU (6-byte slots: five workgroups
+// instead of four) bought nothing.  Here a block of WS steps is unrolled: the slot of entry i is an immediate LDS offset,
+// "i + 1 < w", "i == 0" and "i == w" are decided by the compiler, the first block needs no special case (p = j + 1 - w
+// wraps and matches no read), the suffix pass has no loop, and the bases of a block -- WS <= 17 of them, 34 bits -- come
+// from two dwords requested one block ahead.  The one place a step can leave the unrolled block is when 64 records are
+// queued: they are assembled at a single site and the block is re-entered at the step it was left (the switch).
+template <int WS, bool C>
+__global__ __launch_bounds__(256) void k_superkmers_lanes_s(const uint64_t *__restrict__ P, const uint64_t *__restrict__ offsets,
+                                                            const uint32_t *__restrict__ lengths, uint64_t nreads, uint64_t read_id_base,
+                                                            int k, int m, RecMem<1, C> *__restrict__ recs, uint64_t rec_cap,
+                                                            unsigned long long *__restrict__ counters,
+                                                            unsigned long long *__restrict__ coarse_hist, uint32_t modulo, uint32_t hist_shift,
+                                                            RecMem<1, C> *__restrict__ sample, uint64_t sample_cap) {
+	static_assert(WS >= 2 && WS <= 17, "a block's bases must fit two dwords at any even bit offset");
+	using RM = RecMem<1, C>;
+	constexpr int NB = 2;
+	constexpr uint32_t w = WS;
+	extern __shared__ unsigned long long s_win_all[];  // [4 wavefronts][w entries][64 lanes]
+	__shared__ unsigned long long s_q[4][SKL_RING];
+	__shared__ uint32_t s_hist[NB_COARSE];
+	const uint32_t *__restrict__ P32 = reinterpret_cast<const uint32_t *>(P);
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	unsigned long long *const win = s_win_all + (size_t)wave * w * 64 + lane;  // entry i of this lane: win[i * 64]
+	constexpr uint32_t SB = 16u, LNB = 5u, LANE_SH = SB + LNB, MO_SH = LANE_SH + 6u;
+	unsigned long long *const ring = s_q[wave];
+	s_hist[threadIdx.x] = 0;
+	__syncthreads();
+	const uint32_t maskm = (1u << (2 * m)) - 1;
+	const uint32_t top = 2u * (uint32_t)(m - 1);
+	const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+	const uint64_t ngroups = (nreads + 63) / 64;
+	uint64_t chunk_base = 0;
+	uint32_t chunk_used = REC_CHUNK;
+	bool have_chunk = false, dead = false;
+	unsigned long long occ = 0;
+	uint32_t qhead = 0, qtail = 0;  // wave-uniform
+
+	for (uint64_t g = (uint64_t)blockIdx.x * 4 + wave; g < ngroups; g += nwaves) {
+		const uint64_t rb = g * 64;
+		uint32_t L = 0;
+		uint64_t bit0 = 0;
+		if (rb + lane < nreads) {
+			L = lengths[rb + lane];
+			bit0 = offsets[rb + lane] * 8;
+		}
+		if (L < (uint32_t)k) L = 0;
+		const uint32_t n = L ? L - (uint32_t)k + 1 : 0;
+		occ += n;
+		uint32_t maxn = n;
+#pragma unroll
+		for (int d = 32; d; d >>= 1) {
+			const uint32_t o = __shfl_xor(maxn, d);
+			maxn = o > maxn ? o : maxn;
+		}
+		maxn = (uint32_t)__builtin_amdgcn_readfirstlane((int)maxn);
+		if (maxn == 0) continue;
+		const uint32_t sh = (uint32_t)bit0 & 31u;  // a multiple of 8: reads start on byte boundaries
+		const uint32_t *__restrict__ rp = P32 + (bit0 >> 5);
+		const uint32_t lastw = L ? (sh + 2u * L - 1u) >> 5 : 0u;  // last dword that holds a base of this read
+		const uint32_t nsteps = maxn + w;  // m-mers 0 .. max(nm): k-mer p is complete at j = p + w - 1, and p = n closes the last record
+		uint32_t f = 0, r = 0;
+		{  // the m - 1 bases in front of the first m-mer
+			const uint32_t a0 = L ? rp[0] : 0u, a1 = (L && 1u <= lastw) ? rp[1] : 0u;
+			uint32_t buf = __builtin_amdgcn_alignbit(a1, a0, sh);
+			for (uint32_t t = 0; t + 1 < (uint32_t)m; ++t) {
+				const uint32_t c = buf & 3u;
+				buf >>= 2;
+				f = (f >> 2) | (c << top);
+				r = ((r << 2) | (c ^ 3u)) & maskm;
+			}
+		}
+		// block b holds m-mers j = WS b .. WS b + WS - 1, completed by bases t = j + m - 1: 2 WS bits from bit sh + 2 (WS b + m - 1)
+		uint32_t bitb = sh + 2u * (uint32_t)(m - 1);
+		uint32_t idx = bitb >> 5;
+		uint32_t d0 = (L && idx <= lastw) ? rp[idx] : 0u, d1 = (L && idx + 1 <= lastw) ? rp[idx + 1] : 0u;
+		uint32_t pre_hi = ~0u, pre_lo = 0, cur_hi = 0, cur_lo = ~0u, dbase = 0;
+		const uint32_t lane_term = lane << LANE_SH;
+		uint32_t jb = 0, i0 = 0;
+		bool final = false;
+		uint32_t lo = 0, c16 = 0, mix = 0;
+		unsigned long long sfx = ~0ull;  // S[i + 1] of the previous block for the step about to run: read one step ahead
+		for (;;) {
+			if (i0 == 0) {  // block start: its bases out of the two dwords, the next block's dwords requested
+				sfx = win[1 * 64];
+				const uint32_t o = bitb & 31u;
+				lo = __builtin_amdgcn_alignbit(d1, d0, o);
+				c16 = (d1 >> o) & 3u;
+				bitb += 2u * WS;
+				idx = bitb >> 5;
+				asm volatile("" : "+v"(lo), "+v"(c16) : : "memory");  // the old dwords are used up before the new request
+				d0 = (L && idx <= lastw) ? rp[idx] : 0u;
+				d1 = (L && idx + 1 <= lastw) ? rp[idx + 1] : 0u;
+			}
+#define RG_SKS_STEP(I)                                                                                                           \
+	case I: {                                                                                                                    \
+		const uint32_t j = jb + (I);                                                                                             \
+		if (j >= nsteps) {                                                                                                       \
+			final = true;                                                                                                        \
+			goto flush;                                                                                                          \
+		}                                                                                                                        \
+		const uint32_t c = ((I) < 16) ? ((lo >> (2 * ((I) & 15))) & 3u) : c16;                                                    \
+		f = (f >> 2) | (c << top);                                                                                               \
+		r = ((r << 2) | (c ^ 3u)) & maskm;                                                                                       \
+		const unsigned long long sfx_now = sfx;                                                                                  \
+		if ((I) + 2 < WS) sfx = win[((I) + 2) * 64]; /* for the next step; its slot is rewritten only then */                    \
+		const uint32_t cm = f < r ? f : r;                                                                                       \
+		mix = order_mix(cm);                                                                                                     \
+		win[(I) * 64] = ((unsigned long long)mix << 32) | j;                                                                     \
+		const bool newpre = (I) == 0 || mix < pre_hi;                                                                            \
+		pre_hi = newpre ? mix : pre_hi;                                                                                          \
+		pre_lo = newpre ? j : pre_lo;                                                                                            \
+		const bool use_sfx = ((I) + 1 < WS) && (uint32_t)(sfx_now >> 32) <= pre_hi;                                              \
+		const uint32_t res_lo = use_sfx ? (uint32_t)sfx_now : pre_lo;                                                                \
+		const uint32_t p = j + 1u - w; /* wraps in the first block: matches no position of any read */                           \
+		const bool changed = res_lo != cur_lo;                                                                                   \
+		const bool push = p > 0 && p <= n && (p == n || changed);                                                                \
+		const bool start = p < n && changed;                                                                                     \
+		const unsigned long long bal = __builtin_amdgcn_ballot_w64(push);                                                        \
+		if (__builtin_amdgcn_ballot_w64(push || start)) {                                                                                           \
+			if (push) {                                                                                                          \
+				const uint32_t d = dbase + ((p - 1u) << SB);                                                                     \
+				const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u)); \
+				ring[(qtail + rk) & (SKL_RING - 1)] = ((unsigned long long)cur_hi << 32) | d;                                    \
+			}                                                                                                                    \
+			qtail += (uint32_t)__popcll(bal);                                                                                    \
+			if (start) {                                                                                                         \
+				dbase = (res_lo << MO_SH) + (lane_term + p * (1u - (1u << SB) - (1u << MO_SH)));                                 \
+				cur_lo = res_lo;                                                                                                 \
+				cur_hi = use_sfx ? (uint32_t)(sfx_now >> 32) : pre_hi;                                                               \
+			}                                                                                                                    \
+			if (qtail - qhead >= 64u) {                                                                                          \
+				i0 = (I) + 1;                                                                                                    \
+				goto flush;                                                                                                      \
+			}                                                                                                                    \
+		}                                                                                                                        \
+	}                                                                                                                            \
+		[[fallthrough]];
+			switch (i0) {
+				RG_SKS_STEP(0)
+				RG_SKS_STEP(1)
+				RG_SKS_STEP(2)
+				RG_SKS_STEP(3)
+				RG_SKS_STEP(4)
+				RG_SKS_STEP(5)
+				RG_SKS_STEP(6)
+				RG_SKS_STEP(7)
+				RG_SKS_STEP(8)
+				RG_SKS_STEP(9)
+				RG_SKS_STEP(10)
+				RG_SKS_STEP(11)
+				RG_SKS_STEP(12)
+				RG_SKS_STEP(13)
+				RG_SKS_STEP(14)
+				RG_SKS_STEP(15)
+				RG_SKS_STEP(16)
+			default:
+				break;
+			}
+#undef RG_SKS_STEP
+			static_assert(WS == 17, "the switch above lists the steps of a block of 17");
+			{  // block complete: slot t becomes the minimum of entries t .. w-1 (slot 0 is nobody's S); the last entry is S[w-1] itself
+				uint32_t run_hi = mix, run_lo = jb + WS - 1;
+#pragma unroll
+				for (int q = WS - 2; q >= 1; --q) {
+					const unsigned long long v = win[q * 64];
+					const bool t = (uint32_t)(v >> 32) <= run_hi;
+					run_hi = t ? (uint32_t)(v >> 32) : run_hi;
+					run_lo = t ? (uint32_t)v : run_lo;
+					win[q * 64] = ((unsigned long long)run_hi << 32) | run_lo;
+				}
+			}
+			jb += WS;
+			i0 = 0;
+			if (jb < nsteps) continue;
+			final = true;
+		flush:
+			// assemble 64 queued records (all of them after the last step), lane per record
+			while (qtail - qhead >= 64u || (final && qtail != qhead)) {
+				const uint32_t cnt = (qtail - qhead < 64u) ? qtail - qhead : 64u;
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+				if (chunk_used + cnt > REC_CHUNK) {
+					if (have_chunk && !dead)
+						for (uint32_t q = chunk_used + lane; q < REC_CHUNK; q += 64) rec_mark_invalid(&recs[chunk_base + q]);
+					unsigned long long nbase = 0;
+					if (lane == 0) nbase = atomicAdd(&counters[PC_REC_CURSOR], (unsigned long long)REC_CHUNK);
+					nbase = __shfl(nbase, 0);
+					if (nbase + REC_CHUNK > rec_cap) {
+						dead = true;
+						if (lane == 0) atomicAdd(&counters[PC_REC_OVF], 1ull);
+					}
+					chunk_base = nbase;
+					chunk_used = 0;
+					have_chunk = true;
+				}
+				const unsigned long long d = ring[(qhead + lane) & (SKL_RING - 1)];
+				const uint32_t dl = (uint32_t)d;
+				const uint32_t pr = dl & ((1u << SB) - 1u), len = ((dl >> SB) & ((1u << LNB) - 1u)) + 1u, src = (dl >> LANE_SH) & 63u, jrel = (dl >> MO_SH) & ((1u << LNB) - 1u);
+				const uint32_t Ls = (uint32_t)__shfl((int)L, (int)src);
+				const uint64_t b0 = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(bit0 >> 32), (int)src) << 32) | (uint32_t)__shfl((int)(uint32_t)bit0, (int)src);
+				if (!dead && lane < cnt) {
+					const uint32_t ns = Ls - (uint32_t)k + 1;
+					const uint32_t hasL = pr > 0, hasR = (pr + len) < ns;
+					const uint32_t first = pr - hasL;  // read position of the record's base 0
+					const uint32_t nbases = hasL + len + (uint32_t)k - 1 + hasR;
+					const uint64_t bit = b0 + 2ull * first;
+					const uint32_t *__restrict__ wp = P32 + (bit >> 5);
+					const uint32_t sf = (uint32_t)bit & 31u;
+					const uint32_t ndw = (sf + 2u * nbases + 31u) >> 5;  // dwords that hold the record's bases
+					uint32_t a[2 * NB + 1];
+#pragma unroll
+					for (int q = 0; q < 2 * NB + 1; ++q) a[q] = ((uint32_t)q < ndw) ? wp[q] : 0u;
+					Rec<1> rec;
+#pragma unroll
+					for (int q = 0; q < NB; ++q) {
+						uint64_t word = 0;
+						if (nbases > 32u * q) {
+							word = (uint64_t)__builtin_amdgcn_alignbit(a[2 * q + 1], a[2 * q], sf) |
+							       ((uint64_t)__builtin_amdgcn_alignbit(a[2 * q + 2], a[2 * q + 1], sf) << 32);
+							const uint32_t rem = nbases - 32u * q;
+							if (rem < 32u) word &= (1ull << (2u * rem)) - 1;
+						}
+						rec.w[q] = word;
+					}
+					const uint32_t moff = jrel + hasL;
+					rec.w[NB] = (uint64_t)pr | ((uint64_t)(len - 1) << 16) | ((uint64_t)hasL << 22) | ((uint64_t)hasR << 23) |
+					            ((uint64_t)moff << 24) | ((read_id_base + rb + src) << 31);
+					const RM packed = rec_pack(rec, (RM *)nullptr);
+					recs[chunk_base + chunk_used + lane] = packed;
+					const uint32_t bk = bucket_number(order_unmix((uint32_t)(d >> 32)));
+					atomicAdd(&s_hist[modulo ? bk % modulo : bk >> hist_shift], 1u);
+					sample_record<RM>(packed, bk, sample, sample_cap, counters);
+				}
+				chunk_used += cnt;
+				qhead += cnt;
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+			}
+			if (final) break;
+			if (i0 >= WS) {  // left at the block's last step: the block is complete
+				i0 = WS;     // (the switch falls to its default and the suffix pass runs)
+			}
+		}
+	}
+	if (have_chunk && !dead)
+		for (uint32_t q = chunk_used + lane; q < REC_CHUNK; q += 64) rec_mark_invalid(&recs[chunk_base + q]);
+#pragma unroll
+	for (int d = 32; d; d >>= 1) occ += __shfl_xor(occ, d);
+	if (lane == 0 && occ) atomicAdd(&counters[2 /*C_OCC*/], occ);
+	__syncthreads();
+	if (s_hist[threadIdx.x]) atomicAdd(&coarse_hist[threadIdx.x], (unsigned long long)s_hist[threadIdx.x]);
+}
+
+// ------------------------------------------------------------------------------------------------
 // One partition level.  The input is cut into S segments (seg_begin[S+1]; level 1: the single segment
 // [0, n_in) of k_superkmers output, holes included).  A tile of SCATTER_TILE records never crosses a
 // segment (tile_first[s] = first tile of segment s).  digit = (bucket number >> shift) & (2^dbits - 1);
