@@ -1307,6 +1307,31 @@ __device__ __forceinline__ void wave_sync() {  // orders this wavefront's LDS tr
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// inclusive scans over the 64 lanes with DPP row shifts and row broadcasts (VALU only: no trip through the LDS crossbar,
+// where a __shfl_up ladder makes six dependent ones)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_or_zero(uint32_t v) {
+	return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ uint32_t wave_scan_add(uint32_t v) {
+	v += dpp_or_zero<0x111, 0xf>(v);  // row_shr:1
+	v += dpp_or_zero<0x112, 0xf>(v);  // row_shr:2
+	v += dpp_or_zero<0x114, 0xf>(v);  // row_shr:4
+	v += dpp_or_zero<0x118, 0xf>(v);  // row_shr:8
+	v += dpp_or_zero<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+	v += dpp_or_zero<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+	return v;
+}
+__device__ __forceinline__ uint32_t wave_scan_max(uint32_t v) {
+	v = max(v, dpp_or_zero<0x111, 0xf>(v));
+	v = max(v, dpp_or_zero<0x112, 0xf>(v));
+	v = max(v, dpp_or_zero<0x114, 0xf>(v));
+	v = max(v, dpp_or_zero<0x118, 0xf>(v));
+	v = max(v, dpp_or_zero<0x142, 0xa>(v));
+	v = max(v, dpp_or_zero<0x143, 0xc>(v));
+	return v;
+}
+
 template <int W>
 __device__ __forceinline__ uint32_t agg_hash(uint64_t i0, uint64_t i1) {
 	uint32_t x = (uint32_t)i0 ^ __builtin_amdgcn_alignbit((uint32_t)(i0 >> 32), (uint32_t)(i0 >> 32), 19);
@@ -1405,7 +1430,8 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<
 	__shared__ RecTable<W> s_rtables[agg_waves<W>()];
 	// 20-byte records: a round's 64 records are loaded as 5 x 64 consecutive words (whole cache lines, where a lane loading
 	// its own 20 bytes straddles them: 14.3 ms on C2 against 12.9 with the 24-byte records) and handed to their lanes through LDS
-	__shared__ uint32_t s_stage[C ? agg_waves<W>() : 1][C ? 320 : 1];
+	// (also expand()'s hand-over of a batch of records to their k-mers' lanes: 64 four-word tuples and 64 marks)
+	__shared__ __align__(16) uint32_t s_stage[agg_waves<W>()][320];
 	constexpr bool ANCH = agg_anchors<W, SLOW, SLOTS>();
 	constexpr uint32_t ANCHORS = AnchorTable<W>::N;
 	__shared__ AnchorTable<W> s_anchors[ANCH ? agg_waves<W>() : 1];
@@ -1567,30 +1593,40 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<
 					}
 				}
 			}
-			uint32_t incl = rlen;  // inclusive prefix sums of the lengths
-#pragma unroll
-			for (int d = 1; d < 64; d <<= 1) {
-				const uint32_t o = __shfl_up(incl, d);
-				if (lane >= (uint32_t)d) incl += o;
-			}
+			const uint32_t incl = wave_scan_add(rlen);  // inclusive prefix sums of the lengths
 			const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
 			const uint32_t rpre = incl - rlen;
+			// what a k-mer's lane needs of its record, handed over through LDS in one 16-byte read: slot, first k-mer's number,
+			// anchor, multiplicity, smallest stamp
+			uint32_t *const st = s_stage[wave];
+			{
+				uint4 tp;
+				tp.x = rsl | (ranch << 8) | (rpre << 16);
+				tp.y = rweight;
+				tp.z = (uint32_t)rstamp;
+				tp.w = (uint32_t)(rstamp >> 32);
+				reinterpret_cast<uint4 *>(st)[lane] = tp;
+			}
 			const bool checked = (uint32_t)__builtin_amdgcn_readfirstlane((int)T.fill) + total > LIMIT;  // else no overfill possible
 			for (uint32_t t0 = 0; t0 < total; t0 += 64) {
 				const uint32_t t = t0 + lane;
-				// owner = number of records whose prefix sum is <= t (all lanes take part in the shuffles)
-				uint32_t own = 0;
-#pragma unroll
-				for (uint32_t st = 32; st; st >>= 1) {
-					const uint32_t v = (uint32_t)__shfl((int)incl, (int)(own + st - 1));
-					if (v <= t) own += st;
-				}
-				own = own < 63u ? own : 63u;  // lanes past the last k-mer: any record will do, they do nothing
-				const uint32_t sl = (uint32_t)__shfl((int)rsl, (int)own);
-				const uint32_t i = t - (uint32_t)__shfl((int)rpre, (int)own);
-				const uint32_t weight = (uint32_t)__shfl((int)rweight, (int)own);
-				const uint32_t anch = ANCH ? (uint32_t)__shfl((int)ranch, (int)own) : ANCHORS;
-				const uint64_t stamp0 = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(rstamp >> 32), (int)own) << 32) | (uint32_t)__shfl((int)(uint32_t)rstamp, (int)own);
+				// owner of k-mer t = the last record that starts at or before it: the records that start inside this round mark
+				// their first lane (LDS), a running maximum carries the marks to the lanes behind (DPP), the record that holds
+				// t0 covers the lanes in front of the first mark.  (A binary search over the prefix sums through the lane
+				// crossbar was six dependent LDS round trips per round.)
+				st[256 + lane] = 0;
+				const bool rvalid = e < n;
+				if (rvalid && rpre >= t0 && rpre < t0 + 64u) st[256 + (rpre - t0)] = lane + 1u;
+				const uint32_t own0 = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(rvalid && rpre <= t0));  // 1-based: the record that holds t0
+				wave_sync();
+				uint32_t own = max(wave_scan_max(st[256 + lane]), own0) - 1u;
+				own = own < 63u ? own : 63u;  // (a round has a k-mer, so own0 >= 1; lanes past the last k-mer do nothing)
+				const uint4 tp = reinterpret_cast<const uint4 *>(st)[own];
+				const uint32_t sl = tp.x & 0xFFu;
+				const uint32_t i = t - (tp.x >> 16);
+				const uint32_t weight = tp.y;
+				const uint32_t anch = ANCH ? ((tp.x >> 8) & 0xFFu) : ANCHORS;
+				const uint64_t stamp0 = ((uint64_t)tp.w << 32) | tp.z;
 				if (t < total) {
 					uint64_t bw[NB];
 #pragma unroll
