@@ -514,6 +514,8 @@ def main():
                                   "GBps_over_whole_step": pass1_bytes_per_occ * occ0 / per_step / 1e9,
                                   "frac_of_hbm_peak": pass1_bytes_per_occ * occ0 / per_step / 1e9 / HBM_PEAK_GBS},
             "phases_ms_per_step": {name: sec / args.steps * 1e3 for name, sec in phases.items()},
+            "host_syncs_per_step": st.get("host_syncs"),   # times the host waited for the stream (sizes read back for the next grid / allocation)
+            "kernels_ms_per_step": sum(ms for ms, _ in kprof.values()) / args.steps,
             "after_the_timed_step_ms": after,
             "error_1pct": error_record,
             "setup_s": gen_s,

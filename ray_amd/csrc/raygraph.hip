@@ -1356,6 +1356,12 @@ struct rg_handle {
 	uint64_t export_stage_bytes = 0;
 };
 
+// every wait of the host for the handle's stream goes through here (counted: rg_stats.host_syncs)
+static inline hipError_t rg_stream_sync(rg_handle *h) {
+	h->stats.host_syncs++;
+	return hipStreamSynchronize(h->stream);
+}
+
 // brackets the launches issued during its lifetime with two HIP events on the handle's stream
 struct ProfScope {
 	rg_handle *h;
@@ -1410,7 +1416,7 @@ static uint64_t next_pow2(uint64_t x) {
 
 static int sync_counters(rg_handle *h) {
 	HIP_TRY(h, hipMemcpyAsync(h->h_counters, h->d_counters, sizeof(unsigned long long) * C_NUM, hipMemcpyDeviceToHost, h->stream));
-	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	HIP_TRY(h, rg_stream_sync(h));
 	if (h->h_counters[C_ERR]) return fail(h, RG_ERR_CAPACITY, "table probe limit reached (table full?)");
 	return RG_OK;
 }
@@ -1453,7 +1459,7 @@ static int table_reserve(rg_handle *h, Table &t, uint64_t need, int fill_counter
 	if (h->W == 1) hipLaunchKernelGGL(k_rehash<1>, dim3(grid_for(t.cap)), dim3(BLOCK), 0, h->stream, t.slots, t.cap, bigger.slots, cap, h->d_counters);
 	else hipLaunchKernelGGL(k_rehash<2>, dim3(grid_for(t.cap)), dim3(BLOCK), 0, h->stream, t.slots, t.cap, bigger.slots, cap, h->d_counters);
 	HIP_TRY(h, hipGetLastError());
-	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	HIP_TRY(h, rg_stream_sync(h));
 	pool_free(h->cfg.device, t.slots);
 	t.slots = bigger.slots;
 	t.cap = cap;
@@ -1740,7 +1746,7 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 		const uint32_t tile1[2] = {0, (uint32_t)ntiles};
 		PTRY(hipMemcpyAsync(d_seg, seg1, sizeof seg1, hipMemcpyHostToDevice, h->stream));
 		PTRY(hipMemcpyAsync(d_tile, tile1, sizeof tile1, hipMemcpyHostToDevice, h->stream));
-		PTRY(hipStreamSynchronize(h->stream));  // seg1 / tile1 live on this stack frame
+		PTRY(rg_stream_sync(h));  // seg1 / tile1 live on this stack frame
 		if (ntiles) {
 			ProfScope ps(h, "k_level_hist");
 			hipLaunchKernelGGL((k_level_hist<W, C>), dim3((unsigned)ntiles), dim3(256), 0, h->stream, (const RM *)ext, m, 1u, d_seg, d_tile, hist0_shift, 8, d_hist,
@@ -1884,7 +1890,7 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 		if (level < 2 && dbits[level + 1] > 0) {  // the next level needs this segmentation on the host
 			seg_begin.resize(nout + 1);
 			PTRY(hipMemcpyAsync(seg_begin.data(), d_begin, (nout + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-			PTRY(hipStreamSynchronize(h->stream));
+			PTRY(rg_stream_sync(h));
 			if (seg_begin[nout] != valid) {
 				cleanup();
 				return fail(h, RG_ERR_STATE, "partition level %d lost records: %llu of %llu", level, seg_begin[nout], (unsigned long long)valid);
@@ -2164,7 +2170,7 @@ static int export_records_t(rg_handle *h, void *d_out) {
 		                   (RM *)d_out, size, (uint8_t *)nullptr, 0, 0u);
 		e = hipGetLastError();
 	}
-	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+	if (e == hipSuccess) e = rg_stream_sync(h);
 	pool_free(dev, d_seg);
 	pool_free(dev, d_tile);
 	pool_free(dev, d_cur);
@@ -2263,7 +2269,7 @@ static int bloom_partitioned(rg_handle *h, Table &T, uint64_t m_bits, uint64_t k
 		if (nlevels > 1) {
 			seg_begin.resize(257);
 			BTRY(hipMemcpyAsync(seg_begin.data(), d_begin, 257 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-			BTRY(hipStreamSynchronize(h->stream));
+			BTRY(rg_stream_sync(h));
 			if (seg_begin[256] != 8 * keys) {
 				cleanup();
 				return fail(h, RG_ERR_STATE, "Bloom partition lost items: %llu of %llu", seg_begin[256], (unsigned long long)(8 * keys));
@@ -2317,7 +2323,7 @@ static int bloom_partitioned(rg_handle *h, Table &T, uint64_t m_bits, uint64_t k
 		if (level + 1 < nlevels) {
 			seg_begin.resize(nout + 1);
 			BTRY(hipMemcpyAsync(seg_begin.data(), d_begin, (nout + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-			BTRY(hipStreamSynchronize(h->stream));
+			BTRY(rg_stream_sync(h));
 			if (seg_begin[nout] != 8 * keys) {
 				cleanup();
 				return fail(h, RG_ERR_STATE, "Bloom partition lost items: %llu of %llu", seg_begin[nout], (unsigned long long)(8 * keys));
@@ -2367,7 +2373,7 @@ static int bloom_partitioned(rg_handle *h, Table &T, uint64_t m_bits, uint64_t k
 		else hipLaunchKernelGGL(k_admit_lost<2>, dim3(grid), dim3(BLOCK), 0, h->stream, T.slots, T.cap, d_lost, h->d_counters, h->d_hist_dense, h->d_hist_ovf);
 		BTRY(hipGetLastError());
 	}
-	BTRY(hipStreamSynchronize(h->stream));
+	BTRY(rg_stream_sync(h));
 	cleanup();
 	*ok = true;
 #undef BTRY
@@ -2539,7 +2545,7 @@ static int bloom_xor(rg_handle *h, Table &T, uint64_t m_bits, uint64_t keys, boo
 		if (!gaps) {
 			seg_begin.resize(S64 + 1);
 			XTRY(hipMemcpyAsync(seg_begin.data(), d_begin, (S64 + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-			XTRY(hipStreamSynchronize(h->stream));
+			XTRY(rg_stream_sync(h));
 			held = seg_begin[S64];
 		} else {
 			for (uint64_t d = 0; d < S64; ++d) held += seg_fill[d] - seg_begin[d];
@@ -2640,7 +2646,7 @@ static int bloom_xor(rg_handle *h, Table &T, uint64_t m_bits, uint64_t keys, boo
 		else hipLaunchKernelGGL(k_admit_lost<2>, dim3(grid), dim3(BLOCK), 0, h->stream, T.slots, T.cap, (const uint32_t *)d_lost, h->d_counters, h->d_hist_dense, h->d_hist_ovf);
 		XTRY(hipGetLastError());
 	}
-	XTRY(hipStreamSynchronize(h->stream));
+	XTRY(rg_stream_sync(h));
 	if (keep_lost) {
 		*keep_lost = d_lost;
 		d_lost = nullptr;
@@ -2863,7 +2869,7 @@ static int build_table_ranges(rg_handle *h, const Slot *log, uint64_t n_log, uin
 		if (level + 1 < nlev) {
 			seg_begin.resize(nout + 1);
 			TTRY(hipMemcpyAsync(seg_begin.data(), d_begin, (nout + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-			TTRY(hipStreamSynchronize(h->stream));
+			TTRY(rg_stream_sync(h));
 			if (seg_begin[nout] != retained) {
 				cleanup();
 				pool_free(dev, tab);
@@ -3026,7 +3032,7 @@ int rg_create(const rg_config *cfg, rg_handle **out) {
 int rg_destroy(rg_handle *h) {
 	if (!h) return RG_OK;
 	(void)hipSetDevice(h->cfg.device);
-	if (h->stream) (void)hipStreamSynchronize(h->stream);
+	if (h->stream) (void)rg_stream_sync(h);
 	for (auto &kv : h->prof)
 		for (auto &p : kv.second) {
 			(void)hipEventDestroy(p.first);
@@ -3078,7 +3084,7 @@ int rg_add_reads(rg_handle *h, const uint8_t *packed, uint64_t packed_bytes, con
 	HIP_TRY(h, hipMemcpyAsync(gp.p, packed, packed_bytes, hipMemcpyHostToDevice, h->stream));
 	HIP_TRY(h, hipMemcpyAsync(gof.p, byte_offsets, n_reads * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
 	HIP_TRY(h, hipMemcpyAsync(gl.p, lengths, n_reads * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
-	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	HIP_TRY(h, rg_stream_sync(h));
 	b.d_packed = (const uint64_t *)gp.release();  // the handle owns them from here (rg_destroy frees owned batches)
 	b.d_off = (const uint64_t *)gof.release();
 	b.d_len = (const uint32_t *)gl.release();
@@ -3299,7 +3305,7 @@ int rg_owner_counts(rg_handle *h, uint64_t *counts) {
 	HIP_TRY(h, hipGetLastError());
 	std::vector<unsigned long long> tmp(size);
 	HIP_TRY(h, hipMemcpyAsync(tmp.data(), h->d_owner, sizeof(unsigned long long) * size, hipMemcpyDeviceToHost, h->stream));
-	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	HIP_TRY(h, rg_stream_sync(h));
 	for (uint32_t r = 0; r < size; ++r) h->owner_counts[r] = counts[r] = tmp[r];
 	h->owner_counts_valid = true;
 	return RG_OK;
@@ -3326,7 +3332,7 @@ int rg_export_owner_buckets(rg_handle *h, void *d_out, uint64_t capacity_entries
 	if (h->W == 1) hipLaunchKernelGGL(k_owner_scatter<1>, dim3(grid_for(T.cap)), dim3(BLOCK), size * 12, h->stream, T.slots, T.cap, size, h->d_owner + size, (Slot *)d_out);
 	else hipLaunchKernelGGL(k_owner_scatter<2>, dim3(grid_for(T.cap)), dim3(BLOCK), size * 12, h->stream, T.slots, T.cap, size, h->d_owner + size, (Slot *)d_out);
 	HIP_TRY(h, hipGetLastError());
-	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	HIP_TRY(h, rg_stream_sync(h));
 	return RG_OK;
 }
 
@@ -3354,7 +3360,7 @@ int rg_merge_entries(rg_handle *h, const void *d_entries, uint64_t n_entries) {
 		Slot *copy = nullptr;
 		Slot first;  // entries of the entry route carry no mark: one look spares them the copy
 		HIP_TRY(h, hipMemcpyAsync(&first, d_entries, sizeof(Slot), hipMemcpyDeviceToHost, h->stream));
-		HIP_TRY(h, hipStreamSynchronize(h->stream));
+		HIP_TRY(h, rg_stream_sync(h));
 		if ((first.meta & LOG_UNIQUE) && pool_alloc(h->cfg.device, (void **)&copy, n_entries * sizeof(Slot)) == hipSuccess) {
 			hipError_t e = hipMemsetAsync(h->d_counters + C_ADOPT_BAD, 0, sizeof(unsigned long long), h->stream);
 			if (e == hipSuccess) {
@@ -3387,7 +3393,7 @@ int rg_merge_entries(rg_handle *h, const void *d_entries, uint64_t n_entries) {
 	else hipLaunchKernelGGL(k_merge<2>, dim3(grid_for(n_entries)), dim3(BLOCK), 0, h->stream, (const Slot *)d_entries, n_entries, h->tab.slots, h->tab.cap, h->d_counters);
 	HIP_TRY(h, hipGetLastError());
 	h->tab.fill_pending += n_entries;
-	HIP_TRY(h, hipStreamSynchronize(h->stream));  // the caller may now reuse d_entries
+	HIP_TRY(h, rg_stream_sync(h));  // the caller may now reuse d_entries
 	return RG_OK;
 }
 
@@ -3397,7 +3403,7 @@ int rg_release_local(rg_handle *h) {
 	if (h->phase != PH_COUNTED_LOCAL) return fail(h, RG_ERR_STATE, "rg_release_local needs rg_count_local / rg_count_records first");
 	if (h->cfg.size == 1 && !h->local.slots) return fail(h, RG_ERR_STATE, "rg_release_local: on one rank the local table is the partition");
 	HIP_TRY(h, hipSetDevice(h->cfg.device));
-	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	HIP_TRY(h, rg_stream_sync(h));
 	h->owner_counts_valid = false;
 	table_free(h, h->local);
 	h->phase = PH_MERGING;
@@ -3416,7 +3422,7 @@ int rg_adopt_entries(rg_handle *h, void *d_entries, uint64_t n_entries) {
 	if (in_place) {  // entries of the entry route carry no mark: one look at the first spares them a pass over the buffer
 		Slot first;
 		HIP_TRY(h, hipMemcpyAsync(&first, d_entries, sizeof(Slot), hipMemcpyDeviceToHost, h->stream));
-		HIP_TRY(h, hipStreamSynchronize(h->stream));
+		HIP_TRY(h, rg_stream_sync(h));
 		in_place = (first.meta & LOG_UNIQUE) != 0;
 	}
 	if (in_place) {
@@ -3548,7 +3554,7 @@ int rg_resolve_admission(rg_handle *h, uint64_t local_reads_for_bloom) {
 			}
 			e = hipGetLastError();
 		}
-		hipError_t e2 = hipStreamSynchronize(h->stream);
+		hipError_t e2 = rg_stream_sync(h);
 		pool_free(h->cfg.device, bitstamp);  // the reference destroys its filter here too (MessageProcessor.cpp:1010)
 		if (e != hipSuccess) return fail(h, RG_ERR_HIP, "Bloom resolution failed: %s", hipGetErrorString(e));
 		if (e2 != hipSuccess) return fail(h, RG_ERR_HIP, "Bloom resolution failed: %s", hipGetErrorString(e2));
@@ -3593,7 +3599,7 @@ int rg_resolve_admission(rg_handle *h, uint64_t local_reads_for_bloom) {
 			if (hipGetLastError() != hipSuccess) rc = fail(h, RG_ERR_HIP, "k_admit_lost launch failed");
 		}
 		if (lost_kept) {
-			(void)hipStreamSynchronize(h->stream);
+			(void)rg_stream_sync(h);
 			pool_free(h->cfg.device, lost_kept);
 			pool_free(h->cfg.device, d_first_hist);
 			lost_kept = nullptr;
@@ -3686,7 +3692,7 @@ int rg_purge_edges(rg_handle *h) {
 	if (h->W == 1) hipLaunchKernelGGL(k_purge<1>, dim3(grid_for(h->tab.cap)), dim3(BLOCK), 0, h->stream, h->tab.slots, h->tab.cap, h->cfg.k);
 	else hipLaunchKernelGGL(k_purge<2>, dim3(grid_for(h->tab.cap)), dim3(BLOCK), 0, h->stream, h->tab.slots, h->tab.cap, h->cfg.k);
 	HIP_TRY(h, hipGetLastError());
-	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	HIP_TRY(h, rg_stream_sync(h));
 	h->phase = PH_PURGED;
 	return RG_OK;
 }
@@ -3705,7 +3711,7 @@ int rg_purge_query_counts(rg_handle *h, uint64_t *counts) {
 	HIP_TRY(h, hipGetLastError());
 	std::vector<unsigned long long> tmp(size);
 	HIP_TRY(h, hipMemcpyAsync(tmp.data(), h->d_owner, sizeof(unsigned long long) * size, hipMemcpyDeviceToHost, h->stream));
-	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	HIP_TRY(h, rg_stream_sync(h));
 	h->purge_counts.assign(tmp.begin(), tmp.end());
 	h->purge_total = 0;
 	for (uint32_t r = 0; r < size; ++r) {
@@ -3743,7 +3749,7 @@ int rg_purge_export_queries(rg_handle *h, void *d_queries, uint64_t cap_queries)
 		else hipLaunchKernelGGL((k_purge_queries<2, true>), dim3(grid_for(h->tab.cap)), dim3(BLOCK), 0, h->stream, h->tab.slots, h->tab.cap, h->cfg.k, size, h->d_owner + size, (uint64_t *)d_queries, h->d_purge_origin);
 	}
 	HIP_TRY(h, hipGetLastError());
-	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	HIP_TRY(h, rg_stream_sync(h));
 	return RG_OK;
 }
 
@@ -3758,7 +3764,7 @@ int rg_purge_answer(rg_handle *h, const void *d_queries, uint64_t n, uint8_t *d_
 		else hipLaunchKernelGGL(k_purge_answer<2>, dim3(grid_for(n)), dim3(BLOCK), 0, h->stream, h->tab.slots, h->tab.cap, (const uint64_t *)d_queries, n, d_answers);
 	}
 	HIP_TRY(h, hipGetLastError());
-	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	HIP_TRY(h, rg_stream_sync(h));
 	return RG_OK;
 }
 
@@ -3772,7 +3778,7 @@ int rg_purge_apply(rg_handle *h, const uint8_t *d_answers, uint64_t n) {
 		hipLaunchKernelGGL(k_purge_apply, dim3(grid_for(n)), dim3(BLOCK), 0, h->stream, h->tab.slots, h->d_purge_origin, d_answers, n);
 		HIP_TRY(h, hipGetLastError());
 	}
-	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	HIP_TRY(h, rg_stream_sync(h));
 	pool_free(h->cfg.device, h->d_purge_origin);
 	h->d_purge_origin = nullptr;
 	h->purge_counts.clear();
@@ -3805,7 +3811,7 @@ static int export_to_device(rg_handle *h, uint8_t **d_out_p) {
 	HIP_TRY(h, hipGetLastError());
 	std::vector<unsigned long long> hc(nchunks);
 	HIP_TRY(h, hipMemcpyAsync(hc.data(), d_chunk, nchunks * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	HIP_TRY(h, rg_stream_sync(h));
 	unsigned long long run = 0;
 	for (auto &c : hc) {
 		unsigned long long t = c;
@@ -3817,7 +3823,7 @@ static int export_to_device(rg_handle *h, uint8_t **d_out_p) {
 	if (h->W == 1) hipLaunchKernelGGL(k_export_write<1>, dim3((int)nchunks), dim3(BLOCK), 0, h->stream, h->tab.slots, cap, chunk, d_chunk, d_out, h->phase >= PH_EDGES ? 0xFFu : 0u);
 	else hipLaunchKernelGGL(k_export_write<2>, dim3((int)nchunks), dim3(BLOCK), 0, h->stream, h->tab.slots, cap, chunk, d_chunk, d_out, h->phase >= PH_EDGES ? 0xFFu : 0u);
 	HIP_TRY(h, hipGetLastError());
-	HIP_TRY(h, hipStreamSynchronize(h->stream));  // d_chunk goes back to the pool with this scope
+	HIP_TRY(h, rg_stream_sync(h));  // d_chunk goes back to the pool with this scope
 	*d_out_p = (uint8_t *)g_out.release();
 	return RG_OK;
 }
@@ -3834,7 +3840,7 @@ int rg_export(rg_handle *h, void *host_buf, uint64_t cap_records, uint64_t *n_re
 	uint8_t *d_out = nullptr;
 	if (int rc = export_to_device(h, &d_out)) return rc;
 	hipError_t e = hipMemcpyAsync(host_buf, d_out, n * rec, hipMemcpyDeviceToHost, h->stream);
-	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+	if (e == hipSuccess) e = rg_stream_sync(h);
 	pool_free(h->cfg.device, d_out);
 	if (e != hipSuccess) return fail(h, RG_ERR_HIP, "export failed: %s", hipGetErrorString(e));
 	return RG_OK;
@@ -3885,7 +3891,7 @@ int rg_export_stream(rg_handle *h, uint64_t chunk_records, rg_export_fn consume,
 		if (e == hipSuccess && c + 1 < nchunks) e = issue(c + 1);  // the other buffer: the consumer finished with it one round ago
 		if (e == hipSuccess) stop = consume(user, h->export_stage[c & 1], std::min(chunk_records, n - c * chunk_records));
 	}
-	(void)hipStreamSynchronize(h->stream);
+	(void)rg_stream_sync(h);
 	for (int i = 0; i < 2; ++i)
 		if (done[i]) (void)hipEventDestroy(done[i]);
 	pool_free(h->cfg.device, d_out);
@@ -3915,7 +3921,7 @@ int rg_find(rg_handle *h, const uint64_t *kmers, uint64_t n, uint32_t *coverage,
 	}
 	if (e == hipSuccess) e = hipMemcpyAsync(coverage, dc, n * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream);
 	if (e == hipSuccess) e = hipMemcpyAsync(edges, de, n, hipMemcpyDeviceToHost, h->stream);
-	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+	if (e == hipSuccess) e = rg_stream_sync(h);
 	if (e != hipSuccess) return fail(h, RG_ERR_HIP, "find failed: %s", hipGetErrorString(e));
 	return RG_OK;
 }
@@ -3976,7 +3982,7 @@ int rg_add_reads_text(rg_handle *h, const char *text, uint64_t text_bytes, const
 		e = hipGetLastError();
 	}
 	if (e == hipSuccess) e = hipMemcpyAsync(&total, d_off + n_reads, sizeof total, hipMemcpyDeviceToHost, h->stream);
-	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+	if (e == hipSuccess) e = rg_stream_sync(h);
 	const uint64_t padded = ((total + 7) / 8) * 8 + 16;
 	A((void **)&d_packed, padded);
 	if (e == hipSuccess) e = hipMemsetAsync(d_packed + (padded - 24), 0, 24, h->stream);
@@ -3987,7 +3993,7 @@ int rg_add_reads_text(rg_handle *h, const char *text, uint64_t text_bytes, const
 	}
 	std::vector<uint32_t> tl(n_reads);
 	if (e == hipSuccess) e = hipMemcpyAsync(tl.data(), d_tlen, n_reads * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream);
-	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+	if (e == hipSuccess) e = rg_stream_sync(h);
 	if (e != hipSuccess) {
 		(void)hipGetLastError();
 		cleanup(false);
@@ -4096,7 +4102,7 @@ int rg_read_markers(rg_handle *h, int32_t *d_forward, int32_t *d_reverse) {
 		HIP_TRY(h, hipGetLastError());
 		done += b.n;
 	}
-	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	HIP_TRY(h, rg_stream_sync(h));
 	return RG_OK;
 }
 
@@ -4117,7 +4123,7 @@ int rg_hash_kmers(rg_handle *h, const uint64_t *kmers, uint64_t n, uint64_t *has
 	HIP_TRY(h, hipGetLastError());
 	HIP_TRY(h, hipMemcpyAsync(hash1_out, g1.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
 	HIP_TRY(h, hipMemcpyAsync(hash2_out, g2.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
-	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	HIP_TRY(h, rg_stream_sync(h));
 	return RG_OK;
 }
 
@@ -4225,7 +4231,7 @@ int rg_markers_query_counts_part(rg_handle *h, uint32_t part, uint32_t nparts, u
 	}
 	std::vector<unsigned long long> tmp(size);
 	HIP_TRY(h, hipMemcpyAsync(tmp.data(), h->d_owner, sizeof(unsigned long long) * size, hipMemcpyDeviceToHost, h->stream));
-	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	HIP_TRY(h, rg_stream_sync(h));
 	h->marker_counts.assign(tmp.begin(), tmp.end());
 	h->marker_total = 0;
 	for (uint32_t r = 0; r < size; ++r) {
@@ -4271,7 +4277,7 @@ int rg_markers_export_queries(rg_handle *h, void *d_queries, uint64_t cap_querie
 		HIP_TRY(h, hipGetLastError());
 		done += n;
 	}
-	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	HIP_TRY(h, rg_stream_sync(h));
 	return RG_OK;
 }
 
@@ -4286,7 +4292,7 @@ int rg_markers_answer(rg_handle *h, const void *d_queries, uint64_t n, uint32_t 
 		else hipLaunchKernelGGL(k_marker_answer<2>, dim3(grid_for(n)), dim3(BLOCK), 0, h->stream, h->tab.slots, h->tab.cap, (const uint64_t *)d_queries, n, d_coverage);
 	}
 	HIP_TRY(h, hipGetLastError());
-	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	HIP_TRY(h, rg_stream_sync(h));
 	return RG_OK;
 }
 
@@ -4312,7 +4318,7 @@ int rg_markers_apply(rg_handle *h, const uint32_t *d_coverage, uint64_t n, int32
 		}
 		before += b.n;
 	}
-	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+	if (e == hipSuccess) e = rg_stream_sync(h);
 	markers_free(h);
 	if (e != hipSuccess) return fail(h, RG_ERR_HIP, "rg_markers_apply: %s", hipGetErrorString(e));
 	return RG_OK;
@@ -4357,7 +4363,7 @@ int rg_degree_distribution(rg_handle *h, uint64_t out[25]) {
 	hipLaunchKernelGGL(k_degrees, dim3(grid_for(h->tab.cap)), dim3(BLOCK), 0, h->stream, h->tab.slots, h->tab.cap, d, h->phase >= PH_EDGES ? 0xFFu : 0u);
 	unsigned long long tmp[25];
 	hipError_t e = hipMemcpyAsync(tmp, d, sizeof tmp, hipMemcpyDeviceToHost, h->stream);
-	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+	if (e == hipSuccess) e = rg_stream_sync(h);
 	pool_free(h->cfg.device, d);
 	if (e != hipSuccess) return fail(h, RG_ERR_HIP, "degree distribution failed: %s", hipGetErrorString(e));
 	for (int i = 0; i < 25; ++i) out[i] = tmp[i];
@@ -4393,7 +4399,7 @@ int rg_set_profiling(rg_handle *h, int enable) {
 int rg_get_kernel_profile(rg_handle *h, char *buf, uint64_t cap) {
 	if (!h || !buf || cap == 0) return RG_ERR_ARG;
 	HIP_TRY(h, hipSetDevice(h->cfg.device));
-	HIP_TRY(h, hipStreamSynchronize(h->stream));
+	HIP_TRY(h, rg_stream_sync(h));
 	std::string out;
 	for (auto &kv : h->prof) {
 		double ms = 0;
