@@ -402,7 +402,8 @@ int rg_release_cached_memory(void);
  *   bit  27    keep super-k-mer records in their 24-byte form where the 20-byte one applies (k <= 31)
  *   bit  28    key partitions: size the first level's ranges from a histogram pass instead of in advance
  *   bit  29    key partitions: the dense region kernel even on a sparse filter
- *   bit  30    cut the records of k = 31 with the generic lane-per-read kernel instead of the one unrolled for its window */
+ *   bit  30    cut the records of k = 31 with the generic lane-per-read kernel instead of the one unrolled for its window
+ *   bit  31    count the record sample's distinct k-mers with a nested sweep instead of one set-insertion launch */
 int rg_debug_set(rg_handle *h, uint32_t flags);
 
 /* ---- profiling (the reference's MACRO_COLLECT_PROFILING_INFORMATION probes,

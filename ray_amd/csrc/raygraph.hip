@@ -1723,7 +1723,7 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 		d_sample = nullptr;  // no sample, no harm: the rule of thumb above stands
 	}
 	PTRY(hipMemsetAsync(d_hist, 0, 256 * sizeof(unsigned long long), h->stream));
-	PTRY(hipMemsetAsync(h->d_counters + PC_REC_CURSOR, 0, 9 * sizeof(unsigned long long), h->stream));
+	PTRY(hipMemsetAsync(h->d_counters + PC_REC_CURSOR, 0, 11 * sizeof(unsigned long long), h->stream));
 	// 1. reads -> records.  The kernel that sees every record first (the one that cuts them, or for records received from
 	// other ranks a histogram pass) counts them by the top 8 bits below `top` -- the first level's digits are the top
 	// dbits[0] <= 8 of those, its histogram a fold of this one -- and copies the sample aside.
@@ -1754,8 +1754,24 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 		}
 		PTRY(hipGetLastError());
 	}
+	// the sample's distinct k-mers, counted behind the kernel that took it and read back with the same round trip
+	unsigned long long *d_sset = nullptr;
+	if (d_sample && !(h->dbg & 0x80000000u)) {  // rg_debug_set bit 31: count them with a nested sweep over the sample instead (tests)
+		const uint64_t sset_cap = next_pow2(4 * (occ_bound >> SAMPLE_BITS) + (1ull << 16));
+		if (pool_alloc(dev, (void **)&d_sset, sset_cap * sizeof(unsigned long long)) == hipSuccess) {
+			PTRY(hipMemsetAsync(d_sset, 0xFF, sset_cap * sizeof(unsigned long long), h->stream));
+			ProfScope ps(h, "k_sample_distinct");
+			hipLaunchKernelGGL((k_sample_distinct<W, C>), dim3(grid_for(sample_cap)), dim3(256), 0, h->stream, d_sample, sample_cap, k, d_sset, sset_cap, h->d_counters);
+			PTRY(hipGetLastError());
+		} else {
+			(void)hipGetLastError();
+			d_sset = nullptr;
+		}
+	}
 	PTRY(hipMemcpyAsync(hist0.data(), d_hist, 256 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
 	rc = sync_counters(h);
+	const bool sset_used = d_sset != nullptr;
+	pool_free(dev, d_sset);  // (the stream has drained)
 	if (rc) {
 		cleanup();
 		return rc;
@@ -1783,25 +1799,32 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	if (d_sample) {
 		const uint64_t n_sample = h->h_counters[PC_SAMPLE];
 		if (n_sample && n_sample <= sample_cap) {
-			Slot *slog = nullptr;
-			uint64_t sn = 0;
 			bool sok = false;
-			h->prof_alias = "sample_sweep";
-			const int src = sweep_partitioned_t<W, C>(h, &slog, &sn, &sok, d_sample, n_sample, BUCKET_TOP - SAMPLE_BITS, 12);
-			h->prof_alias = nullptr;
-			pool_free(dev, slog);
-			if (src != RG_OK) {
-				cleanup();
-				return src;
+			unsigned long long sample_keys = 0;
+			if (sset_used && rc == RG_OK && h->h_counters[PC_SAMPLE_FAIL] == 0) {
+				sample_keys = h->h_counters[PC_SAMPLE_DISTINCT];
+				sok = true;
+			} else {  // no room for the set, or the set too full: the sample goes through a small sweep of its own
+				Slot *slog = nullptr;
+				uint64_t sn = 0;
+				h->prof_alias = "sample_sweep";
+				const int src = sweep_partitioned_t<W, C>(h, &slog, &sn, &sok, d_sample, n_sample, BUCKET_TOP - SAMPLE_BITS, 12);
+				h->prof_alias = nullptr;
+				pool_free(dev, slog);
+				if (src != RG_OK) {
+					cleanup();
+					return src;
+				}
+				sample_keys = h->h_counters[PC_LOG_KEYS];
 			}
 			if (sok) {
-				const double distinct = (double)h->h_counters[PC_LOG_KEYS] * (double)(1u << SAMPLE_BITS);
+				const double distinct = (double)sample_keys * (double)(1u << SAMPLE_BITS);
 				sample_distinct = distinct;
 				int want = bits;
 				while (want < MAX_BUCKET_BITS && distinct / (double)(1ull << want) > (double)AGG_TARGET) want++;
 				if (getenv("RG_DEBUG"))
 					fprintf(stderr, "[raygraph] record sample: %llu records, %llu distinct k-mers -> %.3g in all, 2^%d buckets (rule of thumb 2^%d)\n",
-					        (unsigned long long)n_sample, (unsigned long long)h->h_counters[PC_LOG_KEYS], distinct, want, bits);
+					        (unsigned long long)n_sample, sample_keys, distinct, want, bits);
 				if (want != bits) {
 					bits = want;
 					split_levels();

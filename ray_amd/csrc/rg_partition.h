@@ -189,7 +189,7 @@ __device__ __forceinline__ uint32_t rec_bucket(const Rec20 &c, int m) {  // W ==
 	return bucket_number(canon_mmer(f, m));
 }
 
-enum PartCounter { PC_REC_CURSOR = 16, PC_REC_OVF, PC_LOG_CURSOR, PC_LOG_OVF, PC_LDS_SPILL, PC_AGG_RETRY, PC_NONUNIQUE, PC_LOG_KEYS, PC_SAMPLE, PC_CUT_ANCHORED = 30, PC_CUT_EXPANDED = 31 };
+enum PartCounter { PC_REC_CURSOR = 16, PC_REC_OVF, PC_LOG_CURSOR, PC_LOG_OVF, PC_LDS_SPILL, PC_AGG_RETRY, PC_NONUNIQUE, PC_LOG_KEYS, PC_SAMPLE, PC_SAMPLE_DISTINCT, PC_SAMPLE_FAIL, PC_CUT_ANCHORED = 30, PC_CUT_EXPANDED = 31 };
 
 // The sample of the records that sizes the partition: the records whose bucket number has its top SAMPLE_BITS bits clear,
 // i.e. the first 2^(b - SAMPLE_BITS) buckets of a partition into 2^b, whole (the bucket number is a hash: 1 / 4096 of the
@@ -2427,6 +2427,63 @@ __global__ __launch_bounds__(THREADS) void k_aggregate_wg(const RecMem<W, C> *__
 
 // Fallback of the record path: every k-mer of every record goes straight to the vertex table (one upsert per
 // occurrence), used when an estimate of the partitioned path was exceeded.
+// The distinct k-mers of the record sample, counted in ONE launch right behind the kernel that took the sample (its size is
+// read from the device: no host round trip in between): every k-mer of every sampled record claims a slot of a small
+// open-addressing set of 64-bit keys (two-word keys: a 64-bit mix of both words; a collision there would cost the estimate one
+// k-mer).  counters[PC_SAMPLE_DISTINCT] += new keys; counters[PC_SAMPLE_FAIL] when the set is too full to be trusted.
+// (A nested partitioned sweep over the sample gave the same number through six host round trips and a dozen launches.)
+template <int W, bool C>
+__global__ __launch_bounds__(256) void k_sample_distinct(const RecMem<W, C> *__restrict__ sample, uint64_t sample_cap, int k,
+                                                         unsigned long long *__restrict__ set, uint64_t set_cap /* power of two */,
+                                                         unsigned long long *__restrict__ counters) {
+	constexpr int NB = 2 * W;
+	const uint64_t n = counters[PC_SAMPLE] < sample_cap ? counters[PC_SAMPLE] : sample_cap;
+	const uint64_t mask0 = (2 * k >= 64) ? ~0ull : ((1ull << (2 * k)) - 1);
+	const uint64_t mask1 = (k > 32) ? ((1ull << (2 * k - 64)) - 1) : 0ull;
+	uint32_t fresh = 0;
+	bool failed = false;
+	for (uint64_t ri = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; ri < n; ri += (uint64_t)gridDim.x * blockDim.x) {
+		const Rec<W> rec = rec_unpack(sample[ri]);
+		if (rec.w[NB] == REC_INVALID) continue;
+		uint64_t bw[NB];
+#pragma unroll
+		for (int i = 0; i < NB; ++i) bw[i] = rec.w[i];
+		const uint64_t hdr = rec.w[NB];
+		const uint32_t len = ((uint32_t)(hdr >> 16) & 63u) + 1;
+		const uint32_t hasL = (uint32_t)(hdr >> 22) & 1u;
+		for (uint32_t i = 0; i < len; ++i) {
+			uint64_t f0 = rec_ext<W>(bw, hasL + i) & mask0, f1 = 0, r0, r1;
+			if (W == 2 && k > 32) f1 = rec_ext<W>(bw, hasL + i + 32) & mask1;
+			revcomp<W>(f0, f1, k, r0, r1);
+			const bool use_rc = kmer_less<W>(r0, r1, f0, f1);
+			uint64_t key = use_rc ? r0 : f0;
+			if (W == 2) key = (key ^ ((use_rc ? r1 : f1) * 0x9E3779B97F4A7C15ull)) * 0xC2B2AE3D27D4EB4Full;
+			if (key == ~0ull) key = 0;  // ~0 marks a free slot
+			uint64_t h = key * 0xBF58476D1CE4E5B9ull;
+			h ^= h >> 31;
+			uint64_t s = h & (set_cap - 1);
+			uint32_t probe = 0;
+			for (; probe < 256; ++probe) {
+				unsigned long long cur = set[s];
+				if (cur == ~0ull) {
+					cur = atomicCAS(&set[s], ~0ull, (unsigned long long)key);
+					if (cur == ~0ull) {
+						fresh++;
+						break;
+					}
+				}
+				if (cur == key) break;
+				s = (s + 1) & (set_cap - 1);
+			}
+			if (probe == 256) failed = true;
+		}
+	}
+#pragma unroll
+	for (int d = 32; d; d >>= 1) fresh += __shfl_xor(fresh, d);
+	if ((threadIdx.x & 63u) == 0 && fresh) atomicAdd(&counters[PC_SAMPLE_DISTINCT], (unsigned long long)fresh);
+	if (failed) atomicAdd(&counters[PC_SAMPLE_FAIL], 1ull);
+}
+
 template <int W, bool C = false>
 __global__ __launch_bounds__(256) void k_count_records(const RecMem<W, C> *__restrict__ recs, uint64_t n, int k, Slot *__restrict__ tab,
                                                        uint64_t cap, unsigned long long *__restrict__ counters, int c_fill) {
