@@ -1494,14 +1494,14 @@ struct SuperkmerLaunch {
 		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (k_superkmers<W, C>), 256, 0) != hipSuccess || occ < 1) occ = 4;
 		grid_wave = (int)std::min<uint64_t>((uint64_t)n_cu * occ, std::max<uint64_t>(1, (total_reads + 255) / 256));
 		grid_lane = 0;
-		if (w <= SKL_HOST_MAX_W && w <= SKL_MAX_W && !(h->dbg & 0x10000) && !getenv("RG_EXP_SKL_WIDE")) {
+		if (w <= SKL_HOST_MAX_W && w <= SKL_MAX_W && !(h->dbg & 0x10000)) {
 			lds_lane = (size_t)4 * w * 64 * sizeof(unsigned long long);
 			int occl = 0;
 			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occl, (k_superkmers_lanes<W, false, C>), 256, lds_lane) == hipSuccess && occl >= 1)
 				grid_lane = (int)std::min<uint64_t>((uint64_t)n_cu * occl, std::max<uint64_t>(1, (total_reads + 255) / 256));
 			if constexpr (W == 1) {  // rg_debug_set bit 30 keeps the generic kernel (tests)
 				int occs = 0;
-				if (w == 17 && grid_lane > 0 && !(h->dbg & 0x40000000u) && !getenv("RG_EXP_SKL_GENERIC") &&
+				if (w == 17 && grid_lane > 0 && !(h->dbg & 0x40000000u) &&
 				    hipOccupancyMaxActiveBlocksPerMultiprocessor(&occs, (k_superkmers_lanes_s<17, C>), 256, lds_lane) == hipSuccess && occs >= 1) {
 					grid_lane = (int)std::min<uint64_t>((uint64_t)n_cu * occs, std::max<uint64_t>(1, (total_reads + 255) / 256));
 					unrolled = true;

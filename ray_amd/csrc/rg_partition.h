@@ -228,6 +228,12 @@ static constexpr uint32_t SK_WORDS = 24;  // staged 32-bit words: 2 * (1 + 128 +
 // bijective; 0 (poly-A) must not map to the minimum.  One multiplication: the order is decided by the top bits of the
 // product, and those depend on every bit of c (a second round of mixing would only help the low bits, and 32-bit
 // multiplications are quarter rate: the super-k-mer kernels are bound by instruction issue)
+// the first active lane's value as a wave-uniform (scalar) one: what is indexed from it is addressed with scalar arithmetic
+// (a __shfl from lane 0 leaves it in a vector register: 64-bit multiply-adds per lane for every record address)
+__device__ __forceinline__ unsigned long long wave_first(unsigned long long v) {
+	return ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) |
+	       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+}
 __device__ __forceinline__ uint32_t order_mix(uint32_t c) { return (c ^ 0x5bd1e995u) * 0x9E3779B1u; }
 
 template <int W, bool C = false>
@@ -369,7 +375,7 @@ __global__ __launch_bounds__(256) void k_superkmers(const uint64_t *__restrict__
 						for (uint32_t q = chunk_used + lane; q < REC_CHUNK; q += 64) rec_mark_invalid(&recs[chunk_base + q]);
 					unsigned long long nbase = 0;
 					if (lane == 0) nbase = atomicAdd(&counters[PC_REC_CURSOR], (unsigned long long)REC_CHUNK);
-					nbase = __shfl(nbase, 0);
+					nbase = wave_first(nbase);
 					if (nbase + REC_CHUNK > rec_cap) {
 						dead = true;
 						if (lane == 0) atomicAdd(&counters[PC_REC_OVF], 1ull);
@@ -648,7 +654,7 @@ __global__ __launch_bounds__(256) void k_superkmers_lanes(const uint64_t *__rest
 							for (uint32_t q = chunk_used + lane; q < REC_CHUNK; q += 64) rec_mark_invalid(&recs[chunk_base + q]);
 						unsigned long long nbase = 0;
 						if (lane == 0) nbase = atomicAdd(&counters[PC_REC_CURSOR], (unsigned long long)REC_CHUNK);
-						nbase = __shfl(nbase, 0);
+						nbase = wave_first(nbase);
 						if (nbase + REC_CHUNK > rec_cap) {
 							dead = true;
 							if (lane == 0) atomicAdd(&counters[PC_REC_OVF], 1ull);
@@ -907,7 +913,7 @@ __global__ __launch_bounds__(256) void k_superkmers_lanes_s(const uint64_t *__re
 						for (uint32_t q = chunk_used + lane; q < REC_CHUNK; q += 64) rec_mark_invalid(&recs[chunk_base + q]);
 					unsigned long long nbase = 0;
 					if (lane == 0) nbase = atomicAdd(&counters[PC_REC_CURSOR], (unsigned long long)REC_CHUNK);
-					nbase = __shfl(nbase, 0);
+					nbase = wave_first(nbase);
 					if (nbase + REC_CHUNK > rec_cap) {
 						dead = true;
 						if (lane == 0) atomicAdd(&counters[PC_REC_OVF], 1ull);
@@ -1497,7 +1503,7 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<
 				new_dst = atomicAdd(&counters[PC_LOG_CURSOR], (unsigned long long)LOG_CHUNK);
 				if (new_dst + LOG_CHUNK > log_cap) atomicAdd(&counters[PC_LOG_OVF], 1ull);
 			}
-			new_dst = __shfl(new_dst, 0);
+			new_dst = wave_first(new_dst);
 			if (new_dst + LOG_CHUNK > log_cap) log_full = true;  // the launch is void: this wavefront stops after this bucket
 		}
 		for (uint32_t i = lane; i < n; i += 64) {
