@@ -481,25 +481,50 @@ __global__ __launch_bounds__(THREADS) void k_xor_region_sparse(const unsigned lo
 // Tried and dropped for crowded filters, where a quarter of the keys end here: the marks written from a list sorted by
 // stretch of the log (a pass that lists, a tile sort, a pass that marks): 21 + 17 ms against 40 on C5's share, 9.5 + 5.5
 // against 10.7 on C2 with 1 % errors -- the scattered bytes were not what the time went on.
+// One position per lane and trip kept 512 bytes per wavefront in flight: 1.9 TB/s on C2 with 1 % errors (8.3 ms), 1.1 on C5's
+// share per GPU (34 ms).  A wavefront now takes 256 positions a trip, four consecutive ones per lane: the 8 x 4 plane words
+// come in one load by lanes 0..31, and only a lane with a candidate among its four -- a position that won nothing, i.e. a
+// false positive or a pad -- loads their packed words (32 bytes) to tell the two apart, and then the log position.
 __global__ __launch_bounds__(256) void k_xor_fp(const unsigned long long *__restrict__ pk, const uint32_t *__restrict__ ix,
                                                 const unsigned long long *__restrict__ planes, uint64_t plane_words, uint64_t npos,
                                                 uint8_t *__restrict__ lost) {
-	const uint32_t lane = threadIdx.x & 63u;
-	for (uint64_t j0 = (uint64_t)blockIdx.x * 256; j0 < npos; j0 += (uint64_t)gridDim.x * 256) {  // (wave-uniform bounds)
-		const uint64_t j = j0 + threadIdx.x;  // a multiple of 64 + lane
-		const uint64_t word = j >> 6;
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+	for (uint64_t w0 = ((uint64_t)blockIdx.x * 4 + wave) * 4; w0 < plane_words; w0 += nwaves * 4) {  // (wave-uniform) four plane words = 256 positions
 		unsigned long long mine = 0;
-		if (lane < 8 && word < plane_words) mine = planes[(uint64_t)lane * plane_words + word];
-		uint32_t lo = (uint32_t)mine, hi = (uint32_t)(mine >> 32), wlo = 0, whi = 0;
-#pragma unroll
-		for (int i = 0; i < 8; ++i) {
-			wlo |= (uint32_t)__builtin_amdgcn_readlane((int)lo, i);
-			whi |= (uint32_t)__builtin_amdgcn_readlane((int)hi, i);
+		{
+			const uint64_t word = w0 + (lane & 3u);
+			if (lane < 32 && word < plane_words) mine = planes[(uint64_t)(lane >> 2) * plane_words + word];
 		}
-		if (j >= npos) continue;
-		const unsigned long long key = pk[j];
-		const uint32_t bit = lane < 32 ? (wlo >> lane) & 1u : (whi >> (lane - 32)) & 1u;
-		if (key != XOR_PAD && !bit) lost[ix[j]] = 8;
+		// OR over the eight planes: lanes l, l + 4, ..., l + 28 hold the same word of different planes
+		uint32_t lo = (uint32_t)mine, hi = (uint32_t)(mine >> 32);
+		lo |= (uint32_t)__shfl_xor((int)lo, 4);
+		hi |= (uint32_t)__shfl_xor((int)hi, 4);
+		lo |= (uint32_t)__shfl_xor((int)lo, 8);
+		hi |= (uint32_t)__shfl_xor((int)hi, 8);
+		lo |= (uint32_t)__shfl_xor((int)lo, 16);
+		hi |= (uint32_t)__shfl_xor((int)hi, 16);
+		// lane l's positions: bits 4 (l & 15) .. + 3 of word l >> 4, which lanes (l >> 4) + 4 i hold (lane l >> 4 among them)
+		const uint32_t src = lane >> 4;
+		const uint32_t wl = (uint32_t)__shfl((int)lo, (int)src), wh = (uint32_t)__shfl((int)hi, (int)src);
+		const uint32_t sh = 4u * (lane & 15u);
+		const uint32_t won = (sh < 32u ? wl >> sh : wh >> (sh - 32u)) & 15u;
+		const uint64_t j = (w0 << 6) + 4ull * lane;
+		if (won == 15u || j >= npos) continue;
+		unsigned long long key[4];
+		if (j + 4 <= npos) {
+			const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(pk + j), b = *reinterpret_cast<const ulonglong2 *>(pk + j + 2);
+			key[0] = a.x;
+			key[1] = a.y;
+			key[2] = b.x;
+			key[3] = b.y;
+		} else {
+#pragma unroll
+			for (int q = 0; q < 4; ++q) key[q] = j + q < npos ? pk[j + q] : XOR_PAD;
+		}
+#pragma unroll
+		for (int q = 0; q < 4; ++q)
+			if (!((won >> q) & 1u) && key[q] != XOR_PAD) lost[ix[j + q]] = 8;
 	}
 }
 

@@ -1291,9 +1291,7 @@ struct AggTable {
 	uint64_t stamp[SLOTS];
 	uint32_t cnt[SLOTS];
 	uint32_t edges[SLOTS];
-	uint16_t list[SLOTS];
-	uint32_t fill;
-	uint32_t spilled;  // a k-mer of the current bucket went to the log on its own (table full)
+	uint16_t list[SLOTS];  // the slots claimed since the last flush (their number: a register of the wavefront)
 };
 
 template <int W>
@@ -1304,7 +1302,6 @@ struct RecTable {
 	uint32_t tag[RT_SLOTS];  // header bits 16..30: length, neighbour flags, minimizer offset
 	uint32_t cnt[RT_SLOTS];
 	uint16_t list[RT_SLOTS];
-	uint32_t fill;
 };
 
 __device__ __forceinline__ void wave_sync() {  // orders this wavefront's LDS traffic; no s_barrier
@@ -1350,31 +1347,24 @@ static constexpr uint32_t AGG_MAX_SUBPASSES = 4096;
 
 template <int W, int SLOTS>
 __device__ __forceinline__ int lds_upsert(AggTable<W, SLOTS> &t, uint32_t hash, uint64_t i0, uint64_t i1, uint64_t stamp, uint32_t emask,
-                                          uint32_t weight) {  // -> the k-mer's slot, or -1: no slot left
+                                          uint32_t weight, bool &fresh) {  // -> the k-mer's slot, or -1: no slot left; fresh: the slot became this key's here
+	// The probe is the compare-and-swap itself: it returns the key word that holds the slot -- one LDS round trip per probe,
+	// where a read in front made two of every claim.  The caller lists and counts the slots its lanes made theirs after the
+	// lanes have met again (ballot + rank on a fill kept in a scalar register): nothing here reads a counter back.
+	// Exactly one lane is `fresh` per slot: the one whose compare-and-swap set the key's last word.
 	uint32_t s = hash >> (SLOTS == 512 ? 23 : 24);
+	fresh = false;
 	for (uint32_t probe = 0; probe < (uint32_t)SLOTS; ++probe) {
-		uint64_t c0 = t.k0[s];
-		if (c0 == EMPTY) {
-			uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long *>(&t.k0[s]), EMPTY, i0);
-			if (prev == EMPTY) {
-				uint32_t idx = atomicAdd(&t.fill, 1u);
-				t.list[idx] = (uint16_t)s;
-				c0 = i0;
-			} else {
-				c0 = prev;
-			}
-		}
-		if (c0 == i0) {
-			bool match = true;
+		const uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long *>(&t.k0[s]), EMPTY, i0);
+		if (prev == EMPTY || prev == i0) {
+			bool match = true, set_last = prev == EMPTY;
 			if (W == 2) {
-				uint64_t c1 = t.k1[s];
-				if (c1 == EMPTY) {
-					uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long *>(&t.k1[s]), EMPTY, i1);
-					c1 = (prev == EMPTY) ? i1 : prev;
-				}
-				match = (c1 == i1);
+				const uint64_t p1 = atomicCAS(reinterpret_cast<unsigned long long *>(&t.k1[s]), EMPTY, i1);
+				set_last = p1 == EMPTY;
+				match = set_last || p1 == i1;
 			}
 			if (match) {
+				fresh = set_last;
 				atomicMin(reinterpret_cast<unsigned long long *>(&t.stamp[s]), stamp);
 				atomicAdd(&t.cnt[s], weight);
 				atomicOr(&t.edges[s], emask);
@@ -1484,13 +1474,17 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<
 	uint32_t cut_anchored = 0, cut_expanded = 0;  // statistics (lane 0): records cut by a read end that lay inside an anchor / were expanded
 	bool log_full = false;         // wave-uniform
 	bool partial_flushes = false;  // last resort for a bucket that more than AGG_MAX_SUBPASSES passes cannot hold
+	// what the two tables hold, and whether a k-mer of the current bucket went to the log on its own (table full): wave-uniform
+	// registers, kept up by ballots where the lanes meet again -- no counter in LDS is read back on the way
+	uint32_t tfill = 0, rfill = 0;
+	bool tspilled = false;
 
 	// flush() and expand() are wave-uniform: their conditions come from fill counters read after wave_sync().
 	// flush: the k-mer table's entries continue the wavefront's current log chunk and spill over into a new one.
 	auto flush = [&]() {
-		const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)T.fill);
+		const uint32_t n = tfill;
 		if (n == 0) return;
-		const uint64_t mark = (flag_unique && !partial_flushes && __builtin_amdgcn_readfirstlane((int)T.spilled) == 0) ? LOG_UNIQUE : 0ull;
+		const uint64_t mark = (flag_unique && !partial_flushes && !tspilled) ? LOG_UNIQUE : 0ull;
 		// what the host needs to know about the log: its number of entries, and whether all are unique keys (summed per
 		// wavefront, added once at the end: the counters share a cache line with the log cursor)
 		keys_written += n;
@@ -1529,13 +1523,13 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<
 		} else {
 			chunk_used += n;
 		}
-		if (lane == 0) T.fill = 0;
+		tfill = 0;
 		wave_sync();
 	};
 
 	// drop what both tables hold without writing anything (a bucket attempt that overflowed)
 	auto discard = [&]() {
-		const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)T.fill);
+		const uint32_t n = tfill;
 		for (uint32_t i = lane; i < n; i += 64) {
 			const uint32_t sl = T.list[i];
 			T.k0[sl] = EMPTY;
@@ -1544,18 +1538,16 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<
 			T.cnt[sl] = 0;
 			T.edges[sl] = 0;
 		}
-		const uint32_t nr = (uint32_t)__builtin_amdgcn_readfirstlane((int)R.fill);
+		const uint32_t nr = rfill;
 		for (uint32_t i = lane; i < nr; i += 64) {
 			const uint32_t sl = R.list[i];
 			R.fp[sl] = 0;
 			R.cnt[sl] = 0;
 			R.stamp[sl] = INF_STAMP;
 		}
-		if (lane == 0) {
-			T.fill = 0;
-			T.spilled = 0;
-			R.fill = 0;
-		}
+		tfill = 0;
+		tspilled = false;
+		rfill = 0;
 		wave_sync();
 	};
 
@@ -1569,7 +1561,7 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<
 	// neighbour bases straight out of the record's words.
 	// anchoring (ANCH): the records are whole super-k-mers; the first ANCHORS of the bucket become anchors
 	auto expand = [&](uint32_t sub, uint32_t nsub, bool anchoring) -> bool {
-		const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)R.fill);
+		const uint32_t n = rfill;
 		if (n == 0) return true;
 		for (uint32_t e0 = 0; e0 < n; e0 += 64) {
 			const uint32_t e = e0 + lane;
@@ -1613,7 +1605,7 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<
 				tp.w = (uint32_t)(rstamp >> 32);
 				reinterpret_cast<uint4 *>(st)[lane] = tp;
 			}
-			const bool checked = (uint32_t)__builtin_amdgcn_readfirstlane((int)T.fill) + total > LIMIT;  // else no overfill possible
+			const bool checked = tfill + total > LIMIT;  // else no overfill possible
 			for (uint32_t t0 = 0; t0 < total; t0 += 64) {
 				const uint32_t t = t0 + lane;
 				// owner of k-mer t = the last record that starts at or before it: the records that start inside this round mark
@@ -1633,6 +1625,8 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<
 				const uint32_t weight = tp.y;
 				const uint32_t anch = ANCH ? ((tp.x >> 8) & 0xFFu) : ANCHORS;
 				const uint64_t stamp0 = ((uint64_t)tp.w << 32) | tp.z;
+				int kslot = 0;
+				bool fresh = false, nospace = false;  // this lane's k-mer took a free slot / found none
 				if (t < total) {
 					uint64_t bw[NB];
 #pragma unroll
@@ -1657,12 +1651,12 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<
 					uint64_t i0, i1;
 					to_internal<W>(use_rc ? r0 : f0, use_rc ? r1 : f1, i0, i1);
 					const uint32_t hx = agg_hash<W>(i0, i1);
-					int kslot = 0;
 					if (SLOW && ((hx >> (SLOTS == 512 ? 11 : 12)) & (nsub - 1)) != sub) {
 						// another sub-pass owns this k-mer
-					} else if ((kslot = lds_upsert<W, SLOTS>(T, hx, i0, i1, stamp0 + i, em, weight)) < 0) {
+					} else if ((kslot = lds_upsert<W, SLOTS>(T, hx, i0, i1, stamp0 + i, em, weight, fresh)) < 0) {
+						nospace = true;  // no slot left
 						if (!partial_flushes) {
-							T.spilled = 2;  // no slot left: the attempt is void
+							// the attempt is void
 						} else {
 						// LDS table full: this k-mer goes to the log on its own
 						unsigned long long g = atomicAdd(&counters[PC_LOG_CURSOR], 1ull);
@@ -1677,25 +1671,32 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<
 							atomicAdd(&counters[PC_LOG_OVF], 1ull);
 						}
 						atomicAdd(&counters[PC_LDS_SPILL], 1ull);
-						T.spilled = 1;
 						}
 					} else {
 						if constexpr (ANCH)
 							if (anch < ANCHORS && i < AnchorTable<W>::KMERS) A.kslot[anch][i] = (uint8_t)kslot;  // (i < w <= 49 for records this library cut)
 					}
 				}
+				{  // the slots this round made their keys': listed and counted where the lanes meet again
+					const unsigned long long made = __builtin_amdgcn_ballot_w64(fresh);
+					if (fresh) T.list[tfill + __builtin_amdgcn_mbcnt_hi((uint32_t)(made >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)made, 0u))] = (uint16_t)kslot;
+					tfill += (uint32_t)__popcll(made);
+				}
 				if (checked) {
-					wave_sync();
-					if (!partial_flushes && (uint32_t)__builtin_amdgcn_readfirstlane((int)T.spilled) == 2) return false;
-					if ((uint32_t)__builtin_amdgcn_readfirstlane((int)T.fill) > LIMIT) {
+					if (__builtin_amdgcn_ballot_w64(nospace)) {
 						if (!partial_flushes) return false;
+						tspilled = true;
+					}
+					if (tfill > LIMIT) {
+						if (!partial_flushes) return false;
+						wave_sync();
 						flush();
 					}
 				}
 			}
 			wave_sync();
 		}
-		if (lane == 0) R.fill = 0;
+		rfill = 0;
 		wave_sync();
 		return true;
 	};
@@ -1711,11 +1712,6 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<
 		R.fp[i] = 0;
 		R.cnt[i] = 0;
 		R.stamp[i] = INF_STAMP;
-	}
-	if (lane == 0) {
-		T.fill = 0;
-		T.spilled = 0;
-		R.fill = 0;
 	}
 	wave_sync();
 
@@ -1886,12 +1882,16 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<
 							if (cur == fp) break;
 							sl = (sl + 1) & (RT_SLOTS - 1);
 						}
+					}
+					{  // the lanes that claimed a slot number themselves (ballot + rank on the fill, a scalar register)
+						const unsigned long long claimed = __builtin_amdgcn_ballot_w64(owner);
 						if (owner) {
 #pragma unroll
 							for (int i = 0; i < NB; ++i) R.w[i][sl] = bw[i];
 							R.tag[sl] = tag;
-							R.list[atomicAdd(&R.fill, 1u)] = (uint16_t)sl;
+							R.list[rfill + __builtin_amdgcn_mbcnt_hi((uint32_t)(claimed >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)claimed, 0u))] = (uint16_t)sl;
 						}
+						rfill += (uint32_t)__popcll(claimed);
 					}
 					wave_sync();
 					if (pending) {
@@ -1911,7 +1911,7 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<
 					}
 					wave_sync();
 				} while (__any(pending));
-				if ((uint32_t)__builtin_amdgcn_readfirstlane((int)R.fill) > RT_FLUSH) overflow = !expand(hsub, hn, phase == 0);
+				if (rfill > RT_FLUSH) overflow = !expand(hsub, hn, phase == 0);
 			}
 			if (!overflow) overflow = !expand(hsub, hn, phase == 0);
 			return overflow;
@@ -1960,7 +1960,7 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<
 				else partial_flushes = true;
 			}
 		}
-		if (lane == 0) T.spilled = 0;
+		tspilled = false;
 		b = b2;
 		cb = nb_begin;
 		ce = nb_end;

@@ -7,7 +7,7 @@ occurrences, GridTable size, Bloom statistics, the whole histogram, minimum / pe
 CoverageDistribution.txt, and the sha256 of the sorted Vertex::dump records after pass 1, pass 2 and the purge.
 
   python tests/golden/make_full_size_digests.py C1     (about 5 minutes on one core)
-  python tests/golden/make_full_size_digests.py C2     (hours on one core, about 12 GB of memory)
+  python tests/golden/make_full_size_digests.py C2 [out.json]    (hours on one core, about 12 GB of memory)
 """
 import hashlib
 import json
@@ -30,7 +30,7 @@ def digest_records(rec):
     return hashlib.sha256(rec.tobytes()).hexdigest()
 
 
-def main(which):
+def main(which, dst=None):
     name = NAMES[which]
     cfg = CONFIGS[name]
     n = n_reads_for(cfg["genome"], cfg["read_len"], cfg["coverage"])
@@ -52,7 +52,7 @@ def main(which):
         path = os.path.join(d, "CoverageDistribution.txt")
         out["minimum_peak_repeat"] = list(ro.coverage_distribution(cov, cnt, path))
         out["sha256_CoverageDistribution_txt"] = hashlib.sha256(open(path, "rb").read()).hexdigest()
-    dst = os.path.join(HERE, "full_size_%s.json" % which)
+    dst = dst or os.path.join(HERE, "full_size_%s.json" % which)
     with open(dst, "w") as f:   # pass 1 is the headline metric: kept even if the run is cut short before the edges are done
         json.dump(dict(out, _partial="pass 1 only: the run was still going"), f, indent=1)
     t0 = time.time()
@@ -70,4 +70,4 @@ def main(which):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "C1")
+    main(sys.argv[1] if len(sys.argv) > 1 else "C1", sys.argv[2] if len(sys.argv) > 2 else None)
