@@ -1278,6 +1278,7 @@ static constexpr uint32_t RT_SLOTS = 128;
 // (7/8: 12.7)
 static constexpr uint32_t RT_FLUSH = RT_SLOTS * 15 / 16 - 64;
 static constexpr uint32_t LOG_CHUNK = 512;
+static constexpr int RT_TAG_SHIFT = 48;  // RecTable: where the last word of a record carries the header bits
 // wavefronts per workgroup (one per workgroup: 26 ms instead of 17).  Two-word keys have 16.1 KB of tables per wavefront,
 // 8 wavefronts per CU with four per workgroup; three per workgroup (9 per CU) changed nothing (C3 shape: 25.4 ms both), five
 // (80.7 KB: only one workgroup fits) 40.9 ms
@@ -1297,9 +1298,10 @@ struct AggTable {
 template <int W>
 struct RecTable {
 	unsigned long long fp[RT_SLOTS];  // 0 = free, else a 63-bit fingerprint of the key | 1
-	uint64_t w[2 * W][RT_SLOTS];
+	uint64_t w[2 * W][RT_SLOTS];  // the record's bases; the top 16 bits of the last word hold header bits 16..30 (length, neighbour flags,
+	                              // minimizer offset): a record has at most 2k - 13 <= 113 bases, so its last word has 26 bits or more to spare,
+	                              // and what a slot is compared by and expanded from is one LDS access less
 	uint64_t stamp[RT_SLOTS];
-	uint32_t tag[RT_SLOTS];  // header bits 16..30: length, neighbour flags, minimizer offset
 	uint32_t cnt[RT_SLOTS];
 	uint16_t list[RT_SLOTS];
 };
@@ -1569,7 +1571,7 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<
 			uint64_t rstamp = 0;
 			if (e < n) {
 				rsl = R.list[e];
-				rlen = (R.tag[rsl] & 63u) + 1;
+				rlen = ((uint32_t)(R.w[NB - 1][rsl] >> RT_TAG_SHIFT) & 63u) + 1;
 				rweight = R.cnt[rsl];
 				rstamp = R.stamp[rsl];
 				R.fp[rsl] = 0;  // the slot is free again (its words and tag stay readable until it is claimed anew)
@@ -1581,11 +1583,11 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<
 						ranch = a;
 						uint64_t aw[NB];
 #pragma unroll
-						for (int q = 0; q < NB; ++q) {
-							aw[q] = R.w[q][rsl];
-							A.w[q][a] = aw[q];
-						}
-						const uint32_t tg = R.tag[rsl];
+						for (int q = 0; q < NB; ++q) aw[q] = R.w[q][rsl];
+						const uint32_t tg = (uint32_t)(aw[NB - 1] >> RT_TAG_SHIFT);
+						aw[NB - 1] &= (1ull << RT_TAG_SHIFT) - 1;
+#pragma unroll
+						for (int q = 0; q < NB; ++q) A.w[q][a] = aw[q];
 						A.tag[a] = (uint16_t)tg;
 						A.mm[a] = (uint32_t)(rec_ext<W>(aw, (tg >> 8) & 127u) & ((1ull << (2 * mlen)) - 1));
 					}
@@ -1631,7 +1633,8 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<
 					uint64_t bw[NB];
 #pragma unroll
 					for (int q = 0; q < NB; ++q) bw[q] = R.w[q][sl];
-					const uint32_t tag = R.tag[sl];
+					const uint32_t tag = (uint32_t)(bw[NB - 1] >> RT_TAG_SHIFT);
+					bw[NB - 1] &= (1ull << RT_TAG_SHIFT) - 1;
 					const uint32_t len = (tag & 63u) + 1, hasL = (tag >> 6) & 1u, hasR = (tag >> 7) & 1u;
 					const uint32_t pos = hasL + i;  // the k-mer's first base in the record
 					uint64_t f0, f1 = 0, r0, r1;
@@ -1887,8 +1890,7 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<
 						const unsigned long long claimed = __builtin_amdgcn_ballot_w64(owner);
 						if (owner) {
 #pragma unroll
-							for (int i = 0; i < NB; ++i) R.w[i][sl] = bw[i];
-							R.tag[sl] = tag;
+							for (int i = 0; i < NB; ++i) R.w[i][sl] = (i == NB - 1) ? (bw[i] | ((uint64_t)tag << RT_TAG_SHIFT)) : bw[i];
 							R.list[rfill + __builtin_amdgcn_mbcnt_hi((uint32_t)(claimed >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)claimed, 0u))] = (uint16_t)sl;
 						}
 						rfill += (uint32_t)__popcll(claimed);
@@ -1897,9 +1899,8 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<
 					if (pending) {
 						bool same = true;
 						if (!owner) {
-							same = (R.tag[sl] == tag);
 #pragma unroll
-							for (int i = 0; i < NB; ++i) same = same && (R.w[i][sl] == bw[i]);
+							for (int i = 0; i < NB; ++i) same = same && (R.w[i][sl] == ((i == NB - 1) ? (bw[i] | ((uint64_t)tag << RT_TAG_SHIFT)) : bw[i]));
 						}
 						if (same) {
 							atomicAdd(&R.cnt[sl], 1u);
