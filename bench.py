@@ -140,7 +140,18 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device(dev))
             if os.environ.get("RAYGRAPH_BENCH_EXCHANGE", "library") != "torch":
                 from ray_amd.exchange import create_comm
-                comm = create_comm(rank, world, local_rank)
+                # every rank must take the same route: if the library's communicator cannot be made on any of them (no
+                # librccl.so.1 to open, a refused init), all fall back to the exchanges driven over torch.distributed
+                try:
+                    comm = create_comm(rank, world, local_rank)
+                except Exception as exc:   # noqa: BLE001 -- reported below, the run goes on over the other route
+                    comm = None
+                    print("rank %d: rg_comm over RCCL unavailable (%s); using the torch.distributed route" % (rank, exc), file=sys.stderr)
+                made = torch.tensor([1 if comm is not None else 0], device=dev)
+                dist.all_reduce(made, op=dist.ReduceOp.MIN)
+                if int(made.item()) == 0 and comm is not None:
+                    comm.close()
+                    comm = None
         else:
             dist.init_process_group(backend)
 
@@ -493,7 +504,7 @@ def main():
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": args.workload + ("" if args.scale == 1.0 else "@scale=%g" % args.scale) + ("" if args.error is None else "@error=%g" % args.error), "k": k,
                        "read_len": L, "reads_per_gpu": n_reads, "genome_bp": genome, "substitution_error_rate": error,
-                       "parallelism": "owner-partitioned x%d" % world + ("" if nranks == 1 else ", %s route" % route) + ("" if emu == 1 else " (rank 0 of %d emulated on one GPU, no network)" % emu), "bloom": "default 16*k*reads cap 2^33"},
+                       "parallelism": "owner-partitioned x%d" % world + ("" if nranks == 1 else ", %s route" % route) + ("" if emu == 1 else " (rank 0 of %d emulated on one GPU, no network)" % emu) + ("" if world == 1 else (", exchange inside the library (rg_comm, RCCL)" if comm is not None else ", exchange over torch.distributed")), "bloom": "default 16*k*reads cap 2^33"},
             "occurrences_per_s": occ / per_step,
             "kmer_occurrences": occ, "distinct_candidates": cand, "vertices_stored": stored,
             # frac = frac_step: SURVEY 8(d)'s bytes per occurrence (stream + Bloom + table: what the path must move whatever
