@@ -384,9 +384,11 @@ int rg_release_cached_memory(void);
 /* Forces internal routes that the library otherwise chooses by itself; results never depend on them.  No counterpart
  * in the reference; a plugin leaves it alone.  Must be called before the counting starts.  flags:
  *   bits 0-7   sweep: 0 = automatic, 1 = force the partitioned sweep, 2 = force the direct sweep
+ *   bit  3     fold the first partition level into the record kernel on small inputs too (k = 31)
  *   bit  4     force the Bloom resolution by (bit, key) items per Bloom region
  *   bit  5     force the dense first-touch stamps
  *   bit  6     start with a one-chunk log (tests of the overflow path)
+ *   bit  7     never fold the first partition level into the record kernel
  *   bits 8-15  log2 of the bucket count of the partitioned sweep (0 = automatic)
  *   bit  16    cut super-k-mer records with the wavefront-per-read kernel even where the lane-per-read one applies
  *   bit  17    produce the Bloom items straight into their first partition level even from a sparse key array

@@ -1334,6 +1334,7 @@ struct rg_handle {
 	bool owner_counts_valid = false;           // set by rg_owner_counts, cleared by whatever changes the entries it counted
 	Phase phase = PH_CREATED;
 	uint32_t dbg = 0;  // rg_debug_set: internal routes forced by tests and experiments (0 = automatic)
+	bool fuse_off = false;  // the sweep is being done again without the first level folded into the record kernel (a run overflowed)
 	rg_stats stats{};
 	std::string err;
 	// optional per-kernel timing with HIP events on the launch stream (rg_set_profiling)
@@ -1531,6 +1532,14 @@ struct SuperkmerLaunch {
 	}
 	bool lanes(const ReadBatch &b) const { return grid_lane > 0 && b.maxlen <= SKL_MAX_READ; }
 	const char *name(const ReadBatch &b) const { return lanes(b) ? "k_superkmers_lanes" : "k_superkmers"; }
+	// the unrolled kernel with the first partition level folded in: records into 2^fbits runs per workgroup, see k_superkmers_lanes_s
+	bool can_fuse(const ReadBatch &b) const { return W == 1 && unrolled && lanes(b); }
+	void launch_fused(rg_handle *h, const ReadBatch &b, int k, int m, RM *buf, RM *sample, uint64_t sample_cap, uint8_t *side, uint32_t *run_count,
+	                  uint32_t run_cap, int fbits) const {
+		if constexpr (W == 1)
+			hipLaunchKernelGGL((k_superkmers_lanes_s<17, C, true>), dim3(grid_lane), dim3(256), lds_lane, h->stream, b.d_packed, b.d_off, b.d_len, b.n, b.first_id, k, m,
+			                   buf, 0ull, h->d_counters, (unsigned long long *)nullptr, 0u, 0u, sample, sample_cap, side, run_count, run_cap, fbits);
+	}
 	void launch(rg_handle *h, const ReadBatch &b, uint64_t lo, uint64_t n, int k, int m, RM *buf, uint64_t rec_cap,
 	            unsigned long long *d_hist, uint32_t modulo, uint32_t hist_shift, RM *sample = nullptr, uint64_t sample_cap = 0) const {
 		if constexpr (W == 1) {
@@ -1667,13 +1676,18 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	const bool sampling = !nested && !bits_forced && !agg.wg && (bits >= 16 || (h->dbg & 0x2000000)) && bits < MAX_BUCKET_BITS;  // bit 25: small inputs too (tests)
 	// one to three levels of at most 8 bits each, split evenly: fewer digits per level = longer runs per (tile, digit)
 	// (22 bits: 7 + 7 + 8; 8 + 7 + 7 measured 1.5-2.4 ms slower on C2, same box)
-	int nlev = 0, dbits[3] = {0, 0, 0};
+	// fbits > 0: the record kernel itself does a first level of fbits bits (k_superkmers_lanes_s<17, C, true>: decided below, before
+	// the kernel runs -- the record sample may still raise `bits` afterwards, which then only re-splits the levels behind it)
+	int nlev = 0, dbits[4] = {0, 0, 0, 0}, fbits = 0;
 	auto split_levels = [&]() {
-		nlev = bits <= 8 ? 1 : (bits <= 16 ? 2 : 3);
-		dbits[0] = dbits[1] = dbits[2] = 0;
-		for (int l = 0, left = bits; l < nlev; ++l) {
-			dbits[l] = left / (nlev - l);  // the odd bits go to the last levels: the earlier ones also write the digit bytes, in runs as short as their own
-			left -= dbits[l];
+		const int rest = bits - fbits, first = fbits ? 1 : 0;
+		const int more = rest <= 8 ? 1 : (rest <= 16 ? 2 : 3);
+		nlev = first + more;
+		dbits[0] = dbits[1] = dbits[2] = dbits[3] = 0;
+		if (fbits) dbits[0] = fbits;
+		for (int l = 0, left = rest; l < more; ++l) {
+			dbits[first + l] = left / (more - l);  // the odd bits go to the last levels: the earlier ones also write the digit bytes, in runs as short as their own
+			left -= dbits[first + l];
 		}
 	};
 	split_levels();
@@ -1689,7 +1703,41 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	uint64_t launches1 = 0;  // every launch of k_superkmers leaves up to one open chunk per wavefront
 	for (const ReadBatch &b : h->reads)
 		if (b.maxlen >= (uint32_t)k) launches1++;
-	const uint64_t rec_cap = rec_bound + launches1 * (uint64_t)grid1 * 4 * REC_CHUNK;
+	uint64_t rec_cap = rec_bound + launches1 * (uint64_t)grid1 * 4 * REC_CHUNK;
+	// The first level folded into the record kernel (one-word keys in 20-byte records, the kernel unrolled for k = 31, every
+	// batch of reads short enough for it): 2^fbits runs per workgroup of that kernel, each with room for its share of the
+	// bound on the records, a quarter more and eight standard deviations (the bound is about twice what C2's reads make, so a
+	// digit twice as heavy as the others still fits; a run that overflows all the same sends the sweep round again the
+	// classic way).  rg_debug_set bit 7: never; bit 3: on small inputs too (tests).
+	const uint64_t SEGMAX = 1ull << 19;  // segments a level may read: 2^(bits - its own digit), up to 2^19 with a folded first level in front of three more
+	uint32_t run_cap = 0, n_wg = 0;
+	if (W == 1 && C && !ext && !nested && !h->fuse_off && !(h->dbg & 0x80u) && !agg.wg && (bits >= 14 || (h->dbg & 0x8u))) {
+		bool all = sk.grid_lane > 0;
+		for (const ReadBatch &b : h->reads)
+			if (b.maxlen >= (uint32_t)k && !sk.can_fuse(b)) all = false;
+		if (all) {
+			n_wg = (uint32_t)sk.grid_lane;
+			// 5 bits: 32 open runs per workgroup, 128 per CU -- what a CU's cache still merges into whole lines.  C2, record kernel /
+			// the levels behind it / step: not folded 10.3 / 16.2 (7+7+7) / 53.0 ms; 3 bits 10.2 / 15.5 (6+6+6) / 54.5; 4 bits 10.6 /
+			// 15.7 / 54.9; 5 bits 12.7 / 12.8 (8+8) / 51.7; 6 bits 17.0 / 11.8 (7+8) / 55.5
+			fbits = std::min(5, std::max(1, bits / 3));
+			while (fbits > 0 && ((uint64_t)n_wg << fbits) > SEGMAX) fbits--;
+			if (fbits > 0) {
+				const double share = (double)rec_bound / (double)((uint64_t)n_wg << fbits);
+				const uint64_t rc64 = ((uint64_t)(share * 1.25 + 8.0 * std::sqrt(share)) + 64 + 63) & ~63ull;
+				if (rc64 < (1ull << 31) && ((rc64 * n_wg) << fbits) < (1ull << 40)) {
+					run_cap = (uint32_t)rc64;
+					rec_cap = ((uint64_t)run_cap * n_wg) << fbits;
+					split_levels();
+				} else {
+					fbits = 0;
+				}
+			}
+		}
+	}
+	const bool fuse = fbits > 0;
+	uint32_t *d_runcount = nullptr;
+	unsigned long long *d_segend = nullptr;
 	const uint64_t sample_cap = sampling ? (rec_bound >> (SAMPLE_BITS - 2)) + 65536 : 0;  // four times its expected share
 	RM *d_sample = nullptr;
 
@@ -1701,6 +1749,8 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	Slot *log = nullptr;
 	auto cleanup = [&]() {
 		pool_free(dev, d_side);
+		pool_free(dev, d_runcount);
+		pool_free(dev, d_segend);
 		pool_free(dev, d_sample);
 		pool_free(dev, buf[0]);
 		pool_free(dev, buf[1]);
@@ -1723,7 +1773,6 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 		(void)hipGetLastError();
 		{ if (getenv("RG_DEBUG")) fprintf(stderr, "[raygraph] partitioned sweep gives up at line %d (no memory)\n", __LINE__); return RG_OK; }
 	}
-	const uint64_t SEGMAX = 65536;
 	PTRY(pool_alloc(dev, (void **)&d_seg, (SEGMAX + 1) * sizeof(unsigned long long)));
 	PTRY(pool_alloc(dev, (void **)&d_tile, (SEGMAX + 1) * sizeof(uint32_t)));
 	PTRY(pool_alloc(dev, (void **)&d_hist, std::max<uint64_t>(NBUCK_MAX, 256) * sizeof(unsigned long long)));
@@ -1732,6 +1781,15 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	if (sampling && pool_alloc(dev, (void **)&d_sample, sample_cap * sizeof(RM)) != hipSuccess) {
 		(void)hipGetLastError();
 		d_sample = nullptr;  // no sample, no harm: the rule of thumb above stands
+	}
+	std::vector<uint32_t> run_count;  // fuse: what the record kernel put into each of its runs
+	if (fuse) {
+		const uint64_t nruns = (uint64_t)n_wg << fbits;
+		PTRY(pool_alloc(dev, (void **)&d_side, rec_cap));
+		PTRY(pool_alloc(dev, (void **)&d_runcount, nruns * sizeof(uint32_t)));
+		PTRY(pool_alloc(dev, (void **)&d_segend, (SEGMAX + 1) * sizeof(unsigned long long)));
+		PTRY(hipMemsetAsync(d_runcount, 0, nruns * sizeof(uint32_t), h->stream));
+		run_count.resize(nruns);
 	}
 	PTRY(hipMemsetAsync(d_hist, 0, 256 * sizeof(unsigned long long), h->stream));
 	PTRY(hipMemsetAsync(h->d_counters + PC_REC_CURSOR, 0, 11 * sizeof(unsigned long long), h->stream));
@@ -1747,7 +1805,8 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 			if (b.maxlen < (uint32_t)k) continue;
 			{
 				ProfScope ps(h, sk.name(b));
-				sk.launch(h, b, 0, b.n, k, m, buf[0], rec_cap, d_hist, 0u, (uint32_t)hist0_shift, d_sample, sample_cap);
+				if (fuse) sk.launch_fused(h, b, k, m, buf[0], d_sample, sample_cap, d_side, d_runcount, run_cap, fbits);
+				else sk.launch(h, b, 0, b.n, k, m, buf[0], rec_cap, d_hist, 0u, (uint32_t)hist0_shift, d_sample, sample_cap);
 			}
 			PTRY(hipGetLastError());
 		}
@@ -1780,6 +1839,7 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 		}
 	}
 	PTRY(hipMemcpyAsync(hist0.data(), d_hist, 256 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+	if (fuse) PTRY(hipMemcpyAsync(run_count.data(), d_runcount, run_count.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
 	rc = sync_counters(h);
 	const bool sset_used = d_sset != nullptr;
 	pool_free(dev, d_sset);  // (the stream has drained)
@@ -1790,12 +1850,22 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	if (!ext) {
 		if (h->h_counters[PC_REC_OVF]) {
 			cleanup();
+			if (fuse) {  // a run sized in advance was too small: once more with the first level as a pass of its own
+				if (getenv("RG_DEBUG")) fprintf(stderr, "[raygraph] partitioned sweep: a run of the folded first level overflowed, classic levels instead\n");
+				h->fuse_off = true;
+				if (hipMemsetAsync(h->d_counters + C_OCC, 0, sizeof(unsigned long long), h->stream) != hipSuccess) return fail(h, RG_ERR_HIP, "hipMemsetAsync failed");  // forget what the attempt counted
+				const int rc2 = sweep_partitioned_t<W, C>(h, out_log, out_n, ok, ext, ext_n, top, nested_bits);
+				h->fuse_off = false;
+				return rc2;
+			}
 			return RG_OK;
 		}
 		n_in = std::min<uint64_t>(h->h_counters[PC_REC_CURSOR], rec_cap);
 	}
 	valid = 0;
 	for (auto c : hist0) valid += c;
+	if (fuse)
+		for (auto c : run_count) valid += c;
 	if (ext && valid != ext_n) {
 		cleanup();
 		return fail(h, RG_ERR_STATE, "received records: %llu of %llu are valid", (unsigned long long)valid, (unsigned long long)ext_n);
@@ -1849,7 +1919,7 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 		pool_free(dev, d_sample);
 		d_sample = nullptr;
 	}
-	{  // the first level's histogram
+	if (!fuse) {  // the first level's histogram
 		std::vector<unsigned long long> folded(256, 0);
 		for (int d8 = 0; d8 < 256; ++d8) folded[d8 >> (8 - dbits[0])] += hist0[d8];
 		hist0 = folded;
@@ -1868,21 +1938,38 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	std::vector<unsigned long long> seg_begin = {0, n_in};  // host copy of the current segmentation
 	std::vector<uint32_t> tile_first;
 	int used_bits = 0;
-	for (int level = 0; level < 3 && dbits[level] > 0; ++level) {
+	std::vector<unsigned long long> seg_end;  // (runs only)
+	for (int level = 0; level < 4 && dbits[level] > 0; ++level) {
+		if (fuse && level == 0) {  // done by the record kernel: its runs are the next level's input
+			used_bits += dbits[0];
+			const uint32_t nruns = n_wg << fbits;
+			seg_begin.resize(nruns + 1);
+			seg_end.resize(nruns + 1);
+			for (uint32_t r = 0; r <= nruns; ++r) {
+				seg_begin[r] = (uint64_t)r * run_cap;
+				seg_end[r] = seg_begin[r] + (r < nruns ? run_count[r] : 0);
+			}
+			side_valid = true;
+			continue;
+		}
+		const bool runs = fuse && level == 1;  // segments = the record kernel's runs, n_wg of them per output segment
 		const uint32_t S = (uint32_t)seg_begin.size() - 1;
+		const uint32_t seg_div = runs ? n_wg : 1u;
 		const int db = dbits[level];
 		const int shift = top - used_bits - db;
 		tile_first.assign(S + 1, 0);
 		uint64_t ntiles = 0;
 		for (uint32_t sgi = 0; sgi < S; ++sgi) {
 			tile_first[sgi] = (uint32_t)ntiles;
-			ntiles += (seg_begin[sgi + 1] - seg_begin[sgi] + SCATTER_TILE - 1) / SCATTER_TILE;
+			ntiles += ((runs ? seg_end[sgi] : seg_begin[sgi + 1]) - seg_begin[sgi] + SCATTER_TILE - 1) / SCATTER_TILE;
 		}
 		tile_first[S] = (uint32_t)ntiles;
 		PTRY(hipMemcpyAsync(d_seg, seg_begin.data(), (S + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
 		PTRY(hipMemcpyAsync(d_tile, tile_first.data(), (S + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
-		const uint64_t nout = (uint64_t)S << db;  // buckets after this level
-		const bool have_next = level < 2 && dbits[level + 1] > 0;
+		if (runs) PTRY(hipMemcpyAsync(d_segend, seg_end.data(), (S + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
+		const unsigned long long *segend_arg = runs ? d_segend : nullptr;
+		const uint64_t nout = (uint64_t)(S / seg_div) << db;  // buckets after this level
+		const bool have_next = level < 3 && dbits[level + 1] > 0;
 		if (have_next && !d_side && pool_alloc(dev, (void **)&d_side, valid) != hipSuccess) {
 			(void)hipGetLastError();  // no room for the side bytes: the next histogram reads the records
 			d_side = nullptr;
@@ -1890,7 +1977,9 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 		if (level > 0 && side_valid) {  // the previous level's scatter left this level's digits, one byte per record
 			PTRY(hipMemsetAsync(d_hist, 0, nout * sizeof(unsigned long long), h->stream));
 			ProfScope ps(h, "k_level_hist_side");
-			hipLaunchKernelGGL(k_level_hist_side<SCATTER_TILE>, dim3((unsigned)((ntiles + HIST_SIDE_TILES - 1) / HIST_SIDE_TILES)), dim3(256), 0, h->stream, d_side, S, d_seg, d_tile, db, d_hist, (uint32_t)ntiles);
+			// (runs: the record kernel left 8 bucket bits per record, of which this level takes the top db)
+			hipLaunchKernelGGL(k_level_hist_side<SCATTER_TILE>, dim3((unsigned)((ntiles + HIST_SIDE_TILES - 1) / HIST_SIDE_TILES)), dim3(256), 0, h->stream, d_side, S, d_seg, d_tile, db, d_hist, (uint32_t)ntiles,
+			                   segend_arg, seg_div, runs ? 8 - db : 0);
 			PTRY(hipGetLastError());
 		} else if (level > 0) {  // level 0's histogram is in place
 			PTRY(hipMemsetAsync(d_hist, 0, nout * sizeof(unsigned long long), h->stream));
@@ -1911,17 +2000,17 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 			const int ndb = have_next ? dbits[level + 1] : 0;
 			if (nested)
 				hipLaunchKernelGGL((k_scatter<W, 1, C>), dim3((unsigned)ntiles), dim3(scatter_threads<W, C>()), 0, h->stream, level_in, m, S, d_seg, d_tile, shift, db, d_hist,
-				                   buf[cur ^ 1], 0u, side_out, shift - ndb, (1u << ndb) - 1u);
+				                   buf[cur ^ 1], 0u, side_out, shift - ndb, (1u << ndb) - 1u, (const unsigned long long *)nullptr, 1u);
 			else
 				hipLaunchKernelGGL((k_scatter<W, 0, C>), dim3((unsigned)ntiles), dim3(scatter_threads<W, C>()), 0, h->stream, level_in, m, S, d_seg, d_tile, shift, db, d_hist,
-				                   buf[cur ^ 1], 0u, side_out, shift - ndb, (1u << ndb) - 1u);
+				                   buf[cur ^ 1], 0u, side_out, shift - ndb, (1u << ndb) - 1u, segend_arg, seg_div);
 			side_valid = side_out != nullptr;
 		}
 		PTRY(hipGetLastError());
 		used_bits += db;
 		cur ^= 1;
 		level_in = buf[cur];
-		if (level < 2 && dbits[level + 1] > 0) {  // the next level needs this segmentation on the host
+		if (level < 3 && dbits[level + 1] > 0) {  // the next level needs this segmentation on the host
 			seg_begin.resize(nout + 1);
 			PTRY(hipMemcpyAsync(seg_begin.data(), d_begin, (nout + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
 			PTRY(rg_stream_sync(h));

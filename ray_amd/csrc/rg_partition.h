@@ -732,13 +732,24 @@ __global__ __launch_bounds__(256) void k_superkmers_lanes(const uint64_t *__rest
 // wraps and matches no read), the suffix pass has no loop, and the bases of a block -- WS <= 17 of them, 34 bits -- come
 // from two dwords requested one block ahead.  The one place a step can leave the unrolled block is when 64 records are
 // queued: they are assembled at a single site and the block is re-entered at the step it was left (the switch).
-template <int WS, bool C>
+// FUSED: **the first partition level is folded in** (round 3).  The records do not go to chunks in the order they are cut
+// but to 2^fbits runs per workgroup, by the top fbits bits of their bucket number: run (d, g) of digit d and workgroup g is the
+// slice [(d * gridDim.x + g) * run_cap, ... + run_cap) of `recs`, filled through a cursor in LDS (the four wavefronts share
+// the workgroup's runs), and the byte of bucket bits below the digit goes to `side` at the same index (the next level's
+// histogram reads it).  64 open runs per workgroup of 20-byte stores merge into whole lines in L2 before they reach HBM
+// (tools/microbench_streams.hip: at this kernel's pace 64 runs + side bytes cost nothing, 128 runs 4 ms), so a whole
+// k_scatter level -- a read and a write of every record -- goes away.  run_count[d * gridDim.x + g] carries the cursors
+// from launch to launch (several read batches) and tells the next level how much of each run is filled; a run that
+// overflows is counted in PC_REC_OVF and the sweep is done again the classic way.
+template <int WS, bool C, bool FUSED = false>
 __global__ __launch_bounds__(256) void k_superkmers_lanes_s(const uint64_t *__restrict__ P, const uint64_t *__restrict__ offsets,
                                                             const uint32_t *__restrict__ lengths, uint64_t nreads, uint64_t read_id_base,
                                                             int k, int m, RecMem<1, C> *__restrict__ recs, uint64_t rec_cap,
                                                             unsigned long long *__restrict__ counters,
                                                             unsigned long long *__restrict__ coarse_hist, uint32_t modulo, uint32_t hist_shift,
-                                                            RecMem<1, C> *__restrict__ sample, uint64_t sample_cap) {
+                                                            RecMem<1, C> *__restrict__ sample, uint64_t sample_cap,
+                                                            uint8_t *__restrict__ side = nullptr, uint32_t *__restrict__ run_count = nullptr,
+                                                            uint32_t run_cap = 0, int fbits = 0) {
 	static_assert(WS >= 2 && WS <= 17, "a block's bases must fit two dwords at any even bit offset");
 	using RM = RecMem<1, C>;
 	constexpr int NB = 2;
@@ -751,7 +762,8 @@ __global__ __launch_bounds__(256) void k_superkmers_lanes_s(const uint64_t *__re
 	unsigned long long *const win = s_win_all + (size_t)wave * w * 64 + lane;  // entry i of this lane: win[i * 64]
 	constexpr uint32_t SB = 16u, LNB = 5u, LANE_SH = SB + LNB, MO_SH = LANE_SH + 6u;
 	unsigned long long *const ring = s_q[wave];
-	s_hist[threadIdx.x] = 0;
+	if constexpr (FUSED) s_hist[threadIdx.x] = threadIdx.x < (1u << fbits) ? run_count[threadIdx.x * gridDim.x + blockIdx.x] : 0u;  // the runs' cursors
+	else s_hist[threadIdx.x] = 0;
 	__syncthreads();
 	const uint32_t maskm = (1u << (2 * m)) - 1;
 	const uint32_t top = 2u * (uint32_t)(m - 1);
@@ -908,7 +920,7 @@ __global__ __launch_bounds__(256) void k_superkmers_lanes_s(const uint64_t *__re
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 				__builtin_amdgcn_wave_barrier();
 				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-				if (chunk_used + cnt > REC_CHUNK) {
+				if (!FUSED && chunk_used + cnt > REC_CHUNK) {
 					if (have_chunk && !dead)
 						for (uint32_t q = chunk_used + lane; q < REC_CHUNK; q += 64) rec_mark_invalid(&recs[chunk_base + q]);
 					unsigned long long nbase = 0;
@@ -955,9 +967,21 @@ __global__ __launch_bounds__(256) void k_superkmers_lanes_s(const uint64_t *__re
 					rec.w[NB] = (uint64_t)pr | ((uint64_t)(len - 1) << 16) | ((uint64_t)hasL << 22) | ((uint64_t)hasR << 23) |
 					            ((uint64_t)moff << 24) | ((read_id_base + rb + src) << 31);
 					const RM packed = rec_pack(rec, (RM *)nullptr);
-					recs[chunk_base + chunk_used + lane] = packed;
 					const uint32_t bk = bucket_number(order_unmix((uint32_t)(d >> 32)));
-					atomicAdd(&s_hist[modulo ? bk % modulo : bk >> hist_shift], 1u);
+					if constexpr (FUSED) {
+						const uint32_t dg = bk >> (BUCKET_TOP - fbits);
+						const uint32_t at = atomicAdd(&s_hist[dg], 1u);  // the place in run (dg, this workgroup)
+						if (at < run_cap) {
+							const uint64_t idx = ((uint64_t)dg * gridDim.x + blockIdx.x) * run_cap + at;
+							recs[idx] = packed;
+							side[idx] = (uint8_t)(bk >> (BUCKET_TOP - fbits - 8));
+						} else if (at == run_cap) {
+							atomicAdd(&counters[PC_REC_OVF], 1ull);
+						}
+					} else {
+						recs[chunk_base + chunk_used + lane] = packed;
+						atomicAdd(&s_hist[modulo ? bk % modulo : bk >> hist_shift], 1u);
+					}
 					sample_record<RM>(packed, bk, sample, sample_cap, counters);
 				}
 				chunk_used += cnt;
@@ -971,13 +995,17 @@ __global__ __launch_bounds__(256) void k_superkmers_lanes_s(const uint64_t *__re
 			}
 		}
 	}
-	if (have_chunk && !dead)
+	if (!FUSED && have_chunk && !dead)
 		for (uint32_t q = chunk_used + lane; q < REC_CHUNK; q += 64) rec_mark_invalid(&recs[chunk_base + q]);
 #pragma unroll
 	for (int d = 32; d; d >>= 1) occ += __shfl_xor(occ, d);
 	if (lane == 0 && occ) atomicAdd(&counters[2 /*C_OCC*/], occ);
 	__syncthreads();
-	if (s_hist[threadIdx.x]) atomicAdd(&coarse_hist[threadIdx.x], (unsigned long long)s_hist[threadIdx.x]);
+	if constexpr (FUSED) {
+		if (threadIdx.x < (1u << fbits)) run_count[threadIdx.x * gridDim.x + blockIdx.x] = s_hist[threadIdx.x] < run_cap ? s_hist[threadIdx.x] : run_cap;
+	} else {
+		if (s_hist[threadIdx.x]) atomicAdd(&coarse_hist[threadIdx.x], (unsigned long long)s_hist[threadIdx.x]);
+	}
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1016,7 +1044,11 @@ __global__ __launch_bounds__((scatter_threads<W, C>())) void k_scatter(const Rec
                                                  const unsigned long long *__restrict__ seg_begin,
                                                  const uint32_t *__restrict__ tile_first, int shift, int dbits,
                                                  unsigned long long *__restrict__ cursors, RecMem<W, C> *__restrict__ out, uint32_t modulo,
-                                                 uint8_t *__restrict__ side, int next_shift, uint32_t next_mask) {
+                                                 uint8_t *__restrict__ side, int next_shift, uint32_t next_mask,
+                                                 const unsigned long long *__restrict__ seg_end = nullptr, uint32_t seg_div = 1) {
+	// seg_end / seg_div: the input is the runs the record kernel left when it folded the first level in -- segment s is filled
+	// up to seg_end[s] only, and seg_div consecutive segments (the runs of one digit, one per workgroup of that kernel) share
+	// the cursors of output segment s / seg_div
 	using RM = RecMem<W, C>;
 	constexpr int SCATTER_TILE = scatter_tile<W, C>();
 	constexpr int SCATTER_THREADS = scatter_threads<W, C>();
@@ -1032,7 +1064,9 @@ __global__ __launch_bounds__((scatter_threads<W, C>())) void k_scatter(const Rec
 	__shared__ uint32_t s_scan[256];
 	const uint32_t seg = find_segment(tile_first, S, blockIdx.x);
 	const uint64_t begin = seg_begin[seg] + (uint64_t)(blockIdx.x - tile_first[seg]) * SCATTER_TILE;
-	const uint64_t end = begin + SCATTER_TILE < seg_begin[seg + 1] ? begin + SCATTER_TILE : seg_begin[seg + 1];
+	const uint64_t send = seg_end ? seg_end[seg] : seg_begin[seg + 1];
+	const uint64_t end = begin + SCATTER_TILE < send ? begin + SCATTER_TILE : send;
+	const uint32_t oseg = seg / seg_div;
 	const uint32_t dmask = (1u << dbits) - 1;
 	if (threadIdx.x < 256) s_cnt[threadIdx.x] = 0;
 	__syncthreads();
@@ -1077,7 +1111,7 @@ __global__ __launch_bounds__((scatter_threads<W, C>())) void k_scatter(const Rec
 			s_off[threadIdx.x] = before + incl - c;
 			if (threadIdx.x == 255) s_scan[4] = before + incl;
 			unsigned long long g = 0;
-			if (c) g = atomicAdd(&cursors[((uint64_t)seg << dbits) + threadIdx.x], (unsigned long long)c);
+			if (c) g = atomicAdd(&cursors[((uint64_t)oseg << dbits) + threadIdx.x], (unsigned long long)c);
 			s_gbase[threadIdx.x] = g;
 		}
 	}
@@ -1108,22 +1142,25 @@ __global__ __launch_bounds__(256) void k_level_hist_side(const uint8_t *__restri
                                                          const unsigned long long *__restrict__ seg_begin,
                                                          const uint32_t *__restrict__ tile_first, int dbits,
                                                          unsigned long long *__restrict__ hist, uint32_t ntiles,
-                                                         const unsigned long long *__restrict__ seg_end = nullptr) {
+                                                         const unsigned long long *__restrict__ seg_end = nullptr, uint32_t seg_div = 1,
+                                                         int side_shift = 0) {
 	// seg_end: segments that do not touch (ranges sized in advance and filled in part); otherwise segment s ends where s + 1 begins
+	// seg_div, side_shift: the runs of the record kernel's folded first level (see k_scatter) -- seg_div consecutive segments
+	// count into one histogram segment, and the byte holds 8 bucket bits of which the level takes the top dbits
 	__shared__ uint32_t s_cnt[256];
 	const uint32_t t0 = blockIdx.x * HIST_SIDE_TILES;
 	const uint32_t t1 = t0 + HIST_SIDE_TILES < ntiles ? t0 + HIST_SIDE_TILES : ntiles;
-	uint32_t seg = find_segment(tile_first, S, t0), cur = seg;
+	uint32_t seg = find_segment(tile_first, S, t0), cur = seg / seg_div;
 	s_cnt[threadIdx.x] = 0;
 	__syncthreads();
 	for (uint32_t t = t0; t < t1; ++t) {
 		while (t >= tile_first[seg + 1]) ++seg;  // tile_first[S] = ntiles > t: ends; segments without tiles are passed over
-		if (seg != cur) {  // the counts so far belong to the segment left behind
+		if (seg / seg_div != cur) {  // the counts so far belong to the segment left behind
 			__syncthreads();
 			if (threadIdx.x < (1u << dbits) && s_cnt[threadIdx.x]) atomicAdd(&hist[((uint64_t)cur << dbits) + threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
 			s_cnt[threadIdx.x] = 0;
 			__syncthreads();
-			cur = seg;
+			cur = seg / seg_div;
 		}
 		const uint64_t begin = seg_begin[seg] + (uint64_t)(t - tile_first[seg]) * TILE;
 		const uint64_t send = seg_end ? seg_end[seg] : seg_begin[seg + 1];
@@ -1135,9 +1172,9 @@ __global__ __launch_bounds__(256) void k_level_hist_side(const uint8_t *__restri
 				uint64_t v;
 				__builtin_memcpy(&v, side + i, 8);
 #pragma unroll
-				for (int b = 0; b < 8; ++b) atomicAdd(&s_cnt[(uint32_t)(v >> (8 * b)) & 255u], 1u);
+				for (int b = 0; b < 8; ++b) atomicAdd(&s_cnt[((uint32_t)(v >> (8 * b)) & 255u) >> side_shift], 1u);
 			} else {
-				for (uint64_t j = i; j < end; ++j) atomicAdd(&s_cnt[side[j]], 1u);
+				for (uint64_t j = i; j < end; ++j) atomicAdd(&s_cnt[(uint32_t)side[j] >> side_shift], 1u);
 			}
 		}
 	}

@@ -29,14 +29,14 @@ def assert_records_equal(a, b, what=""):
 
 
 def gpu_vs_oracle(ro, packed, offsets, lengths, k, bloom_bits=None, W=None, purge=True, batches=1, tmpdir=None, first_read_id=0,
-                  sweeps=(1 | 16 | (8 << 8) | 0x20000, 1 | 32 | (12 << 8), 1 | 16 | (19 << 8), 1 | 16 | (12 << 8) | 0x10000, 1 | 16 | (19 << 8) | 0x200000, 1 | 32 | (10 << 8) | 0x200000, 1 | 16 | (12 << 8) | 0x400000, 1 | 32 | (8 << 8) | 0x800000, 1 | 16 | 0x2000000, 1 | 32 | (9 << 8) | 0x4000000, 1 | 16 | (17 << 8) | 0x8000000, 1 | 32 | (12 << 8) | 0x8000000 | 0x10000, 1 | 16 | (12 << 8) | 0x40000000, 1 | 32 | 0x2000000 | 0x80000000, 2 | 32, 2 | 16 | 0x20000)):
+                  sweeps=(1 | 16 | (8 << 8) | 0x20000, 1 | 32 | (12 << 8), 1 | 16 | (19 << 8), 1 | 16 | (12 << 8) | 0x10000, 1 | 16 | (19 << 8) | 0x200000, 1 | 32 | (10 << 8) | 0x200000, 1 | 16 | (12 << 8) | 0x400000, 1 | 32 | (8 << 8) | 0x800000, 1 | 16 | 0x2000000, 1 | 32 | (9 << 8) | 0x4000000, 1 | 16 | (17 << 8) | 0x8000000, 1 | 32 | (12 << 8) | 0x8000000 | 0x10000, 1 | 16 | (12 << 8) | 0x40000000, 1 | 32 | 0x2000000 | 0x80000000, 1 | 16 | 8 | (13 << 8), 1 | 32 | 8 | (17 << 8) | 0x100000, 1 | 16 | 8 | 0x2000000, 1 | 32 | 0x80 | (12 << 8), 2 | 32, 2 | 16 | 0x20000)):
     """single-rank parity through the C ABI, once per sweep implementation: the partitioned sweep
     (super-k-mer records + LDS aggregation) with 2^8, 2^12 and 2^19 buckets = one, two and three partition
     levels (records cut by k_superkmers_lanes where it applies; flag 0x10000 forces k_superkmers; aggregated by a wavefront
     per bucket, k_aggregate, or with flag 0x200000 by a workgroup per bucket, k_aggregate_wg), and the direct sweep;
     flag 0x400000 builds the vertex table range by range from partitioned entries (k_build_ranges) however small it is, 0x800000 never
     (one table upsert per occurrence); flag 0x2000000 with no bucket count given sizes the partition from a sample of the records
-    (the route big inputs take by themselves), flag 0x4000000 aggregates with the 512-slot tables of diverse inputs; flag 0x80000000 counts the sample's distinct k-mers with the nested sweep instead of the one-launch set; flag 0x40000000 cuts the records of k = 31 with the generic lane-per-read kernel (every other sweep here takes the kernel unrolled for its window of 17 m-mers); flag 0x8000000 keeps the 24-byte records where k <= 31 would take the 20-byte form (every other sweep here takes that one when k <= 31); flag 16 asks for the Bloom-region
+    (the route big inputs take by themselves), flag 0x4000000 aggregates with the 512-slot tables of diverse inputs; flag 0x80000000 counts the sample's distinct k-mers with the nested sweep instead of the one-launch set; flag 8 folds the first partition level into the record kernel (k = 31: runs per workgroup instead of chunks, what big inputs get by themselves) and flag 0x80 forbids it; flag 0x40000000 cuts the records of k = 31 with the generic lane-per-read kernel (every other sweep here takes the kernel unrolled for its window of 17 m-mers); flag 0x8000000 keeps the 24-byte records where k <= 31 would take the 20-byte form (every other sweep here takes that one when k <= 31); flag 16 asks for the Bloom-region
     partitioning (it falls back by itself when the filter is too full), flag 32 for the dense first-touch
     stamps; flag 0x20000 makes the Bloom items straight into their first partition level even
     when the key array is sparse (k_bloom_scatter_items instead of k_bloom_items + one more k_scatter64 level);
