@@ -416,11 +416,12 @@ def main():
         occ0, cand0, recs0 = st["occurrences"], st["candidates"], st["superkmer_records"]
         rec_bytes = 20 if k <= 31 else 8 * (2 * W + 1)  # rg_record_counts reports the same
         ent_bytes = 16 if W == 1 else 32                # an admitted entry between the log and the table (rg_table.h)
+        scatter_levels = st["partition_levels"] - (1 if st.get("folded_level_bits") else 0)   # levels that are a k_scatter pass of their own
         alg_bytes = {
             "k_count": occ0 * (L / (4.0 * n_per_read) + Kb + 8),            # read bits + key compare + count RMW
             "k_superkmers": occ0 * L / (4.0 * n_per_read) + recs0 * rec_bytes,  # read bits in, records out
-            "k_superkmers_lanes": occ0 * L / (4.0 * n_per_read) + recs0 * rec_bytes,  # same bytes, a lane per read
-            "k_scatter": st["partition_levels"] * 2 * recs0 * rec_bytes + max(0, st["partition_levels"] - 1) * recs0,  # records in + out per level, + the next level's digit byte
+            "k_superkmers_lanes": occ0 * L / (4.0 * n_per_read) + recs0 * (rec_bytes + (1 if st.get("folded_level_bits") else 0)),  # same bytes, a lane per read (+ a digit byte per record when it does the first level)
+            "k_scatter": scatter_levels * 2 * recs0 * rec_bytes + max(0, scatter_levels - 1) * recs0,  # records in + out per level, + the next level's digit byte
             "k_level_hist": max(0, st["partition_levels"] - 1) * recs0 * rec_bytes,
             "k_level_hist_side": max(0, st["partition_levels"] - 1) * recs0,     # one digit byte per record and level
             "k_aggregate": recs0 * rec_bytes + st["log_entries"] * 32,       # records in, entries out

@@ -370,6 +370,7 @@ typedef struct rg_stats {
 	uint64_t log_entries;       /* partitioned sweep: aggregated entries handed to the table merge */
 	uint64_t bloom_partitioned; /* admission resolved by: 0 dense first-touch stamps, 1 Bloom-region partitioning of (bit, key) items, 2 key partitions (filters of 2^B bits) */
 	uint64_t host_syncs;        /* times the host has waited for the handle's stream so far (sizes read back for the next allocation or grid) */
+	uint64_t folded_level_bits; /* partitioned sweep: bits of the first partition level done by the record kernel itself (0 = none); partition_levels counts it */
 } rg_stats;
 int rg_get_stats(rg_handle *h, rg_stats *out);
 

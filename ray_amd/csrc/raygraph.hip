@@ -2157,7 +2157,8 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	h->log_all_unique = flag_unique && h->h_counters[PC_NONUNIQUE] == 0 && h->h_counters[PC_LDS_SPILL] == 0;
 	h->log_keys = h->h_counters[PC_LOG_KEYS];
 	h->stats.superkmer_records = valid;
-	h->stats.partition_levels = (uint64_t)((dbits[0] > 0) + (dbits[1] > 0) + (dbits[2] > 0));
+	h->stats.partition_levels = (uint64_t)((dbits[0] > 0) + (dbits[1] > 0) + (dbits[2] > 0) + (dbits[3] > 0));
+	h->stats.folded_level_bits = (uint64_t)fbits;
 	h->stats.log_entries = *out_n;
 	if (getenv("RG_DEBUG"))
 		fprintf(stderr, "[raygraph] partitioned sweep: %llu reads, %llu occurrences, 2^%d buckets, %llu record slots (%llu valid, cap %llu), log %llu entries (cap %llu), %llu LDS spills, %llu bucket retries\n",
