@@ -371,6 +371,7 @@ typedef struct rg_stats {
 	uint64_t bloom_partitioned; /* admission resolved by: 0 dense first-touch stamps, 1 Bloom-region partitioning of (bit, key) items, 2 key partitions (filters of 2^B bits) */
 	uint64_t host_syncs;        /* times the host has waited for the handle's stream so far (sizes read back for the next allocation or grid) */
 	uint64_t folded_level_bits; /* partitioned sweep: bits of the first partition level done by the record kernel itself (0 = none); partition_levels counts it */
+	uint64_t items_from_sweep;  /* 1: the Bloom admission started from items the aggregation made while it wrote the log (no pass over the log to make them) */
 } rg_stats;
 int rg_get_stats(rg_handle *h, rg_stats *out);
 
@@ -385,6 +386,7 @@ int rg_release_cached_memory(void);
 /* Forces internal routes that the library otherwise chooses by itself; results never depend on them.  No counterpart
  * in the reference; a plugin leaves it alone.  Must be called before the counting starts.  flags:
  *   bits 0-7   sweep: 0 = automatic, 1 = force the partitioned sweep, 2 = force the direct sweep
+ *   bit  2     the aggregation never makes the Bloom admission's items on the way (one rank, filters of 2^28 bits or more)
  *   bit  3     fold the first partition level into the record kernel on small inputs too (k = 31)
  *   bit  4     force the Bloom resolution by (bit, key) items per Bloom region
  *   bit  5     force the dense first-touch stamps

@@ -1343,6 +1343,17 @@ struct rg_handle {
 	// rg_histogram is called twice by every caller (size query, then fill): the table is scanned once
 	bool log_all_unique = false;         // the last sweep's log holds every key once
 	uint64_t log_keys = 0;               // entries of the last sweep's log
+	// the Bloom admission's items of that log, made by k_aggregate on the way (AggItems): valid for exactly this log and filter size
+	struct HeldItems {
+		Item16 *items = nullptr;
+		uint8_t *side = nullptr;
+		uint32_t *d_count = nullptr;
+		std::vector<uint32_t> count;  // what each run holds
+		uint32_t n_wg = 0, run_cap = 0;
+		uint64_t m_bits = 0, total = 0;
+		const Slot *log = nullptr;
+		bool valid = false;
+	} held;
 	Slot *pending_log = nullptr;         // size == 1: the sweep's log of distinct k-mers, admitted before it is inserted
 	bool pending_borrowed = false;       // the pending log is the caller's buffer (rg_adopt_entries): never freed here
 	uint64_t pending_n = 0, pending_keys = 0;
@@ -1412,6 +1423,13 @@ static int fail(rg_handle *h, int code, const char *fmt, ...) {
 		hipError_t e_ = (call);                                                                            \
 		if (e_ != hipSuccess) return fail(h, e_ == hipErrorOutOfMemory ? RG_ERR_NOMEM : RG_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
 	} while (0)
+
+static void drop_held_items(rg_handle *h) {
+	pool_free(h->cfg.device, h->held.items);
+	pool_free(h->cfg.device, h->held.side);
+	pool_free(h->cfg.device, h->held.d_count);
+	h->held = rg_handle::HeldItems();
+}
 
 static int grid_for(uint64_t items) {
 	uint64_t b = (items + BLOCK - 1) / BLOCK;
@@ -1591,6 +1609,7 @@ struct AggLaunch {
 	// from the record sample)
 	uint64_t occ_per_bucket() const { return wg ? (uint64_t)KS * 24 : 4096; }
 	unsigned grid_for_buckets(uint64_t n, int n_cu) const { return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n + per_group() - 1) / per_group(), (uint64_t)n_cu * occ)); }
+	AggItems items = {nullptr, nullptr, nullptr, 0, 0, 0, 0};  // k_aggregate makes the Bloom admission's items on the way (sweep_partitioned_t decides)
 	void fast(rg_handle *h, unsigned grid, const RM *recs, const unsigned long long *begin, uint32_t nb, int k, Slot *log, uint64_t log_cap,
 	          uint32_t flag_unique, uint32_t *retry, int m, uint32_t rbits) const {
 		if (wg)
@@ -1598,10 +1617,10 @@ struct AggLaunch {
 			                   flag_unique, (const uint32_t *)nullptr, retry, m, rbits);
 		else if (big)
 			hipLaunchKernelGGL((k_aggregate<W, false, AGG_SLOTS_BIG, C>), dim3(grid), dim3(64 * agg_waves<W>()), 0, h->stream, recs, begin, nb, k, log, log_cap, h->d_counters,
-			                   flag_unique, (const uint32_t *)nullptr, retry, m, rbits);
+			                   flag_unique, (const uint32_t *)nullptr, retry, m, rbits, items);
 		else
 			hipLaunchKernelGGL((k_aggregate<W, false, AGG_SLOTS, C>), dim3(grid), dim3(64 * agg_waves<W>()), 0, h->stream, recs, begin, nb, k, log, log_cap, h->d_counters, flag_unique,
-			                   (const uint32_t *)nullptr, retry, m, rbits);
+			                   (const uint32_t *)nullptr, retry, m, rbits, items);
 	}
 	void slow(rg_handle *h, unsigned grid, const RM *recs, const unsigned long long *begin, uint32_t nlist, int k, Slot *log, uint64_t log_cap,
 	          uint32_t flag_unique, const uint32_t *list, int m, uint32_t rbits) const {
@@ -1610,10 +1629,10 @@ struct AggLaunch {
 			                   flag_unique, list, (uint32_t *)nullptr, m, rbits);
 		else if (big)
 			hipLaunchKernelGGL((k_aggregate<W, true, AGG_SLOTS_BIG, C>), dim3(grid), dim3(64 * agg_waves<W>()), 0, h->stream, recs, begin, nlist, k, log, log_cap, h->d_counters,
-			                   flag_unique, list, (uint32_t *)nullptr, m, rbits);
+			                   flag_unique, list, (uint32_t *)nullptr, m, rbits, items);
 		else
 			hipLaunchKernelGGL((k_aggregate<W, true, AGG_SLOTS, C>), dim3(grid), dim3(64 * agg_waves<W>()), 0, h->stream, recs, begin, nlist, k, log, log_cap, h->d_counters, flag_unique,
-			                   list, (uint32_t *)nullptr, m, rbits);
+			                   list, (uint32_t *)nullptr, m, rbits, items);
 	}
 };
 
@@ -2046,7 +2065,46 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	}
 	// entries may be marked unique unless other ranks aggregate the same keys (entry route, size > 1)
 	const uint32_t flag_unique = (h->cfg.size == 1 || ext) ? 1u : 0u;
+	// One rank, a filter of 2^28 bits or more (the reference's cap is 2^33: every large input) and a log sized by the record
+	// sample: k_aggregate makes the Bloom admission's items while it writes the log, and rg_resolve_admission starts from
+	// them instead of reading the log to make them (k_xor_keys: 13 ms on C2 with 1 % errors, 1.1 error-free).  A run that
+	// overflows, a log that had to grow, an entry that is not unique: the items are dropped and the admission goes the
+	// usual way.  rg_debug_set bit 2: never.
+	if (!nested) drop_held_items(h);
+	bool with_items = false;
+	uint64_t items_bits = 0;
+	if (!nested && !ext && h->cfg.size == 1 && flag_unique && !agg.wg && !(h->dbg & 0x4u) && sized_by_sample && (sample_distinct >= (double)(1u << 21) || (h->dbg & 0x2000000u))) {  // (bit 25: the sample, hence this, on small inputs too: tests)
+		uint64_t mb = h->cfg.bloom_bits;
+		if (mb == RG_BLOOM_DEFAULT) {  // as rg_resolve_admission will size it (MessageProcessor.cpp:886-899 + VerticesExtractor.cpp:276-320)
+			mb = 4ull * ((uint64_t)h->cfg.k * 2 * 2) * h->n_reads;
+			if (mb > 1024ull * 1024 * 1024 * 8) mb = 1024ull * 1024 * 1024 * 8;
+		}
+		if (mb >= (1ull << 28) && !(mb & (mb - 1))) {  // (2^28: what leaves the admission's key partition two levels or more behind this one)
+			const uint64_t nruns = (uint64_t)AGG_ITEM_RUNS * agg_grid;
+			const double share = (double)(log_cap - log_slack) / (double)nruns;
+			const uint64_t rcap = ((uint64_t)(share * 1.25 + 8.0 * std::sqrt(share)) + 64 + 63) & ~63ull;
+			if (rcap < (1ull << 31) && pool_alloc(dev, (void **)&h->held.items, nruns * rcap * sizeof(Item16)) == hipSuccess &&
+			    pool_alloc(dev, (void **)&h->held.side, nruns * rcap) == hipSuccess && pool_alloc(dev, (void **)&h->held.d_count, nruns * sizeof(uint32_t)) == hipSuccess) {
+				int B = 0;
+				while ((1ull << B) < mb) B++;
+				agg.items = AggItems{h->held.items, h->held.side, h->held.d_count, (uint32_t)rcap, agg_grid, mb - 1, B - 5};
+				h->held.n_wg = agg_grid;
+				h->held.run_cap = (uint32_t)rcap;
+				h->held.count.resize(nruns);
+				items_bits = mb;
+				with_items = true;
+			} else {
+				(void)hipGetLastError();
+				drop_held_items(h);
+			}
+		}
+	}
 	for (int attempt = 0;; ++attempt) {
+		if (with_items && attempt > 0) {  // the log had to grow: the runs were sized for the first one
+			with_items = false;
+			agg.items.items = nullptr;
+			drop_held_items(h);
+		}
 		const bool force_probe = (h->dbg & 0x40000) != 0;
 		const bool will_probe = !nested && attempt == 0 && !(h->dbg & 64) && !sized_by_sample && (NBUCK >= (1u << 16) || force_probe);
 		const uint32_t P = force_probe ? std::max<uint32_t>((uint32_t)NBUCK / 4, 1u) : (uint32_t)NBUCK / 256;
@@ -2103,6 +2161,8 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 		}
 		bool too_small = false;
 		hipError_t e0 = hipMemsetAsync(h->d_counters + PC_LOG_CURSOR, 0, 6 * sizeof(unsigned long long), h->stream);
+		if (e0 == hipSuccess && with_items) e0 = hipMemsetAsync(h->d_counters + PC_ITEM_OVF, 0, sizeof(unsigned long long), h->stream);
+		if (e0 == hipSuccess && with_items) e0 = hipMemsetAsync(h->held.d_count, 0, h->held.count.size() * sizeof(uint32_t), h->stream);
 		if (e0 == hipSuccess) e0 = hipMemsetAsync(h->d_counters + PC_CUT_ANCHORED, 0, 2 * sizeof(unsigned long long), h->stream);
 		if (e0 == hipSuccess && mostly_overflowing) {
 			// an attempt at whole buckets would be thrown away for most of them (C2 with 1 % errors: 47 ms): every bucket goes
@@ -2126,10 +2186,12 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 			}
 		}
 		hipError_t e = (e0 != hipSuccess) ? e0 : hipGetLastError();
+		if (e == hipSuccess && !rc && with_items) e = hipMemcpyAsync(h->held.count.data(), h->held.d_count, h->held.count.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream);
 		if (e == hipSuccess && !rc) rc = sync_counters(h);
 		if (e != hipSuccess || rc) {
 			pool_free(dev, d_retry);
 			cleanup();
+			drop_held_items(h);
 			pool_free(dev, log);
 			return e != hipSuccess ? fail(h, RG_ERR_HIP, "k_aggregate: %s", hipGetErrorString(e)) : rc;
 		}
@@ -2159,6 +2221,19 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	if (nested) return RG_OK;  // the caller reads PC_LOG_KEYS
 	h->log_all_unique = flag_unique && h->h_counters[PC_NONUNIQUE] == 0 && h->h_counters[PC_LDS_SPILL] == 0;
 	h->log_keys = h->h_counters[PC_LOG_KEYS];
+	if (with_items) {
+		uint64_t total = 0;
+		for (auto c : h->held.count) total += c;
+		if (h->log_all_unique && h->h_counters[PC_ITEM_OVF] == 0 && total == h->log_keys && *out_n < (1ull << 32)) {
+			h->held.valid = true;
+			h->held.log = log;
+			h->held.m_bits = items_bits;
+			h->held.total = total;
+		} else {
+			if (getenv("RG_DEBUG")) fprintf(stderr, "[raygraph] the items k_aggregate made are dropped (%llu of %llu keys, %llu runs overflowed)\n", (unsigned long long)total, (unsigned long long)h->log_keys, (unsigned long long)h->h_counters[PC_ITEM_OVF]);
+			drop_held_items(h);
+		}
+	}
 	h->stats.superkmer_records = valid;
 	h->stats.partition_levels = (uint64_t)((dbits[0] > 0) + (dbits[1] > 0) + (dbits[2] > 0) + (dbits[3] > 0));
 	h->stats.folded_level_bits = (uint64_t)fbits;
@@ -2543,6 +2618,20 @@ static int bloom_xor(rg_handle *h, Table &T, uint64_t m_bits, uint64_t keys, boo
 		c1 = PB / 2;
 		c3 = PB - c1;
 	}
+	// the items of this very log and filter, made by k_aggregate while it wrote the log (AggItems): the first level (5 bits) is
+	// done, in runs per workgroup of that kernel
+	const bool from_items = h->held.valid && h->held.log == T.slots && h->held.m_bits == m_bits && h->held.total == keys && !counted && PB - 5 > 8 && PB - 5 <= 16;
+	if (!from_items) drop_held_items(h);  // (whatever is held belongs to another log or filter)
+	rg_handle::HeldItems held;            // owned here from now on
+	h->stats.items_from_sweep = from_items ? 1 : 0;
+	if (from_items) {
+		held = h->held;
+		h->held = rg_handle::HeldItems();
+		c1 = 5;
+		c2 = (PB - 5) / 2;
+		c3 = PB - 5 - c2;
+	}
+	const uint32_t item_runs = from_items ? AGG_ITEM_RUNS * held.n_wg : 0;
 	const uint64_t m_mask = m_bits - 1;
 	int n_cu = 256;
 	(void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
@@ -2557,9 +2646,14 @@ static int bloom_xor(rg_handle *h, Table &T, uint64_t m_bits, uint64_t keys, boo
 	// A range that overflows all the same is noticed and the counted way taken.
 	const uint64_t S1 = 1ull << c1;
 	const uint64_t slot1 = (keys / S1 + (uint64_t)(8.0 * std::sqrt((double)keys / (double)S1)) + 4096 + 63) & ~63ull;
-	const uint64_t cap1 = counted ? keys : S1 * slot1;  // items the first level's output holds
+	const uint64_t cap1 = from_items ? (uint64_t)item_runs * held.run_cap : (counted ? keys : S1 * slot1);  // items the first level's output holds
+	Item16 *Bb_own = nullptr;  // from_items: the middle level's output is a block of its own (A is k_aggregate's)
 	auto cleanup = [&]() {
 		pool_free(dev, d_lim);
+		pool_free(dev, Bb_own);
+		pool_free(dev, held.d_count);
+		if (from_items && (void *)d_side == (void *)held.side) d_side = nullptr;
+		pool_free(dev, held.side);
 		pool_free(dev, A);  // Bb is its second half
 		if ((void *)pk != (void *)A) {
 			pool_free(dev, pk);
@@ -2580,9 +2674,17 @@ static int bloom_xor(rg_handle *h, Table &T, uint64_t m_bits, uint64_t keys, boo
 	// with a middle level the last one reads Bb and A is free by then: the packed words and slot indices (12 B per position)
 	// take its place (16 B per key) when they fit -- at C5's share per GPU (3.5e9 keys) that is 42 GB less at the peak
 	const bool alias = c2 && npos_cap * 12 + 256 <= keys * sizeof(Item16);
-	hipError_t e = pool_alloc(dev, (void **)&A, (cap1 + (c2 ? keys : 0)) * sizeof(Item16));  // both item buffers in one block (see build_table_ranges)
-	if (e == hipSuccess && c2) Bb = A + cap1;
-	if (e == hipSuccess) e = pool_alloc(dev, (void **)&d_lim, 256 * sizeof(unsigned long long));
+	hipError_t e = hipSuccess;
+	if (from_items) {
+		A = held.items;
+		held.items = nullptr;
+		e = pool_alloc(dev, (void **)&Bb_own, keys * sizeof(Item16));
+		Bb = Bb_own;
+	} else {
+		e = pool_alloc(dev, (void **)&A, (cap1 + (c2 ? keys : 0)) * sizeof(Item16));  // both item buffers in one block (see build_table_ranges)
+		if (e == hipSuccess && c2) Bb = A + cap1;
+	}
+	if (e == hipSuccess) e = pool_alloc(dev, (void **)&d_lim, std::max<uint64_t>(256, (uint64_t)item_runs + 1) * sizeof(unsigned long long));
 	if (alias) {
 		pk = (unsigned long long *)A;
 		ix = (uint32_t *)((uint8_t *)A + ((npos_cap * 8 + 255) & ~255ull));
@@ -2591,7 +2693,8 @@ static int bloom_xor(rg_handle *h, Table &T, uint64_t m_bits, uint64_t keys, boo
 		if (e == hipSuccess) e = pool_alloc(dev, (void **)&ix, npos_cap * 4);
 	}
 	if (e == hipSuccess) e = pool_alloc(dev, (void **)&planes, 8 * plane_words * 8);
-	if (e == hipSuccess) e = pool_alloc(dev, (void **)&d_side, cap1);
+	if (from_items) d_side = held.side;
+	else if (e == hipSuccess) e = pool_alloc(dev, (void **)&d_side, cap1);
 	if (e == hipSuccess) e = pool_alloc(dev, (void **)&d_lost, T.cap + 4);
 	if (e == hipSuccess) e = pool_alloc(dev, (void **)&d_seg, (SEGMAX + 1) * sizeof(unsigned long long));
 	if (e == hipSuccess) e = pool_alloc(dev, (void **)&d_tile, (SEGMAX + 1) * sizeof(uint32_t));
@@ -2622,7 +2725,13 @@ static int bloom_xor(rg_handle *h, Table &T, uint64_t m_bits, uint64_t keys, boo
 	XTRY(hipMemsetAsync(d_hist, 0, 256 * sizeof(unsigned long long), h->stream));
 	// level 1: items produced straight into the ranges of the top c1 bits -- ranges sized in advance, or (counted) from a histogram pass
 	std::vector<unsigned long long> seg_begin, seg_fill;  // seg_fill: where the filling of the level-1 ranges ended (sized in advance only)
-	if (counted) {
+	if (from_items) {  // done by k_aggregate: its runs are the ranges, filled as far as it counted
+		seg_begin.resize((size_t)item_runs + 1);
+		seg_fill.resize(item_runs);
+		for (uint32_t r = 0; r <= item_runs; ++r) seg_begin[r] = (uint64_t)r * held.run_cap;
+		for (uint32_t r = 0; r < item_runs; ++r) seg_fill[r] = seg_begin[r] + held.count[r];
+		XTRY(hipMemcpyAsync(d_lim, seg_fill.data(), (size_t)item_runs * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
+	} else if (counted) {
 		const int grid_scan = (int)std::min<uint64_t>((uint64_t)n_cu * 8, (T.cap + 255) / 256);
 		ProfScope ps(h, "k_xor_hist");
 		if (h->W == 1) hipLaunchKernelGGL(k_xor_hist<1>, dim3(grid_scan), dim3(256), 0, h->stream, T.slots, T.cap, m_mask, B - c1, (1u << c1) - 1u, d_hist);
@@ -2639,7 +2748,7 @@ static int bloom_xor(rg_handle *h, Table &T, uint64_t m_bits, uint64_t keys, boo
 	}
 	const int nd = c2 ? c2 : c3;                 // bits of the level after the first
 	const int nshift = B - c1 - nd;
-	{
+	if (!from_items) {
 		ProfScope ps(h, "k_xor_keys");
 		const unsigned grid = (unsigned)((T.cap + XOR_TILE - 1) / XOR_TILE);
 		const unsigned long long *lim = counted ? nullptr : d_lim;
@@ -2647,7 +2756,7 @@ static int bloom_xor(rg_handle *h, Table &T, uint64_t m_bits, uint64_t keys, boo
 		else hipLaunchKernelGGL(k_xor_keys<2>, dim3(grid), dim3(XOR_THREADS), 0, h->stream, T.slots, T.cap, m_mask, B - c1, (1u << c1) - 1u, d_hist, A, d_side, nshift, (1u << nd) - 1u, lim, h->d_counters);
 		XTRY(hipGetLastError());
 	}
-	if (!counted) {
+	if (!counted && !from_items) {
 		XTRY(hipMemcpyAsync(seg_fill.data(), d_hist, S1 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
 		const int rcs = sync_counters(h);
 		if (rcs) {
@@ -2666,7 +2775,9 @@ static int bloom_xor(rg_handle *h, Table &T, uint64_t m_bits, uint64_t keys, boo
 	for (int level = 1; level <= (c2 ? 2 : 1); ++level) {
 		const bool final_level = level == (c2 ? 2 : 1);
 		const int db = final_level ? c3 : c2;
-		const uint64_t S64 = 1ull << used;
+		const bool runs = from_items && level == 1;  // the segments are k_aggregate's runs, held.n_wg of them per output segment
+		const uint64_t S64 = runs ? item_runs : 1ull << used;
+		const uint32_t seg_div = runs ? held.n_wg : 1u;
 		const bool gaps = level == 1 && !counted;  // the segments are the ranges sized in advance: [seg_begin[s], seg_fill[s])
 		uint64_t held = 0;
 		if (!gaps) {
@@ -2692,11 +2803,13 @@ static int bloom_xor(rg_handle *h, Table &T, uint64_t m_bits, uint64_t keys, boo
 		tile_first[S] = (uint32_t)ntiles;
 		XTRY(hipMemcpyAsync(d_seg, seg_begin.data(), (S + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
 		XTRY(hipMemcpyAsync(d_tile, tile_first.data(), (S + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
-		const uint64_t nout = (uint64_t)S << db;
+		const uint64_t nout = (uint64_t)(S / seg_div) << db;
 		XTRY(hipMemsetAsync(d_hist, 0, nout * sizeof(unsigned long long), h->stream));
 		{
 			ProfScope ps(h, "k_level_hist_side");
-			hipLaunchKernelGGL(k_level_hist_side<XOR_TILE>, dim3((unsigned)((ntiles + HIST_SIDE_TILES - 1) / HIST_SIDE_TILES)), dim3(256), 0, h->stream, d_side, S, d_seg, d_tile, db, d_hist, (uint32_t)ntiles, d_segend);
+			// (runs: k_aggregate left 8 bits of o per item, of which this level takes the top db)
+			hipLaunchKernelGGL(k_level_hist_side<XOR_TILE>, dim3((unsigned)((ntiles + HIST_SIDE_TILES - 1) / HIST_SIDE_TILES)), dim3(256), 0, h->stream, d_side, S, d_seg, d_tile, db, d_hist, (uint32_t)ntiles, d_segend,
+			                   seg_div, runs ? 8 - db : 0);
 			XTRY(hipGetLastError());
 		}
 		if (final_level) hipLaunchKernelGGL(k_round64, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, h->stream, d_hist, nout);
@@ -2708,10 +2821,10 @@ static int bloom_xor(rg_handle *h, Table &T, uint64_t m_bits, uint64_t keys, boo
 			const int shift = B - used - db;
 			if (final_level)
 				hipLaunchKernelGGL((k_scatter16<true>), dim3((unsigned)ntiles), dim3(XOR_THREADS), 0, h->stream, level_in, S, d_seg, d_tile, shift, db, d_hist, (Item16 *)nullptr,
-				                   (uint8_t *)nullptr, 0, 0u, pk, ix, (1ull << R) - 1ull, d_segend);
+				                   (uint8_t *)nullptr, 0, 0u, pk, ix, (1ull << R) - 1ull, d_segend, seg_div);
 			else
 				hipLaunchKernelGGL((k_scatter16<false>), dim3((unsigned)ntiles), dim3(XOR_THREADS), 0, h->stream, level_in, S, d_seg, d_tile, shift, db, d_hist, Bb, d_side,
-				                   shift - c3, (1u << c3) - 1u, (unsigned long long *)nullptr, (uint32_t *)nullptr, 0ull, d_segend);
+				                   shift - c3, (1u << c3) - 1u, (unsigned long long *)nullptr, (uint32_t *)nullptr, 0ull, d_segend, seg_div);
 			XTRY(hipGetLastError());
 		}
 		used += db;
@@ -3173,6 +3286,7 @@ int rg_destroy(rg_handle *h) {
 		}
 	table_free(h, h->tab);
 	table_free(h, h->local);
+	drop_held_items(h);
 	if (h->d_counters) pool_free(h->cfg.device, h->d_counters);
 	if (h->h_counters) (void)hipHostFree(h->h_counters);
 	if (h->d_owner) pool_free(h->cfg.device, h->d_owner);
@@ -3464,6 +3578,7 @@ int rg_export_owner_buckets(rg_handle *h, void *d_out, uint64_t capacity_entries
 }
 
 int rg_merge_entries(rg_handle *h, const void *d_entries, uint64_t n_entries) {
+	if (h) drop_held_items(h);  // (items k_aggregate made belong to the log of rg_count_local alone)
 	if (h) h->hist_valid = false;
 	if (!h) return RG_ERR_ARG;
 	if (h->phase != PH_COUNTED_LOCAL && h->phase != PH_MERGING) return fail(h, RG_ERR_STATE, "rg_merge_entries needs rg_count_local first");
@@ -3525,6 +3640,7 @@ int rg_merge_entries(rg_handle *h, const void *d_entries, uint64_t n_entries) {
 }
 
 int rg_release_local(rg_handle *h) {
+	if (h) drop_held_items(h);  // (items k_aggregate made belong to the log of rg_count_local alone)
 	if (!h) return RG_ERR_ARG;
 	if (h->phase == PH_MERGING) return RG_OK;  // already released (by this call or by the first rg_merge_entries)
 	if (h->phase != PH_COUNTED_LOCAL) return fail(h, RG_ERR_STATE, "rg_release_local needs rg_count_local / rg_count_records first");
@@ -3538,6 +3654,7 @@ int rg_release_local(rg_handle *h) {
 }
 
 int rg_adopt_entries(rg_handle *h, void *d_entries, uint64_t n_entries) {
+	if (h) drop_held_items(h);  // (items k_aggregate made belong to the log of rg_count_local alone)
 	if (h) h->hist_valid = false;
 	if (!h) return RG_ERR_ARG;
 	if (h->phase != PH_COUNTED_LOCAL && h->phase != PH_MERGING) return fail(h, RG_ERR_STATE, "rg_adopt_entries needs rg_count_local first");

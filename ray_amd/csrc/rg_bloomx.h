@@ -35,17 +35,7 @@ static constexpr int XOR_THREADS = 512;
 static constexpr unsigned long long XOR_PAD = ~0ull;  // padding entry of the packed array
 static constexpr int XOR_SPER = 3;               // items per stream a thread of k_xor_region keeps in registers (8 streams)
 
-struct Item16 {
-	unsigned long long a;  // o << 31 | low 31 bits of the slot index
-	unsigned long long b;  // arrival stamp of the key (49 bits) | bit 31 of the slot index << 63: key arrays of up to 2^32 slots
-};
-
-template <int W>
-__device__ __forceinline__ uint64_t xor_origin(uint64_t k0, uint64_t k1, uint64_t m_mask) {
-	uint64_t K0, K1;
-	from_internal<W>(k0, k1, K0, K1);
-	return hash2<W>(K0, K1) & m_mask;
-}
+// (Item16 and xor_origin: rg_partition.h, where k_aggregate makes such items too)
 
 // keys per first-level digit (digit = (o >> shift) & dmask)
 template <int W>
@@ -160,7 +150,9 @@ __global__ __launch_bounds__(XOR_THREADS) void k_scatter16(const Item16 *__restr
                                                            unsigned long long *__restrict__ cursors, Item16 *__restrict__ out, uint8_t *__restrict__ side,
                                                            int next_shift, uint32_t next_mask, unsigned long long *__restrict__ pk,
                                                            uint32_t *__restrict__ ix, uint64_t low_mask,
-                                                           const unsigned long long *__restrict__ seg_end = nullptr) {
+                                                           const unsigned long long *__restrict__ seg_end = nullptr, uint32_t seg_div = 1) {
+	// seg_div: the input is the runs k_aggregate left (AggItems) -- seg_div consecutive segments, one per workgroup of that
+	// kernel, share the cursors of output segment seg / seg_div
 	constexpr int PER = XOR_TILE / XOR_THREADS;
 	__shared__ Item16 s_item[XOR_TILE];
 	__shared__ uint8_t s_dig[XOR_TILE];
@@ -194,7 +186,7 @@ __global__ __launch_bounds__(XOR_THREADS) void k_scatter16(const Item16 *__restr
 		}
 	}
 	__syncthreads();
-	const uint32_t total = xor_claim(s_cnt, s_off, s_scan, s_gbase, cursors + ((uint64_t)seg << dbits));
+	const uint32_t total = xor_claim(s_cnt, s_off, s_scan, s_gbase, cursors + ((uint64_t)(seg / seg_div) << dbits));
 #pragma unroll
 	for (int q = 0; q < PER; ++q)
 		if (dr[q] != 0xFFFFFFFFu) {

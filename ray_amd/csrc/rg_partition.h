@@ -189,7 +189,7 @@ __device__ __forceinline__ uint32_t rec_bucket(const Rec20 &c, int m) {  // W ==
 	return bucket_number(canon_mmer(f, m));
 }
 
-enum PartCounter { PC_REC_CURSOR = 16, PC_REC_OVF, PC_LOG_CURSOR, PC_LOG_OVF, PC_LDS_SPILL, PC_AGG_RETRY, PC_NONUNIQUE, PC_LOG_KEYS, PC_SAMPLE, PC_SAMPLE_DISTINCT, PC_SAMPLE_FAIL, PC_CUT_ANCHORED = 30, PC_CUT_EXPANDED = 31 };
+enum PartCounter { PC_REC_CURSOR = 16, PC_REC_OVF, PC_LOG_CURSOR, PC_LOG_OVF, PC_LDS_SPILL, PC_AGG_RETRY, PC_NONUNIQUE, PC_LOG_KEYS, PC_SAMPLE, PC_SAMPLE_DISTINCT, PC_SAMPLE_FAIL, PC_ITEM_OVF, PC_CUT_ANCHORED = 30, PC_CUT_EXPANDED = 31 };
 
 // The sample of the records that sizes the partition: the records whose bucket number has its top SAMPLE_BITS bits clear,
 // i.e. the first 2^(b - SAMPLE_BITS) buckets of a partition into 2^b, whole (the bucket number is a hash: 1 / 4096 of the
@@ -1294,6 +1294,33 @@ __global__ __launch_bounds__(256) void k_scan_add(unsigned long long *__restrict
 // Neither table can overfill: their fill is checked at points between which at most 64 keys arrive
 // (the spill path of the k-mer table is for safety only).  The records of the next round (or of the
 // next bucket's first round) are loaded before the current round is processed.
+// The item of the Bloom admission's key partition (rg_bloomx.h): where a key's eight filter bits start from (o = hash2 & mask),
+// where the key sits (slot of the table, or position in the log) and when it first arrived.
+struct Item16 {
+	unsigned long long a;  // o << 31 | low 31 bits of the slot index
+	unsigned long long b;  // arrival stamp of the key (49 bits) | bit 31 of the slot index << 63: key arrays of up to 2^32 slots
+};
+template <int W>
+__device__ __forceinline__ uint64_t xor_origin(uint64_t k0, uint64_t k1, uint64_t m_mask) {
+	uint64_t K0, K1;
+	from_internal<W>(k0, k1, K0, K1);
+	return hash2<W>(K0, K1) & m_mask;
+}
+// k_aggregate can make those items itself, while an entry is on its way from LDS to the log (round 3): the admission then has
+// no first pass over the log (k_xor_keys: 32 bytes read per entry to make 16).  They go to 32 runs per workgroup by the top
+// 5 bits of o -- run (d, g) = slice [(d * n_wg + g) * run_cap, ...) -- like the records of the folded first level (see
+// k_superkmers_lanes_s), with the next 8 bits of o in a byte beside them; run_count carries the cursors from launch to launch.
+// items == nullptr: nothing of this happens.
+struct AggItems {
+	Item16 *items;
+	uint8_t *side;
+	uint32_t *run_count;
+	uint32_t run_cap, n_wg;
+	uint64_t m_mask;
+	int shift1;  // log2(filter bits) - 5
+};
+static constexpr uint32_t AGG_ITEM_RUNS = 32;
+
 static constexpr uint32_t AGG_SLOTS = 256;      // the k-mer table of a wavefront ...
 static constexpr uint32_t AGG_SLOTS_BIG = 512;  // ... and of the variant for diverse inputs (the sample says a bucket holds about 100 k-mers or more even at 2^24 buckets:
                                                 // reads with 1 % errors at 30x and beyond), two workgroups per CU instead of three, no bucket retried in two halves
@@ -1449,7 +1476,7 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<
                                                               int k, Slot *__restrict__ log, uint64_t log_cap,
                                                               unsigned long long *__restrict__ counters, uint32_t flag_unique,
                                                               const uint32_t *__restrict__ bucket_list, uint32_t *__restrict__ retry_list,
-                                                              int m, uint32_t rbits) {
+                                                              int m, uint32_t rbits, AggItems ai) {
 	// flag_unique: the caller guarantees that nothing outside this launch's log carries the same keys on their way
 	// to the same table; the entries are then marked LOG_UNIQUE (every k-mer lives in exactly one bucket, see
 	// k_superkmers, and a bucket is flushed once per sub-pass, each sub-pass owning a disjoint share of the k-mers).
@@ -1470,6 +1497,11 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<
 	constexpr bool ANCH = agg_anchors<W, SLOW, SLOTS>();
 	constexpr uint32_t ANCHORS = AnchorTable<W>::N;
 	__shared__ AnchorTable<W> s_anchors[ANCH ? agg_waves<W>() : 1];
+	__shared__ uint32_t s_icur[AGG_ITEM_RUNS];  // cursors of this workgroup's item runs (AggItems)
+	if (ai.items) {
+		if (threadIdx.x < AGG_ITEM_RUNS) s_icur[threadIdx.x] = ai.run_count[threadIdx.x * ai.n_wg + blockIdx.x];
+		__syncthreads();
+	}
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	AggTable<W, SLOTS> &T = s_tables[wave];
 	RecTable<W> &R = s_rtables[wave];
@@ -1549,6 +1581,18 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<
 				e.stamp = T.stamp[sl];
 				e.meta = (uint64_t)T.cnt[sl] | ((uint64_t)(T.edges[sl] & 0xFFu) << PEND_SHIFT) | mark;
 				log[dst] = e;
+				if (ai.items) {
+					const uint64_t o = xor_origin<W>(e.k0, e.k1, ai.m_mask);
+					const uint32_t d = (uint32_t)(o >> ai.shift1);
+					const uint32_t at = atomicAdd(&s_icur[d], 1u);
+					if (at < ai.run_cap) {
+						const uint64_t idx = ((uint64_t)d * ai.n_wg + blockIdx.x) * ai.run_cap + at;
+						*reinterpret_cast<ulonglong2 *>(&ai.items[idx]) = make_ulonglong2((o << 31) | (dst & 0x7FFFFFFFull), e.stamp | ((dst >> 31) << 63));
+						ai.side[idx] = (uint8_t)(o >> (ai.shift1 - 8));
+					} else if (at == ai.run_cap) {
+						atomicAdd(&counters[PC_ITEM_OVF], 1ull);
+					}
+				}
 			}
 			T.k0[sl] = EMPTY;
 			if (W == 2) T.k1[sl] = EMPTY;
@@ -2013,6 +2057,10 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<
 	if (chunk_base != NO_CHUNK)
 		for (uint32_t i = chunk_used + lane; i < LOG_CHUNK; i += 64)
 			if (chunk_base + i < log_cap) log[chunk_base + i].k0 = EMPTY;
+	if (ai.items) {
+		__syncthreads();
+		if (threadIdx.x < AGG_ITEM_RUNS) ai.run_count[threadIdx.x * ai.n_wg + blockIdx.x] = s_icur[threadIdx.x] < ai.run_cap ? s_icur[threadIdx.x] : ai.run_cap;
+	}
 }
 
 // ------------------------------------------------------------------------------------------------

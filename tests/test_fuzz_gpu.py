@@ -13,7 +13,7 @@ from ray_amd.synth import make_reads_numpy
 
 pytestmark = pytest.mark.gpu
 
-FLAG_CHOICES = (0x8, 0x80, 0x10000, 0x20000, 0x40000, 0x100000, 0x400000, 0x800000, 0x1000000, 0x2000000, 0x4000000, 0x8000000, 0x10000000, 0x20000000, 0x40000000, 0x80000000)
+FLAG_CHOICES = (0x4, 0x8, 0x80, 0x10000, 0x20000, 0x40000, 0x100000, 0x400000, 0x800000, 0x1000000, 0x2000000, 0x4000000, 0x8000000, 0x10000000, 0x20000000, 0x40000000, 0x80000000)
 
 
 def _case(seed):

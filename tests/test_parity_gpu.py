@@ -241,6 +241,21 @@ def test_power_of_two_filters_by_key_partitions(oracle, k, log2_bits):
     assert want["builder"].stats()["bloom_partitioned"] == 2
 
 
+@pytest.mark.parametrize("k,log2_bits", [(31, 28), (31, 33), (21, 30), (63, 32)])
+def test_admission_items_made_by_the_aggregation(oracle, k, log2_bits):
+    """one rank, a filter of 2^28 bits or more: k_aggregate makes the admission's items while it writes the log (runs per
+    workgroup by the top 5 bits of the key's origin) and the key partition starts from them -- with the flag that forbids
+    it the same result comes from k_xor_keys; one- and two-word keys, with and without the folded record level"""
+    # (k = 63 makes fewer records: more reads, so that the record sample -- 1 / 4096 of the buckets -- is not empty)
+    packed, offsets, lengths = make_reads_numpy(genome=25000 if k < 63 else 120000, read_len=150 if k < 63 else 200, n_reads=7000 if k < 63 else 40000, seed=190 + log2_bits, error=0.02)
+    base = 1 | 0x2000000 | 0x1000000 | 0x400000
+    want = gpu_vs_oracle(oracle, packed, offsets, lengths, k, bloom_bits=1 << log2_bits, sweeps=(base, base | 8))
+    st = want["builder"].stats()
+    assert st["bloom_partitioned"] == 2 and st["items_from_sweep"] == 1
+    want = gpu_vs_oracle(oracle, packed, offsets, lengths, k, bloom_bits=1 << log2_bits, sweeps=(base | 4,))
+    assert want["builder"].stats()["items_from_sweep"] == 0
+
+
 @pytest.mark.parametrize("k", [21, 31, 47, 63])
 def test_hashes_are_checked_against_the_callers(oracle, k):
     """rg_check_hashes / rg_hash_kmers: the device's hash_function_1 / _2 against the caller's own (here the oracle's, the
