@@ -424,7 +424,7 @@ def main():
             "k_scatter": scatter_levels * 2 * recs0 * rec_bytes + max(0, scatter_levels - 1) * recs0,  # records in + out per level, + the next level's digit byte
             "k_level_hist": max(0, st["partition_levels"] - 1) * recs0 * rec_bytes,
             "k_level_hist_side": max(0, st["partition_levels"] - 1) * recs0,     # one digit byte per record and level
-            "k_aggregate": recs0 * rec_bytes + st["log_entries"] * 32,       # records in, entries out
+            "k_aggregate": recs0 * rec_bytes + st["log_entries"] * (32 + (17 if st.get("items_from_sweep") else 0)),  # records in, entries out (+ the admission's 16-byte item and digit byte per entry when it makes them)
             "k_merge": st["log_entries"] * 32 + cand0 * 32,                  # entries in, slots written
             "k_bloom_items": (st["log_entries"] if "k_insert_admitted" in kprof else st["table_slots"]) * 32 + cand0 * 64,  # scan in, 8 items of 8 B per key out
             "k_bloom_hist": (st["log_entries"] if "k_insert_admitted" in kprof else st["table_slots"]) * 32,   # key scan, nothing written
