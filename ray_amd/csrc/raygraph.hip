@@ -44,6 +44,9 @@ enum Counter {
 	C_FILL_LOCAL,   // claimed slots (local aggregation table)
 	C_EXPORT,       // export cursor
 	C_ADOPT_BAD,    // received entries that are not marked unique (rg_merge_entries)
+	C_LOG_MULTI,    // = 10: entries of the pending log seen twice or more (rg_partition.h PC_LOG_MULTI; k_adopt_entries counts them too)
+	C_FP_COUNT,     // = 11: keys the Bloom key partition marked as false positives (k_xor_fp)
+	C_ENT_PRESIZE,  // = 12: admitted entries that found no room in a table range sized in advance (k_scatter_entries)
 	C_NUM = 32
 };
 
@@ -1355,6 +1358,7 @@ struct rg_handle {
 		bool valid = false;
 	} held;
 	Slot *pending_log = nullptr;         // size == 1: the sweep's log of distinct k-mers, admitted before it is inserted
+	uint64_t pending_multi = ~0ull;      // its entries seen twice or more (~0: not known): with the false positives they bound what admission stores
 	bool pending_borrowed = false;       // the pending log is the caller's buffer (rg_adopt_entries): never freed here
 	uint64_t pending_n = 0, pending_keys = 0;
 	bool merge_started = false;          // rg_merge_entries has been called with entries
@@ -2161,6 +2165,7 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 		}
 		bool too_small = false;
 		hipError_t e0 = hipMemsetAsync(h->d_counters + PC_LOG_CURSOR, 0, 6 * sizeof(unsigned long long), h->stream);
+		if (e0 == hipSuccess) e0 = hipMemsetAsync(h->d_counters + PC_LOG_MULTI, 0, sizeof(unsigned long long), h->stream);
 		if (e0 == hipSuccess && with_items) e0 = hipMemsetAsync(h->d_counters + PC_ITEM_OVF, 0, sizeof(unsigned long long), h->stream);
 		if (e0 == hipSuccess && with_items) e0 = hipMemsetAsync(h->held.d_count, 0, h->held.count.size() * sizeof(uint32_t), h->stream);
 		if (e0 == hipSuccess) e0 = hipMemsetAsync(h->d_counters + PC_CUT_ANCHORED, 0, 2 * sizeof(unsigned long long), h->stream);
@@ -2876,7 +2881,8 @@ static int bloom_xor(rg_handle *h, Table &T, uint64_t m_bits, uint64_t keys, boo
 	}
 	{
 		ProfScope ps(h, "k_xor_fp");
-		hipLaunchKernelGGL(k_xor_fp, dim3(grid_for(npos_cap)), dim3(256), 0, h->stream, pk, ix, planes, plane_words, npos_cap, d_lost);
+		XTRY(hipMemsetAsync(h->d_counters + C_FP_COUNT, 0, sizeof(unsigned long long), h->stream));
+		hipLaunchKernelGGL(k_xor_fp, dim3(grid_for(npos_cap)), dim3(256), 0, h->stream, pk, ix, planes, plane_words, npos_cap, d_lost, h->d_counters + C_FP_COUNT);
 		XTRY(hipGetLastError());
 	}
 	if (!keep_lost) {
@@ -2886,7 +2892,13 @@ static int bloom_xor(rg_handle *h, Table &T, uint64_t m_bits, uint64_t keys, boo
 		else hipLaunchKernelGGL(k_admit_lost<2>, dim3(grid), dim3(BLOCK), 0, h->stream, T.slots, T.cap, (const uint32_t *)d_lost, h->d_counters, h->d_hist_dense, h->d_hist_ovf);
 		XTRY(hipGetLastError());
 	}
-	XTRY(rg_stream_sync(h));
+	{  // (with the counters: the false positives counted by k_xor_fp bound what the admission stores)
+		const int rcf = sync_counters(h);
+		if (rcf) {
+			cleanup();
+			return rcf;
+		}
+	}
 	if (keep_lost) {
 		*keep_lost = d_lost;
 		d_lost = nullptr;
@@ -2906,16 +2918,19 @@ __global__ __launch_bounds__(256) void k_adopt_entries(const Slot *__restrict__ 
                                                        unsigned long long *__restrict__ counters) {
 	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-	uint32_t bad = 0;
+	uint32_t bad = 0, multi = 0;
 	for (; i < n; i += stride) {
 		const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(&in[i].k0), b = *reinterpret_cast<const ulonglong2 *>(&in[i].stamp);
 		if (a.x == EMPTY || !(b.y & LOG_UNIQUE)) bad++;
+		else if ((b.y & COUNT_MASK & ~LOG_UNIQUE) >= 2) multi++;  // (what admission stores whatever the filter says: sizes the table build)
 		if (out) {  // no copy: the caller's buffer itself becomes the log (rg_adopt_entries)
 			*reinterpret_cast<ulonglong2 *>(&out[i].k0) = a;
 			*reinterpret_cast<ulonglong2 *>(&out[i].stamp) = b;
 		}
 	}
 	if (bad) atomicAdd(&counters[C_ADOPT_BAD], (unsigned long long)bad);
+	for (int d = 32; d > 0; d >>= 1) multi += __shfl_down(multi, d);
+	if ((threadIdx.x & 63) == 0 && multi) atomicAdd(&counters[C_LOG_MULTI], (unsigned long long)multi);
 }
 
 // size == 1 with a pending log and a caller that wants the table of all candidates before admission (the owner
@@ -2976,9 +2991,14 @@ static int collect_histogram(rg_handle *h, const unsigned long long *dense, cons
 // lost != nullptr: the log is as the sweep wrote it, lost[i] is entry i's mark and first_hist the admitted entries per top byte
 // of the slot hash (k_admit_lost<W, false>): the first partition level applies the admission rule to what it reads.
 // lost == nullptr: the log was admitted in place.
+// fused: the first level is the admission's only pass over the log (k_scatter_entries with AdmitStats) -- `retained` is then an
+// upper bound on the stored vertices (entries seen twice or more + false positives), the level writes into ranges sized in
+// advance from it and counts the vertices, after which the table gets its real capacity.  *presize_failed: a range was too
+// small; nothing was built, the statistics the pass gathered are void and the caller counts first, the classic way.
 static int build_table_ranges(rg_handle *h, const Slot *log, uint64_t n_log, uint64_t retained, bool *done, const uint8_t *lost = nullptr,
-                              const unsigned long long *first_hist = nullptr) {
+                              const unsigned long long *first_hist = nullptr, bool fused = false, bool *presize_failed = nullptr) {
 	*done = false;
+	if (presize_failed) *presize_failed = false;
 	const int dev = h->cfg.device;
 	Table &T = h->tab;
 	if (T.slots || retained == 0 || n_log == 0) return RG_OK;
@@ -3003,6 +3023,10 @@ static int build_table_ranges(rg_handle *h, const Slot *log, uint64_t n_log, uin
 		dbits[2] = rem - dbits[1];
 	}
 	const uint64_t NBUCK = 1ull << bits;
+	if (fused && nlev < 2) {  // one level: its output must be the ranges themselves, without gaps
+		if (presize_failed) *presize_failed = true;
+		return RG_OK;
+	}
 	Slot *tab = nullptr, *ovf = nullptr;
 	uint8_t *buf[2] = {nullptr, nullptr};  // admitted entries between the levels: Ent<W>, 16 bytes for one-word keys
 	const size_t esz = h->W == 1 ? sizeof(Ent<1>) : sizeof(Ent<2>);
@@ -3011,7 +3035,14 @@ static int build_table_ranges(rg_handle *h, const Slot *log, uint64_t n_log, uin
 	uint32_t *d_tile = nullptr;
 	uint8_t *d_side = nullptr;
 	const uint64_t ovf_cap = retained / 16 + 4096;
+	// fused: 256 ranges of the first level, an even share of the bound each plus eight standard deviations and a little
+	const uint64_t slot0 = fused ? ((retained / 256 + (uint64_t)(8.0 * std::sqrt((double)retained / 256.0)) + 4096 + 63) & ~63ull) : 0;
+	const uint64_t cap0 = fused ? 256 * slot0 : retained;  // entries the first level's output holds
+	unsigned long long *d_lim = nullptr, *d_segend = nullptr, *d_spread = nullptr;
 	auto cleanup = [&]() {
+		pool_free(dev, d_lim);
+		pool_free(dev, d_segend);
+		pool_free(dev, d_spread);
 		pool_free(dev, buf[0]);  // buf[1] is its second half
 		pool_free(dev, ovf);
 		pool_free(dev, d_seg);
@@ -3022,18 +3053,21 @@ static int build_table_ranges(rg_handle *h, const Slot *log, uint64_t n_log, uin
 		pool_free(dev, d_side);
 	};
 	const uint64_t SEGMAX = 65536;
-	hipError_t e = pool_alloc(dev, (void **)&tab, cap * sizeof(Slot));
+	// (fused: the table is allocated once the first level has counted the vertices)
+	hipError_t e = fused ? hipSuccess : pool_alloc(dev, (void **)&tab, cap * sizeof(Slot));
 	// the two entry buffers are one block: a few large blocks of the same sizes every time are what the pool can hand out
 	// again when the device is nearly full (C5's share per GPU), where many middling ones go back to the driver and return
-	if (e == hipSuccess) e = pool_alloc(dev, (void **)&buf[0], (nlev > 1 ? 2 : 1) * retained * esz);
-	if (e == hipSuccess && nlev > 1) buf[1] = buf[0] + retained * esz;
+	if (e == hipSuccess) e = pool_alloc(dev, (void **)&buf[0], (cap0 + (nlev > 1 ? retained : 0)) * esz);
+	if (e == hipSuccess && nlev > 1) buf[1] = buf[0] + cap0 * esz;
+	if (e == hipSuccess && fused) e = pool_alloc(dev, (void **)&d_lim, 256 * sizeof(unsigned long long));
+	if (e == hipSuccess && fused) e = pool_alloc(dev, (void **)&d_segend, 257 * sizeof(unsigned long long));
 	if (e == hipSuccess) e = pool_alloc(dev, (void **)&ovf, ovf_cap * sizeof(Slot));
 	if (e == hipSuccess) e = pool_alloc(dev, (void **)&d_seg, (SEGMAX + 1) * sizeof(unsigned long long));
 	if (e == hipSuccess) e = pool_alloc(dev, (void **)&d_tile, (SEGMAX + 1) * sizeof(uint32_t));
 	if (e == hipSuccess) e = pool_alloc(dev, (void **)&d_hist, NBUCK * sizeof(unsigned long long));
 	if (e == hipSuccess) e = pool_alloc(dev, (void **)&d_begin, (NBUCK + 1) * sizeof(unsigned long long));
 	if (e == hipSuccess) e = pool_alloc(dev, (void **)&d_sums, (NBUCK / SCAN_PER_BLOCK + 2) * sizeof(unsigned long long));
-	if (e == hipSuccess && nlev > 1) e = pool_alloc(dev, (void **)&d_side, retained);
+	if (e == hipSuccess && nlev > 1) e = pool_alloc(dev, (void **)&d_side, cap0);
 	if (e != hipSuccess) {  // not enough memory for the partition buffers: the classic insert needs none
 		(void)hipGetLastError();
 		cleanup();
@@ -3051,26 +3085,38 @@ static int build_table_ranges(rg_handle *h, const Slot *log, uint64_t n_log, uin
 	} while (0)
 	TTRY(hipMemsetAsync(h->d_counters + TC_OVF_CURSOR, 0, 2 * sizeof(unsigned long long), h->stream));
 	TTRY(hipMemsetAsync(h->d_counters + C_FILL, 0, sizeof(unsigned long long), h->stream));
-	std::vector<unsigned long long> seg_begin = {0, n_log};
+	std::vector<unsigned long long> seg_begin = {0, n_log}, seg_end;  // seg_end: where the ranges sized in advance were filled to (fused, second level)
 	std::vector<uint32_t> tile_first;
 	const void *level_in = log;
 	int used_bits = 0, cur = 0;
+	uint64_t stored = retained;  // fused: what the first level counted
+	AdmitStats no_stats = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0};
 	for (int level = 0; level < nlev; ++level) {
 		const uint32_t S = (uint32_t)seg_begin.size() - 1;
 		const int db = dbits[level];
 		const int shift = bits - used_bits - db;
+		const bool gaps = fused && level == 1;
 		tile_first.assign(S + 1, 0);
 		uint64_t ntiles = 0;
 		for (uint32_t sgi = 0; sgi < S; ++sgi) {
 			tile_first[sgi] = (uint32_t)ntiles;
-			ntiles += (seg_begin[sgi + 1] - seg_begin[sgi] + TILE - 1) / TILE;
+			ntiles += ((gaps ? seg_end[sgi] : seg_begin[sgi + 1]) - seg_begin[sgi] + TILE - 1) / TILE;
 		}
 		tile_first[S] = (uint32_t)ntiles;
 		TTRY(hipMemcpyAsync(d_seg, seg_begin.data(), (S + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
 		TTRY(hipMemcpyAsync(d_tile, tile_first.data(), (S + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+		if (gaps) TTRY(hipMemcpyAsync(d_segend, seg_end.data(), S * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
+		const unsigned long long *segend_arg = gaps ? d_segend : nullptr;
 		const uint64_t nout = (uint64_t)S << db;
 		TTRY(hipMemsetAsync(d_hist, 0, nout * sizeof(unsigned long long), h->stream));
-		if (level == 0 && first_hist) {
+		std::vector<unsigned long long> starts;  // fused first level: where its ranges start
+		if (level == 0 && fused) {
+			starts.resize(257);
+			for (int d = 0; d <= 256; ++d) starts[d] = (uint64_t)d * slot0;
+			TTRY(hipMemcpyAsync(d_hist, starts.data(), 256 * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));      // the cursors
+			TTRY(hipMemcpyAsync(d_lim, starts.data() + 1, 256 * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));  // the ends
+			TTRY(hipMemsetAsync(h->d_counters + C_ENT_PRESIZE, 0, sizeof(unsigned long long), h->stream));
+		} else if (level == 0 && first_hist) {
 			TTRY(hipMemcpyAsync(d_hist, first_hist, 256 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, h->stream));
 		} else if (level == 0) {
 			ProfScope ps(h, "k_entry_hist");
@@ -3079,15 +3125,23 @@ static int build_table_ranges(rg_handle *h, const Slot *log, uint64_t n_log, uin
 			else hipLaunchKernelGGL(k_entry_hist<2>, dim3(grid), dim3(256), 0, h->stream, log, n_log, bits, shift, (1u << db) - 1u, d_hist);
 		} else {
 			ProfScope ps(h, "k_level_hist_side");
-			if (h->W == 1) hipLaunchKernelGGL(k_level_hist_side<ent_tile<1>()>, dim3((unsigned)((ntiles + HIST_SIDE_TILES - 1) / HIST_SIDE_TILES)), dim3(256), 0, h->stream, d_side, S, d_seg, d_tile, db, d_hist, (uint32_t)ntiles);
-			else hipLaunchKernelGGL(k_level_hist_side<ent_tile<2>()>, dim3((unsigned)((ntiles + HIST_SIDE_TILES - 1) / HIST_SIDE_TILES)), dim3(256), 0, h->stream, d_side, S, d_seg, d_tile, db, d_hist, (uint32_t)ntiles);
+			if (h->W == 1) hipLaunchKernelGGL(k_level_hist_side<ent_tile<1>()>, dim3((unsigned)((ntiles + HIST_SIDE_TILES - 1) / HIST_SIDE_TILES)), dim3(256), 0, h->stream, d_side, S, d_seg, d_tile, db, d_hist, (uint32_t)ntiles, segend_arg);
+			else hipLaunchKernelGGL(k_level_hist_side<ent_tile<2>()>, dim3((unsigned)((ntiles + HIST_SIDE_TILES - 1) / HIST_SIDE_TILES)), dim3(256), 0, h->stream, d_side, S, d_seg, d_tile, db, d_hist, (uint32_t)ntiles, segend_arg);
 		}
 		TTRY(hipGetLastError());
-		const uint32_t nblk = (uint32_t)((nout + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK);
-		hipLaunchKernelGGL(k_scan_local, dim3(nblk), dim3(256), 0, h->stream, d_hist, d_begin, nout, d_sums);
-		hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(64), 0, h->stream, d_sums, nblk, d_sums + nblk);
-		hipLaunchKernelGGL(k_scan_add, dim3(nblk), dim3(256), 0, h->stream, d_begin, nout, d_sums, d_sums + nblk, d_hist);
-		TTRY(hipGetLastError());
+		if (!(level == 0 && fused)) {  // (the fused first level's cursors are its ranges' starts)
+			const uint32_t nblk = (uint32_t)((nout + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK);
+			hipLaunchKernelGGL(k_scan_local, dim3(nblk), dim3(256), 0, h->stream, d_hist, d_begin, nout, d_sums);
+			hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(64), 0, h->stream, d_sums, nblk, d_sums + nblk);
+			hipLaunchKernelGGL(k_scan_add, dim3(nblk), dim3(256), 0, h->stream, d_begin, nout, d_sums, d_sums + nblk, d_hist);
+			TTRY(hipGetLastError());
+		}
+		AdmitStats st = no_stats;
+		if (level == 0 && fused) {
+			TTRY(pool_alloc(dev, (void **)&d_spread, (size_t)ADMIT_SPREAD * 258 * sizeof(unsigned long long)));
+			TTRY(hipMemsetAsync(d_spread, 0, (size_t)ADMIT_SPREAD * 258 * sizeof(unsigned long long), h->stream));
+			st = AdmitStats{h->d_counters, h->d_hist_dense, h->d_hist_ovf, d_lim, d_spread, HIST_DENSE, HIST_OVF_CAP, (int)C_RETAINED, (int)C_INSERTIONS, (int)C_OVF, (int)C_ENT_PRESIZE};
+		}
 		{
 			ProfScope ps(h, "k_scatter_entries");
 			const bool have_next = level + 1 < nlev;
@@ -3095,25 +3149,55 @@ static int build_table_ranges(rg_handle *h, const Slot *log, uint64_t n_log, uin
 			uint8_t *side_out = have_next ? d_side : nullptr;
 			uint8_t *out = buf[cur];
 			if (h->W == 1) {
-				if (level == 0) hipLaunchKernelGGL((k_scatter_entries<1, true>), dim3((unsigned)ntiles), dim3(ENT_THREADS), 0, h->stream, (const Slot *)level_in, S, d_seg, d_tile, bits, shift, db, d_hist, (Ent<1> *)out, side_out, shift - ndb, (1u << ndb) - 1u, lost);
-				else hipLaunchKernelGGL((k_scatter_entries<1, false>), dim3((unsigned)ntiles), dim3(ENT_THREADS), 0, h->stream, (const Ent<1> *)level_in, S, d_seg, d_tile, bits, shift, db, d_hist, (Ent<1> *)out, side_out, shift - ndb, (1u << ndb) - 1u, (const uint8_t *)nullptr);
+				if (level == 0) hipLaunchKernelGGL((k_scatter_entries<1, true>), dim3((unsigned)ntiles), dim3(ENT_THREADS), 0, h->stream, (const Slot *)level_in, S, d_seg, d_tile, bits, shift, db, d_hist, (Ent<1> *)out, side_out, shift - ndb, (1u << ndb) - 1u, lost, st);
+				else hipLaunchKernelGGL((k_scatter_entries<1, false>), dim3((unsigned)ntiles), dim3(ENT_THREADS), 0, h->stream, (const Ent<1> *)level_in, S, d_seg, d_tile, bits, shift, db, d_hist, (Ent<1> *)out, side_out, shift - ndb, (1u << ndb) - 1u, (const uint8_t *)nullptr, no_stats, segend_arg);
 			} else {
-				if (level == 0) hipLaunchKernelGGL((k_scatter_entries<2, true>), dim3((unsigned)ntiles), dim3(ENT_THREADS), 0, h->stream, (const Slot *)level_in, S, d_seg, d_tile, bits, shift, db, d_hist, (Ent<2> *)out, side_out, shift - ndb, (1u << ndb) - 1u, lost);
-				else hipLaunchKernelGGL((k_scatter_entries<2, false>), dim3((unsigned)ntiles), dim3(ENT_THREADS), 0, h->stream, (const Ent<2> *)level_in, S, d_seg, d_tile, bits, shift, db, d_hist, (Ent<2> *)out, side_out, shift - ndb, (1u << ndb) - 1u, (const uint8_t *)nullptr);
+				if (level == 0) hipLaunchKernelGGL((k_scatter_entries<2, true>), dim3((unsigned)ntiles), dim3(ENT_THREADS), 0, h->stream, (const Slot *)level_in, S, d_seg, d_tile, bits, shift, db, d_hist, (Ent<2> *)out, side_out, shift - ndb, (1u << ndb) - 1u, lost, st);
+				else hipLaunchKernelGGL((k_scatter_entries<2, false>), dim3((unsigned)ntiles), dim3(ENT_THREADS), 0, h->stream, (const Ent<2> *)level_in, S, d_seg, d_tile, bits, shift, db, d_hist, (Ent<2> *)out, side_out, shift - ndb, (1u << ndb) - 1u, (const uint8_t *)nullptr, no_stats, segend_arg);
 			}
 		}
 		TTRY(hipGetLastError());
+		if (level == 0 && fused) hipLaunchKernelGGL(k_fold_admit_stats, dim3(1), dim3(320), 0, h->stream, st);
 		used_bits += db;
 		level_in = buf[cur];
 		cur ^= 1;
-		if (level + 1 < nlev) {
+		if (level == 0 && fused) {  // what the pass counted: the vertices stored, and how far each range was filled
+			seg_end.resize(257);
+			TTRY(hipMemcpyAsync(seg_end.data(), d_hist, 256 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+			const int rcs = sync_counters(h);
+			if (rcs) {
+				cleanup();
+				return rcs;
+			}
+			if (h->h_counters[C_ENT_PRESIZE]) {  // a range sized in advance was too small: the caller counts first
+				cleanup();
+				if (presize_failed) *presize_failed = true;
+				return RG_OK;
+			}
+			stored = h->h_counters[C_RETAINED];
+			seg_begin = starts;
+			uint64_t held = 0;
+			for (int d = 0; d < 256; ++d) held += seg_end[d] - seg_begin[d];
+			if (held != stored || stored > retained) {
+				cleanup();
+				return fail(h, RG_ERR_STATE, "the admission pass stored %llu vertices, its ranges hold %llu (bound %llu)", (unsigned long long)stored, (unsigned long long)held, (unsigned long long)retained);
+			}
+			if (stored == 0) {  // nothing admitted: an empty table, made by the caller
+				cleanup();
+				return RG_OK;
+			}
+			cap = (uint64_t)((double)stored / 0.7) + 1;
+			if (cap < 4096) cap = 4096;
+			if (h->cfg.table_slots > cap) cap = h->cfg.table_slots;
+			TTRY(pool_alloc(dev, (void **)&tab, cap * sizeof(Slot)));
+		} else if (level + 1 < nlev) {
 			seg_begin.resize(nout + 1);
 			TTRY(hipMemcpyAsync(seg_begin.data(), d_begin, (nout + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
 			TTRY(rg_stream_sync(h));
-			if (seg_begin[nout] != retained) {
+			if (seg_begin[nout] != stored) {
 				cleanup();
 				pool_free(dev, tab);
-				return fail(h, RG_ERR_STATE, "table partition level %d holds %llu of %llu admitted entries", level, seg_begin[nout], (unsigned long long)retained);
+				return fail(h, RG_ERR_STATE, "table partition level %d holds %llu of %llu admitted entries", level, seg_begin[nout], (unsigned long long)stored);
 			}
 		}
 	}
@@ -3391,6 +3475,7 @@ int rg_count_local(rg_handle *h) {
 					h->pending_keys = h->log_keys;
 					rc = sync_counters(h);
 					if (rc) return rc;
+					h->pending_multi = h->h_counters[C_LOG_MULTI];
 				} else if (single) {
 					rc = table_reserve(h, T, n_log ? n_log : 1, fill_counter);
 					if (rc == RG_OK && n_log) {
@@ -3604,7 +3689,7 @@ int rg_merge_entries(rg_handle *h, const void *d_entries, uint64_t n_entries) {
 		HIP_TRY(h, hipMemcpyAsync(&first, d_entries, sizeof(Slot), hipMemcpyDeviceToHost, h->stream));
 		HIP_TRY(h, rg_stream_sync(h));
 		if ((first.meta & LOG_UNIQUE) && pool_alloc(h->cfg.device, (void **)&copy, n_entries * sizeof(Slot)) == hipSuccess) {
-			hipError_t e = hipMemsetAsync(h->d_counters + C_ADOPT_BAD, 0, sizeof(unsigned long long), h->stream);
+			hipError_t e = hipMemsetAsync(h->d_counters + C_ADOPT_BAD, 0, 2 * sizeof(unsigned long long), h->stream);  // (and C_LOG_MULTI behind it)
 			if (e == hipSuccess) {
 				ProfScope ps(h, "k_adopt_entries");
 				hipLaunchKernelGGL(k_adopt_entries, dim3(grid_for(n_entries)), dim3(BLOCK), 0, h->stream, (const Slot *)d_entries, n_entries, copy, h->d_counters);
@@ -3618,6 +3703,7 @@ int rg_merge_entries(rg_handle *h, const void *d_entries, uint64_t n_entries) {
 			if (h->h_counters[C_ADOPT_BAD] == 0) {
 				h->pending_log = copy;
 				h->pending_n = h->pending_keys = n_entries;
+				h->pending_multi = h->h_counters[C_LOG_MULTI];
 				if (getenv("RG_DEBUG")) fprintf(stderr, "[raygraph] rank %d: %llu received entries kept as a log of distinct k-mers\n", h->cfg.rank, (unsigned long long)n_entries);
 				return RG_OK;  // synchronised: the caller may reuse d_entries
 			}
@@ -3670,7 +3756,7 @@ int rg_adopt_entries(rg_handle *h, void *d_entries, uint64_t n_entries) {
 		in_place = (first.meta & LOG_UNIQUE) != 0;
 	}
 	if (in_place) {
-		hipError_t e = hipMemsetAsync(h->d_counters + C_ADOPT_BAD, 0, sizeof(unsigned long long), h->stream);
+		hipError_t e = hipMemsetAsync(h->d_counters + C_ADOPT_BAD, 0, 2 * sizeof(unsigned long long), h->stream);  // (and C_LOG_MULTI behind it)
 		if (e == hipSuccess) {
 			ProfScope ps(h, "k_adopt_entries");
 			hipLaunchKernelGGL(k_adopt_entries, dim3(grid_for(n_entries)), dim3(BLOCK), 0, h->stream, (const Slot *)d_entries, n_entries, (Slot *)nullptr, h->d_counters);
@@ -3690,6 +3776,7 @@ int rg_adopt_entries(rg_handle *h, void *d_entries, uint64_t n_entries) {
 	h->pending_log = (Slot *)d_entries;  // pool_free ignores pointers the pool did not hand out: the buffer stays the caller's
 	h->pending_borrowed = true;
 	h->pending_n = h->pending_keys = n_entries;
+	h->pending_multi = h->h_counters[C_LOG_MULTI];
 	if (getenv("RG_DEBUG")) fprintf(stderr, "[raygraph] rank %d: %llu received entries admitted in the caller's buffer\n", h->cfg.rank, (unsigned long long)n_entries);
 	return RG_OK;
 }
@@ -3807,7 +3894,35 @@ int rg_resolve_admission(rg_handle *h, uint64_t local_reads_for_bloom) {
 		else hipLaunchKernelGGL((k_admit<2, false>), dim3(grid), dim3(BLOCK), 0, h->stream, T.slots, T.cap, 0ull, (const unsigned long long *)nullptr, h->d_counters, h->d_hist_dense, h->d_hist_ovf);
 		HIP_TRY(h, hipGetLastError());
 	}
-	if (lost_kept) {  // the counting pass of the admission: statistics, histogram, first level of the table partition; the log stays as it is
+	// One pass instead of two (round 3): the first level of the table partition applies the admission rule, gathers the
+	// statistics and the histogram and writes into ranges sized in advance -- possible when the stored vertices can be bounded
+	// before it: entries seen twice or more (counted by whoever made the log) + false positives (counted by k_xor_fp).
+	bool fused_built = false, fused_tried = false;
+	if (lost_kept && from_log && h->pending_multi != ~0ull && !(h->dbg & 0x800000)) {
+		const uint64_t bound = std::min<uint64_t>(h->pending_keys, h->pending_multi + h->h_counters[C_FP_COUNT]);
+		if (bound >= (1ull << 20) || (h->dbg & 0x400000)) {
+			bool presize_failed = false;
+			fused_tried = true;
+			int rcb = build_table_ranges(h, h->pending_log, h->pending_n, std::max<uint64_t>(bound, 1), &fused_built, lost_kept, nullptr, true, &presize_failed);
+			if (rcb) {
+				pool_free(h->cfg.device, lost_kept);
+				return rcb;
+			}
+			(void)presize_failed;
+			if (!fused_built) {
+				// nothing was built (a range too small, a table of one level, nothing admitted, no memory): what the pass may have gathered is void, count first
+				hipError_t ez = hipMemsetAsync(h->d_hist_dense, 0, HIST_DENSE * sizeof(unsigned long long), h->stream);
+				if (ez == hipSuccess) ez = hipMemsetAsync(h->d_counters + C_RETAINED, 0, 2 * sizeof(unsigned long long), h->stream);  // (and C_INSERTIONS)
+				if (ez == hipSuccess) ez = hipMemsetAsync(h->d_counters + C_OVF, 0, sizeof(unsigned long long), h->stream);
+				if (ez != hipSuccess) {
+					pool_free(h->cfg.device, lost_kept);
+					return fail(h, RG_ERR_HIP, "admission: %s", hipGetErrorString(ez));
+				}
+				fused_tried = false;
+			}
+		}
+	}
+	if (lost_kept && !fused_tried) {  // the counting pass of the admission: statistics, histogram, first level of the table partition; the log stays as it is
 		hipError_t e = pool_alloc(h->cfg.device, (void **)&d_first_hist, 256 * sizeof(unsigned long long));
 		if (e == hipSuccess) e = hipMemsetAsync(d_first_hist, 0, 256 * sizeof(unsigned long long), h->stream);
 		if (e == hipSuccess) {
@@ -3833,8 +3948,8 @@ int rg_resolve_admission(rg_handle *h, uint64_t local_reads_for_bloom) {
 		candidates = h->pending_keys;
 		const uint64_t retained = h->h_counters[C_RETAINED];
 		// the table range by range, without global atomics (rg_debug_set bit 22 forces it on small inputs, bit 23 never: tests)
-		bool built = false;
-		if (!(h->dbg & 0x800000) && (retained >= (1ull << 20) || (h->dbg & 0x400000)))
+		bool built = fused_built;
+		if (!built && !fused_tried && !(h->dbg & 0x800000) && (retained >= (1ull << 20) || (h->dbg & 0x400000)))
 			rc = build_table_ranges(h, h->pending_log, h->pending_n, retained, &built, lost_kept, d_first_hist);
 		if (rc == RG_OK && !built && lost_kept) {  // the classic insert wants the log admitted in place: write what the counting pass left out
 			ProfScope ps(h, "k_admit");
@@ -3859,6 +3974,7 @@ int rg_resolve_admission(rg_handle *h, uint64_t local_reads_for_bloom) {
 		if (rc == RG_OK) rc = sync_counters(h);
 		pool_free(h->cfg.device, h->pending_log);  // (a borrowed buffer is not the pool's: nothing happens)
 		h->pending_log = nullptr;
+		h->pending_multi = ~0ull;
 		h->pending_borrowed = false;
 		h->pending_n = 0;
 		if (rc) return rc;

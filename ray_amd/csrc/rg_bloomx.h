@@ -479,9 +479,10 @@ __global__ __launch_bounds__(THREADS) void k_xor_region_sparse(const unsigned lo
 // false positive or a pad -- loads their packed words (32 bytes) to tell the two apart, and then the log position.
 __global__ __launch_bounds__(256) void k_xor_fp(const unsigned long long *__restrict__ pk, const uint32_t *__restrict__ ix,
                                                 const unsigned long long *__restrict__ planes, uint64_t plane_words, uint64_t npos,
-                                                uint8_t *__restrict__ lost) {
+                                                uint8_t *__restrict__ lost, unsigned long long *__restrict__ fp_count = nullptr) {
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+	uint32_t marked = 0;  // false positives this lane found (their number bounds what admission stores: sizes the table build)
 	for (uint64_t w0 = ((uint64_t)blockIdx.x * 4 + wave) * 4; w0 < plane_words; w0 += nwaves * 4) {  // (wave-uniform) four plane words = 256 positions
 		unsigned long long mine = 0;
 		{
@@ -516,7 +517,14 @@ __global__ __launch_bounds__(256) void k_xor_fp(const unsigned long long *__rest
 		}
 #pragma unroll
 		for (int q = 0; q < 4; ++q)
-			if (!((won >> q) & 1u) && key[q] != XOR_PAD) lost[ix[j + q]] = 8;
+			if (!((won >> q) & 1u) && key[q] != XOR_PAD) {
+				lost[ix[j + q]] = 8;
+				marked++;
+			}
+	}
+	if (fp_count) {
+		for (int d = 32; d > 0; d >>= 1) marked += __shfl_down(marked, d);
+		if (lane == 0 && marked) atomicAdd(fp_count, (unsigned long long)marked);
 	}
 }
 

@@ -189,7 +189,8 @@ __device__ __forceinline__ uint32_t rec_bucket(const Rec20 &c, int m) {  // W ==
 	return bucket_number(canon_mmer(f, m));
 }
 
-enum PartCounter { PC_REC_CURSOR = 16, PC_REC_OVF, PC_LOG_CURSOR, PC_LOG_OVF, PC_LDS_SPILL, PC_AGG_RETRY, PC_NONUNIQUE, PC_LOG_KEYS, PC_SAMPLE, PC_SAMPLE_DISTINCT, PC_SAMPLE_FAIL, PC_ITEM_OVF, PC_CUT_ANCHORED = 30, PC_CUT_EXPANDED = 31 };
+enum PartCounter { PC_REC_CURSOR = 16, PC_REC_OVF, PC_LOG_CURSOR, PC_LOG_OVF, PC_LDS_SPILL, PC_AGG_RETRY, PC_NONUNIQUE, PC_LOG_KEYS, PC_SAMPLE, PC_SAMPLE_DISTINCT, PC_SAMPLE_FAIL, PC_CUT_ANCHORED = 30, PC_CUT_EXPANDED = 31,
+                   PC_LOG_MULTI = 10 /* = C_LOG_MULTI */, PC_ITEM_OVF = 13 };
 
 // The sample of the records that sizes the partition: the records whose bucket number has its top SAMPLE_BITS bits clear,
 // i.e. the first 2^(b - SAMPLE_BITS) buckets of a partition into 2^b, whole (the bucket number is a hash: 1 / 4096 of the
@@ -1541,6 +1542,7 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<
 	};
 	uint32_t chunk_used = 0;
 	unsigned long long keys_written = 0;
+	uint32_t multi_written = 0;  // entries written with a count of two or more (what admission stores whatever the filter says)
 	uint32_t nonunique_flushes = 0;
 	uint32_t cut_anchored = 0, cut_expanded = 0;  // statistics (lane 0): records cut by a read end that lay inside an anchor / were expanded
 	bool log_full = false;         // wave-uniform
@@ -1581,6 +1583,7 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<
 				e.stamp = T.stamp[sl];
 				e.meta = (uint64_t)T.cnt[sl] | ((uint64_t)(T.edges[sl] & 0xFFu) << PEND_SHIFT) | mark;
 				log[dst] = e;
+				multi_written += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64((uint32_t)e.meta >= 2u));  // (the count is the low 32 bits here)
 				if (ai.items) {
 					const uint64_t o = xor_origin<W>(e.k0, e.k1, ai.m_mask);
 					const uint32_t d = (uint32_t)(o >> ai.shift1);
@@ -2049,6 +2052,7 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<
 	}
 	if (lane == 0) {
 		if (keys_written) atomicAdd(&counters[PC_LOG_KEYS], keys_written);
+		if (multi_written) atomicAdd(&counters[PC_LOG_MULTI], (unsigned long long)multi_written);
 		if (nonunique_flushes) atomicAdd(&counters[PC_NONUNIQUE], (unsigned long long)nonunique_flushes);
 		if (cut_anchored) atomicAdd(&counters[PC_CUT_ANCHORED], (unsigned long long)cut_anchored);
 		if (cut_expanded) atomicAdd(&counters[PC_CUT_EXPANDED], (unsigned long long)cut_expanded);

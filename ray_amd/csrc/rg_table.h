@@ -108,6 +108,25 @@ __global__ __launch_bounds__(256) void k_entry_hist(const Slot *__restrict__ in,
 	if (s_cnt[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
 }
 
+// The first level can be the admission's only pass over the log (round 3): with `st.counters` set it gathers what the counting
+// pass gathered -- vertices stored, Bloom insertions, the coverage histogram (256 bins in LDS, the rest straight to the dense
+// bins and the overflow list) -- and writes into ranges sized in advance (st.limits[d] = end of the range of digit d: the top
+// byte of a slot hash takes an even share of the admitted entries, whose number is bounded before the pass by the entries seen
+// twice or more plus the false positives); an entry that finds its range full is counted in counters[st.c_presize] and the
+// host goes back to counting first.
+static constexpr uint32_t ADMIT_SPREAD = 256;
+struct AdmitStats {
+	unsigned long long *counters;    // nullptr: no statistics, exact ranges (the classic first level)
+	unsigned long long *hist_dense;  // [hist_dense_n]
+	uint32_t *hist_ovf;              // [hist_ovf_cap], filled through counters[c_ovf]
+	const unsigned long long *limits;
+	unsigned long long *spread;      // [ADMIT_SPREAD][258]: the 256 low histogram bins, vertices stored and Bloom insertions of a tile go to copy
+	                                 // blockIdx.x % ADMIT_SPREAD (a tile per workgroup: hundreds of thousands of workgroups adding to the same few
+	                                 // addresses took 67 ms on C2 with 1 % errors where the counting pass, 2048 workgroups, took 7.6); k_fold_admit_stats sums them
+	uint32_t hist_dense_n, hist_ovf_cap;
+	int c_retained, c_insertions, c_ovf, c_presize;
+};
+
 // One partition level of 32-byte entries (see k_scatter for the scheme).  FIRST: the input is the log of the sweep --
 // unused chunk entries and entries that are not admitted are dropped here; lost != nullptr: the log is as the sweep wrote
 // it and the admission rule is applied on the way (lost[i] = the mark of entry i), lost == nullptr: admitted in place.
@@ -117,10 +136,13 @@ __global__ __launch_bounds__(ENT_THREADS) void k_scatter_entries(const std::cond
                                                                  const uint32_t *__restrict__ tile_first, int bits, int shift, int dbits,
                                                                  unsigned long long *__restrict__ cursors, Ent<W> *__restrict__ out,
                                                                  uint8_t *__restrict__ side, int next_shift, uint32_t next_mask,
-                                                                 const uint8_t *__restrict__ lost) {
+                                                                 const uint8_t *__restrict__ lost, AdmitStats st,
+                                                                 const unsigned long long *__restrict__ seg_end = nullptr) {
+	// seg_end: the input segments are ranges sized in advance and filled in part (the level behind a first level with st.limits)
 	using E = Ent<W>;
 	constexpr int TILE = ent_tile<W>();
 	constexpr int PER = TILE / ENT_THREADS;
+	__shared__ uint32_t s_h[FIRST ? 256 : 1];
 	__shared__ E s_ent[TILE];
 	__shared__ uint8_t s_dig[TILE], s_next[TILE];
 	__shared__ uint32_t s_cnt[256], s_off[256], s_scan[8];
@@ -133,9 +155,13 @@ __global__ __launch_bounds__(ENT_THREADS) void k_scatter_entries(const std::cond
 	}
 	const uint32_t seg = lo;
 	const uint64_t begin = seg_begin[seg] + (uint64_t)(blockIdx.x - tile_first[seg]) * TILE;
-	const uint64_t end = begin + TILE < seg_begin[seg + 1] ? begin + TILE : seg_begin[seg + 1];
+	const uint64_t send = seg_end ? seg_end[seg] : seg_begin[seg + 1];
+	const uint64_t end = begin + TILE < send ? begin + TILE : send;
 	const uint32_t dmask = (1u << dbits) - 1;
 	if (threadIdx.x < 256) s_cnt[threadIdx.x] = 0;
+	const bool stats = FIRST && st.counters != nullptr;
+	if (FIRST && threadIdx.x < 256) s_h[threadIdx.x] = 0;
+	uint32_t retained = 0, inserted = 0;
 	__syncthreads();
 	E mine[PER];
 	uint32_t dig[PER], rank[PER], nxt[PER];
@@ -148,7 +174,29 @@ __global__ __launch_bounds__(ENT_THREADS) void k_scatter_entries(const std::cond
 		if (i < end) {
 			Slot v = ent_load(&in[i]);
 			bool keep = true;
-			if (FIRST) keep = lost ? admit_entry(v, lost, i) : entry_admitted(v);
+			if (FIRST && stats) {  // the admission rule with its statistics (k_admit_lost: MessageProcessor.cpp:741-804)
+				keep = false;
+				if (v.k0 != EMPTY) {
+					const uint64_t N = v.meta & COUNT_MASK & ~LOG_UNIQUE;
+					const bool fp = lost[i] == 8;
+					uint64_t cov = fp ? N + 1 : (N >= 2 ? N : 0);
+					if (cov > 0xFFFFFFFFull) cov = 0xFFFFFFFFull;
+					if (!fp) inserted++;
+					if (cov) {
+						retained++;
+						if (cov < 256) atomicAdd(&s_h[(uint32_t)cov], 1u);
+						else if (cov < st.hist_dense_n) atomicAdd(&st.hist_dense[cov], 1ull);
+						else {
+							const unsigned long long pos = atomicAdd(&st.counters[st.c_ovf], 1ull);
+							if (pos < st.hist_ovf_cap) st.hist_ovf[pos] = (uint32_t)cov;
+						}
+						v.meta = admitted_meta(v.meta, cov);
+						keep = true;
+					}
+				}
+			} else if (FIRST) {
+				keep = lost ? admit_entry(v, lost, i) : entry_admitted(v);
+			}
 			if (keep) {
 				const uint32_t r = entry_range<W>(v, bits);
 				dig[j] = (r >> shift) & dmask;
@@ -200,10 +248,36 @@ __global__ __launch_bounds__(ENT_THREADS) void k_scatter_entries(const std::cond
 		const uint32_t i = i2 / PARTS, part = i2 % PARTS;
 		const uint32_t d = s_dig[i];
 		const unsigned long long dst = s_gbase[d] + (i - s_off[d]);
+		if (FIRST && stats && st.limits && dst >= st.limits[d]) {
+			if (part == 0) atomicAdd(&st.counters[st.c_presize], 1ull);
+			continue;
+		}
 		const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(reinterpret_cast<const uint64_t *>(&s_ent[i]) + 2 * part);
 		*reinterpret_cast<ulonglong2 *>(reinterpret_cast<uint64_t *>(&out[dst]) + 2 * part) = v;
 		if (side && part == 0) side[dst] = s_next[i];
 	}
+	if (FIRST && stats) {
+		for (int d = 32; d > 0; d >>= 1) {
+			retained += __shfl_down(retained, d);
+			inserted += __shfl_down(inserted, d);
+		}
+		unsigned long long *copy = st.spread + (size_t)(blockIdx.x % ADMIT_SPREAD) * 258;
+		if ((threadIdx.x & 63) == 0) {
+			if (retained) atomicAdd(&copy[256], (unsigned long long)retained);
+			if (inserted) atomicAdd(&copy[257], (unsigned long long)inserted);
+		}
+		if (threadIdx.x < 256 && s_h[threadIdx.x]) atomicAdd(&copy[threadIdx.x], (unsigned long long)s_h[threadIdx.x]);
+	}
+}
+
+// the copies of AdmitStats::spread summed into the histogram's dense bins and the two counters
+__global__ __launch_bounds__(320) void k_fold_admit_stats(AdmitStats st) {
+	if (threadIdx.x >= 258) return;
+	unsigned long long sum = 0;
+	for (uint32_t c = 0; c < ADMIT_SPREAD; ++c) sum += st.spread[(size_t)c * 258 + threadIdx.x];
+	if (!sum) return;
+	if (threadIdx.x < 256) atomicAdd(&st.hist_dense[threadIdx.x], sum);
+	else atomicAdd(&st.counters[threadIdx.x == 256 ? st.c_retained : st.c_insertions], sum);
 }
 
 // One workgroup per table range (at most SPAN_MAX slots): fill it in LDS, write it out whole.  range_begin[r] ..
