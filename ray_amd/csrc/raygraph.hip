@@ -3626,8 +3626,11 @@ int rg_owner_counts(rg_handle *h, uint64_t *counts) {
 	const uint32_t size = (uint32_t)h->cfg.size;
 	Table &T = h->local.slots ? h->local : h->tab;  // size == 1 after rg_count_local: the table itself
 	HIP_TRY(h, hipMemsetAsync(h->d_owner, 0, sizeof(unsigned long long) * 2 * size, h->stream));
-	if (h->W == 1) hipLaunchKernelGGL(k_owner_counts<1>, dim3(grid_for(T.cap)), dim3(BLOCK), size * sizeof(uint32_t), h->stream, T.slots, T.cap, size, h->d_owner);
-	else hipLaunchKernelGGL(k_owner_counts<2>, dim3(grid_for(T.cap)), dim3(BLOCK), size * sizeof(uint32_t), h->stream, T.slots, T.cap, size, h->d_owner);
+	{
+		ProfScope ps(h, "k_owner_counts");
+		if (h->W == 1) hipLaunchKernelGGL(k_owner_counts<1>, dim3(grid_for(T.cap)), dim3(BLOCK), size * sizeof(uint32_t), h->stream, T.slots, T.cap, size, h->d_owner);
+		else hipLaunchKernelGGL(k_owner_counts<2>, dim3(grid_for(T.cap)), dim3(BLOCK), size * sizeof(uint32_t), h->stream, T.slots, T.cap, size, h->d_owner);
+	}
 	HIP_TRY(h, hipGetLastError());
 	std::vector<unsigned long long> tmp(size);
 	HIP_TRY(h, hipMemcpyAsync(tmp.data(), h->d_owner, sizeof(unsigned long long) * size, hipMemcpyDeviceToHost, h->stream));
@@ -3655,8 +3658,11 @@ int rg_export_owner_buckets(rg_handle *h, void *d_out, uint64_t capacity_entries
 	if (total == 0) return RG_OK;
 	if (!d_out) return fail(h, RG_ERR_ARG, "null bucket buffer");
 	HIP_TRY(h, hipMemcpyAsync(h->d_owner + size, cursors.data(), sizeof(unsigned long long) * size, hipMemcpyHostToDevice, h->stream));
-	if (h->W == 1) hipLaunchKernelGGL(k_owner_scatter<1>, dim3(grid_for(T.cap)), dim3(BLOCK), size * 12, h->stream, T.slots, T.cap, size, h->d_owner + size, (Slot *)d_out);
-	else hipLaunchKernelGGL(k_owner_scatter<2>, dim3(grid_for(T.cap)), dim3(BLOCK), size * 12, h->stream, T.slots, T.cap, size, h->d_owner + size, (Slot *)d_out);
+	{
+		ProfScope ps(h, "k_owner_scatter");
+		if (h->W == 1) hipLaunchKernelGGL(k_owner_scatter<1>, dim3(grid_for(T.cap)), dim3(BLOCK), size * 12, h->stream, T.slots, T.cap, size, h->d_owner + size, (Slot *)d_out);
+		else hipLaunchKernelGGL(k_owner_scatter<2>, dim3(grid_for(T.cap)), dim3(BLOCK), size * 12, h->stream, T.slots, T.cap, size, h->d_owner + size, (Slot *)d_out);
+	}
 	HIP_TRY(h, hipGetLastError());
 	HIP_TRY(h, rg_stream_sync(h));
 	return RG_OK;
