@@ -11,7 +11,7 @@
 
 // SHARED: the four wavefronts of a workgroup share their runs (a quarter of the open runs, four times as long); SIDE: one byte
 // per record goes to a parallel array as well (the next level's digit)
-template <int NS, bool SHARED, bool SIDE>
+template <int NS, bool SHARED, bool SIDE, bool SORTED = false>
 __global__ __launch_bounds__(256) void k_streams(uint32_t *__restrict__ out, uint8_t *__restrict__ side, uint32_t per_wave, uint32_t run_cap, int spin, uint32_t *sink) {
 	__shared__ uint32_t cur[4][NS];
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -24,7 +24,8 @@ __global__ __launch_bounds__(256) void k_streams(uint32_t *__restrict__ out, uin
 	uint32_t x = ((uint32_t)blockIdx.x * 4 + wave) * 2654435761u + lane;
 	for (uint32_t t = 0; t < per_wave; t += 64) {
 		for (int s = 0; s < spin; ++s) x = x * 1664525u + 1013904223u;
-		const uint32_t d = (x >> 13) % NS;
+		// SORTED: the lanes of a trip hold their digits in order (neighbouring lanes write neighbouring records of a run)
+		const uint32_t d = SORTED ? ((lane * NS) / 64 + t / 64) % NS : (x >> 13) % NS;
 		const uint32_t pos = atomicAdd(&cursors[d], 1u);
 		if (pos < cap) {
 			const uint64_t at = base + (uint64_t)d * cap + pos;
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(256) void k_streams(uint32_t *__restrict__ out, uin
 	if (x == 0x12345678u) *sink = x;
 }
 
-template <int NS, bool SHARED = false, bool SIDE = false>
+template <int NS, bool SHARED = false, bool SIDE = false, bool SORTED = false>
 static void run(uint32_t *out, uint8_t *side, uint64_t cap_words, uint32_t per_wave, int spin, uint32_t *sink) {
 	const int grid = 1024;  // 4 workgroups per CU, as the record kernel
 	const uint32_t run_cap = (uint32_t)(per_wave / NS + per_wave / NS / 4 + 64);
@@ -46,10 +47,10 @@ static void run(uint32_t *out, uint8_t *side, uint64_t cap_words, uint32_t per_w
 	CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
 	for (int rep = 0; rep < 3; ++rep) {
 		CHECK(hipEventRecord(a));
-		hipLaunchKernelGGL((k_streams<NS, SHARED, SIDE>), dim3(grid), dim3(256), 0, 0, out, side, per_wave, run_cap, spin, sink);
+		hipLaunchKernelGGL((k_streams<NS, SHARED, SIDE, SORTED>), dim3(grid), dim3(256), 0, 0, out, side, per_wave, run_cap, spin, sink);
 		CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
 		float ms = 0; CHECK(hipEventElapsedTime(&ms, a, b));
-		if (rep == 2) printf("NS %3d%s%s: %7.3f ms, %7.1f GB/s of records\n", NS, SHARED ? " shared by the workgroup" : "", SIDE ? " + side byte" : "", ms, (double)grid * 4 * per_wave * 20 / ms / 1e6);
+		if (rep == 2) printf("NS %3d%s%s%s: %7.3f ms, %7.1f GB/s of records\n", NS, SHARED ? " shared by the workgroup" : "", SIDE ? " + side byte" : "", SORTED ? ", digits in lane order" : "", ms, (double)grid * 4 * per_wave * 20 / ms / 1e6);
 	}
 }
 
@@ -67,5 +68,6 @@ int main(int argc, char **argv) {
 	run<32, true, false>(out, side, cap_words, per_wave, spin, sink); run<32, true, true>(out, side, cap_words, per_wave, spin, sink);
 	run<64, true, true>(out, side, cap_words, per_wave, spin, sink); run<128, true, true>(out, side, cap_words, per_wave, spin, sink);
 	run<1, true, true>(out, side, cap_words, per_wave, spin, sink);
+	run<32, true, true, true>(out, side, cap_words, per_wave, spin, sink); run<64, true, true, true>(out, side, cap_words, per_wave, spin, sink);
 	return 0;
 }
