@@ -417,6 +417,7 @@ def main():
         rec_bytes = 20 if k <= 31 else 8 * (2 * W + 1)  # rg_record_counts reports the same
         ent_bytes = 16 if W == 1 else 32                # an admitted entry between the log and the table (rg_table.h)
         scatter_levels = st["partition_levels"] - (1 if st.get("folded_level_bits") else 0)   # levels that are a k_scatter pass of their own
+        log_bytes = 16 if st.get("compact_log") == 1 else 32   # an entry of the sweep's log (16: key + meta, the admission's item carries the stamp)
         alg_bytes = {
             "k_count": occ0 * (L / (4.0 * n_per_read) + Kb + 8),            # read bits + key compare + count RMW
             "k_superkmers": occ0 * L / (4.0 * n_per_read) + recs0 * rec_bytes,  # read bits in, records out
@@ -424,7 +425,7 @@ def main():
             "k_scatter": scatter_levels * 2 * recs0 * rec_bytes + max(0, scatter_levels - 1) * recs0,  # records in + out per level, + the next level's digit byte
             "k_level_hist": max(0, st["partition_levels"] - 1) * recs0 * rec_bytes,
             "k_level_hist_side": max(0, st["partition_levels"] - 1) * recs0,     # one digit byte per record and level
-            "k_aggregate": recs0 * rec_bytes + st["log_entries"] * (32 + (17 if st.get("items_from_sweep") else 0)),  # records in, entries out (+ the admission's 16-byte item and digit byte per entry when it makes them)
+            "k_aggregate": recs0 * rec_bytes + st["log_entries"] * (log_bytes + (17 if st.get("items_from_sweep") else 0)),  # records in, entries out (+ the admission's 16-byte item and digit byte per entry when it makes them)
             "k_merge": st["log_entries"] * 32 + cand0 * 32,                  # entries in, slots written
             "k_bloom_items": (st["log_entries"] if "k_insert_admitted" in kprof else st["table_slots"]) * 32 + cand0 * 64,  # scan in, 8 items of 8 B per key out
             "k_bloom_hist": (st["log_entries"] if "k_insert_admitted" in kprof else st["table_slots"]) * 32,   # key scan, nothing written
@@ -438,7 +439,7 @@ def main():
             "k_histogram": st["table_slots"] * 32,
             "k_entry_hist": st["log_entries"] * 32,                                                  # log scan
             "k_admit_count": st["log_entries"] * 33,                                                 # log scan + one mark byte per entry, nothing written
-            "k_scatter_entries": st["log_entries"] * 33 + st["stored_pairs"] * ent_bytes,                   # first level: log in, admitted entries out (further levels added below)
+            "k_scatter_entries": st["log_entries"] * (log_bytes + 1) + st["stored_pairs"] * ent_bytes,                   # first level: log in, admitted entries out (further levels added below)
             "k_build_ranges": st["stored_pairs"] * ent_bytes + st["table_slots"] * 32,                      # entries in, every slot of the table written once
             "k_xor_hist": (st["log_entries"] if "k_build_ranges" in kprof or "k_insert_admitted" in kprof else st["table_slots"]) * 32,
             "k_xor_keys": (st["log_entries"] if "k_build_ranges" in kprof or "k_insert_admitted" in kprof else st["table_slots"]) * 32 + cand0 * 17,  # key scan in, one 16-byte item + digit byte out

@@ -372,6 +372,8 @@ typedef struct rg_stats {
 	uint64_t host_syncs;        /* times the host has waited for the handle's stream so far (sizes read back for the next allocation or grid) */
 	uint64_t folded_level_bits; /* partitioned sweep: bits of the first partition level done by the record kernel itself (0 = none); partition_levels counts it */
 	uint64_t items_from_sweep;  /* 1: the Bloom admission started from items the aggregation made while it wrote the log (no pass over the log to make them) */
+	uint64_t compact_log;       /* one-word keys, items made by the aggregation: 1 = the log was written in 16-byte entries (key, count and edge bits; the item carries the
+	                             * arrival stamp) and read as such by the one-pass admission, 2 = written so and expanded to full entries for another route, 0 = full entries */
 } rg_stats;
 int rg_get_stats(rg_handle *h, rg_stats *out);
 
@@ -404,7 +406,8 @@ int rg_release_cached_memory(void);
  *   bit  24    resolve a power-of-two Bloom filter by key partitions whatever its fill
  *   bit  25    pick the bucket count from a sample of the records even on small inputs
  *   bit  26    aggregate with the 512-slot k-mer tables that diverse inputs get
- *   bit  27    keep super-k-mer records in their 24-byte form where the 20-byte one applies (k <= 31)
+ *   bit  27    keep super-k-mer records in their 24-byte form where the 20-byte one applies (k <= 31), and log entries in their
+ *              32-byte form where the 16-byte one applies (one-word keys, items made by the aggregation)
  *   bit  28    key partitions: size the first level's ranges from a histogram pass instead of in advance
  *   bit  29    key partitions: the dense region kernel even on a sparse filter
  *   bit  30    cut the records of k = 31 with the generic lane-per-read kernel instead of the one unrolled for its window

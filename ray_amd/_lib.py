@@ -39,7 +39,7 @@ class RgConfig(C.Structure):
 
 class RgStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("reads", "occurrences", "candidates", "stored_pairs", "bloom_bits",
-                                         "bloom_insertions", "bloom_set_bits", "table_slots", "sweep_partitioned", "superkmer_records", "partition_levels", "log_entries", "bloom_partitioned", "host_syncs", "folded_level_bits", "items_from_sweep")]
+                                         "bloom_insertions", "bloom_set_bits", "table_slots", "sweep_partitioned", "superkmer_records", "partition_levels", "log_entries", "bloom_partitioned", "host_syncs", "folded_level_bits", "items_from_sweep", "compact_log")]
 
 
 # every symbol include/raygraph.h declares

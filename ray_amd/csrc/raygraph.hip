@@ -1360,6 +1360,8 @@ struct rg_handle {
 	Slot *pending_log = nullptr;         // size == 1: the sweep's log of distinct k-mers, admitted before it is inserted
 	uint64_t pending_multi = ~0ull;      // its entries seen twice or more (~0: not known): with the false positives they bound what admission stores
 	bool pending_borrowed = false;       // the pending log is the caller's buffer (rg_adopt_entries): never freed here
+	bool pending_compact = false;        // the pending log holds 16-byte entries (AggItems::compact): read as such by the one-pass admission, expanded for every other route
+	bool log_compact = false;            // the last sweep's log is such a log
 	uint64_t pending_n = 0, pending_keys = 0;
 	bool merge_started = false;          // rg_merge_entries has been called with entries
 	void *rec_buf = nullptr;             // rg_records_local .. rg_export_records: super-k-mer records of the local reads
@@ -1613,7 +1615,7 @@ struct AggLaunch {
 	// from the record sample)
 	uint64_t occ_per_bucket() const { return wg ? (uint64_t)KS * 24 : 4096; }
 	unsigned grid_for_buckets(uint64_t n, int n_cu) const { return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n + per_group() - 1) / per_group(), (uint64_t)n_cu * occ)); }
-	AggItems items = {nullptr, nullptr, nullptr, 0, 0, 0, 0};  // k_aggregate makes the Bloom admission's items on the way (sweep_partitioned_t decides)
+	AggItems items = {nullptr, nullptr, nullptr, 0, 0, 0, 0, 0};  // k_aggregate makes the Bloom admission's items on the way (sweep_partitioned_t decides)
 	void fast(rg_handle *h, unsigned grid, const RM *recs, const unsigned long long *begin, uint32_t nb, int k, Slot *log, uint64_t log_cap,
 	          uint32_t flag_unique, uint32_t *retry, int m, uint32_t rbits) const {
 		if (wg)
@@ -2076,6 +2078,11 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	// usual way.  rg_debug_set bit 2: never.
 	if (!nested) drop_held_items(h);
 	bool with_items = false;
+	// ... and, for one-word keys, writes the log in 16-byte entries (key, meta): the item carries the stamp, and the one-pass
+	// admission reads nothing else (half the bytes of the log, written here and read there; every other route gets the log
+	// expanded first: expand_pending_log).  Such a log serves only with its items: if they turn out unusable the aggregation is
+	// done again the plain way.  rg_debug_set bit 27: never.
+	bool compact = false;
 	uint64_t items_bits = 0;
 	if (!nested && !ext && h->cfg.size == 1 && flag_unique && !agg.wg && !(h->dbg & 0x4u) && sized_by_sample && (sample_distinct >= (double)(1u << 21) || (h->dbg & 0x2000000u))) {  // (bit 25: the sample, hence this, on small inputs too: tests)
 		uint64_t mb = h->cfg.bloom_bits;
@@ -2091,12 +2098,14 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 			    pool_alloc(dev, (void **)&h->held.side, nruns * rcap) == hipSuccess && pool_alloc(dev, (void **)&h->held.d_count, nruns * sizeof(uint32_t)) == hipSuccess) {
 				int B = 0;
 				while ((1ull << B) < mb) B++;
-				agg.items = AggItems{h->held.items, h->held.side, h->held.d_count, (uint32_t)rcap, agg_grid, mb - 1, B - 5};
+				agg.items = AggItems{h->held.items, h->held.side, h->held.d_count, (uint32_t)rcap, agg_grid, mb - 1, B - 5, 0};
 				h->held.n_wg = agg_grid;
 				h->held.run_cap = (uint32_t)rcap;
 				h->held.count.resize(nruns);
 				items_bits = mb;
 				with_items = true;
+				compact = W == 1 && !(h->dbg & 0x8000000u);
+				agg.items.compact = compact ? 1u : 0u;
 			} else {
 				(void)hipGetLastError();
 				drop_held_items(h);
@@ -2106,16 +2115,19 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	for (int attempt = 0;; ++attempt) {
 		if (with_items && attempt > 0) {  // the log had to grow: the runs were sized for the first one
 			with_items = false;
+			compact = false;
 			agg.items.items = nullptr;
+			agg.items.compact = 0;
 			drop_held_items(h);
 		}
+		const size_t log_esz = compact ? sizeof(Ent16) : sizeof(Slot);
 		const bool force_probe = (h->dbg & 0x40000) != 0;
 		const bool will_probe = !nested && attempt == 0 && !(h->dbg & 64) && !sized_by_sample && (NBUCK >= (1u << 16) || force_probe);
 		const uint32_t P = force_probe ? std::max<uint32_t>((uint32_t)NBUCK / 4, 1u) : (uint32_t)NBUCK / 256;
 		// the sample runs on a small log of its own (one entry per occurrence of its share would always do; 1.5 x the average
 		// share + the chunks left open is what it gets), the real log is allocated once its size is known
 		const uint64_t alloc_cap = will_probe ? std::min<uint64_t>(log_cap, (uint64_t)((double)occ_bound * 1.5 * (double)P / (double)NBUCK) + log_slack + (1ull << 16)) : log_cap;
-		if (pool_alloc(dev, (void **)&log, alloc_cap * sizeof(Slot)) != hipSuccess) {
+		if (pool_alloc(dev, (void **)&log, alloc_cap * log_esz) != hipSuccess) {
 			(void)hipGetLastError();
 			log = nullptr;
 			pool_free(dev, d_retry);
@@ -2156,7 +2168,7 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 			}
 			pool_free(dev, log);  // the sample's log; the real one has the size the sample asks for (or, if the sample failed, the default)
 			log = nullptr;
-			if (pool_alloc(dev, (void **)&log, log_cap * sizeof(Slot)) != hipSuccess) {
+			if (pool_alloc(dev, (void **)&log, log_cap * log_esz) != hipSuccess) {
 				(void)hipGetLastError();
 				pool_free(dev, d_retry);
 				cleanup();
@@ -2206,7 +2218,22 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 			pool_free(dev, log);
 			return RG_OK;
 		}
-		if (!h->h_counters[PC_LOG_OVF] && !too_small) break;
+		if (!h->h_counters[PC_LOG_OVF] && !too_small) {
+			if (compact) {  // usable only if the items are (the conditions below, where they are kept)
+				uint64_t total = 0;
+				for (auto c : h->held.count) total += c;
+				const uint64_t n = h->h_counters[PC_LOG_CURSOR];
+				const bool fine = flag_unique && h->h_counters[PC_NONUNIQUE] == 0 && h->h_counters[PC_LDS_SPILL] == 0 && h->h_counters[PC_ITEM_OVF] == 0 &&
+				                  total == h->h_counters[PC_LOG_KEYS] && n > 0 && n < (1ull << 32);
+				if (!fine) {
+					if (getenv("RG_DEBUG")) fprintf(stderr, "[raygraph] partitioned sweep: the compact log is of no use without its items, aggregating again\n");
+					pool_free(dev, log);
+					log = nullptr;
+					continue;  // (the next attempt drops the items and writes full entries; the log keeps its size)
+				}
+			}
+			break;
+		}
 		pool_free(dev, log);
 		log = nullptr;
 		if (log_cap >= occ_bound + log_slack) {  // cannot happen: one entry per occurrence always fits
@@ -2226,6 +2253,8 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	if (nested) return RG_OK;  // the caller reads PC_LOG_KEYS
 	h->log_all_unique = flag_unique && h->h_counters[PC_NONUNIQUE] == 0 && h->h_counters[PC_LDS_SPILL] == 0;
 	h->log_keys = h->h_counters[PC_LOG_KEYS];
+	h->log_compact = compact;
+	h->stats.compact_log = compact ? 1 : 0;
 	if (with_items) {
 		uint64_t total = 0;
 		for (auto c : h->held.count) total += c;
@@ -2237,6 +2266,11 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 		} else {
 			if (getenv("RG_DEBUG")) fprintf(stderr, "[raygraph] the items k_aggregate made are dropped (%llu of %llu keys, %llu runs overflowed)\n", (unsigned long long)total, (unsigned long long)h->log_keys, (unsigned long long)h->h_counters[PC_ITEM_OVF]);
 			drop_held_items(h);
+			if (compact) {  // (checked before the loop was left)
+				pool_free(dev, log);
+				*out_log = nullptr;
+				return fail(h, RG_ERR_STATE, "a compact log lost its items");
+			}
 		}
 	}
 	h->stats.superkmer_records = valid;
@@ -2592,6 +2626,39 @@ static int bloom_partitioned(rg_handle *h, Table &T, uint64_t m_bits, uint64_t k
 // keep_lost != nullptr: the admission kernel is not run; the marks (one byte per slot of T, 8 = false positive) are handed to
 // the caller, who admits while building the table and frees them with pool_free.
 // counted: the first level's ranges come from a histogram pass (k_xor_hist) instead of being sized in advance.
+// The pending log in its full form, if it is a compact one (AggItems::compact): for every route but the one-pass admission.
+// with_stamps: the arrival stamps come back from the items k_aggregate made beside the log, which must still be held (they
+// stay valid for the expanded log: same positions); without, the stamps are INF_STAMP -- enough once the admission is decided.
+static int expand_pending_log(rg_handle *h, bool with_stamps) {
+	if (!h->pending_log || !h->pending_compact) return RG_OK;
+	const int dev = h->cfg.device;
+	const bool items = h->held.valid && h->held.log == h->pending_log;
+	if (with_stamps && !items) return fail(h, RG_ERR_STATE, "a compact log without its items");
+	Slot *full = nullptr;
+	if (pool_alloc(dev, (void **)&full, h->pending_n * sizeof(Slot)) != hipSuccess) {
+		(void)hipGetLastError();
+		return fail(h, RG_ERR_NOMEM, "out of device memory expanding the log");
+	}
+	{
+		ProfScope ps(h, "k_expand_log");
+		hipLaunchKernelGGL(k_expand_entries, dim3((unsigned)std::min<uint64_t>((h->pending_n + 255) / 256, 1u << 16)), dim3(256), 0, h->stream, (const Ent16 *)h->pending_log, h->pending_n, full);
+		if (with_stamps)
+			hipLaunchKernelGGL(k_expand_stamps, dim3(AGG_ITEM_RUNS * h->held.n_wg), dim3(256), 0, h->stream, h->held.items, h->held.d_count, h->held.run_cap, full, h->pending_n);
+	}
+	hipError_t e = hipGetLastError();
+	if (e == hipSuccess) e = rg_stream_sync(h);
+	if (e != hipSuccess) {
+		pool_free(dev, full);
+		return fail(h, RG_ERR_HIP, "expanding the log: %s", hipGetErrorString(e));
+	}
+	pool_free(dev, h->pending_log);
+	if (items) h->held.log = full;
+	h->pending_log = full;
+	h->pending_compact = false;
+	h->stats.compact_log = 2;
+	return RG_OK;
+}
+
 static int bloom_xor(rg_handle *h, Table &T, uint64_t m_bits, uint64_t keys, bool *ok, uint8_t **keep_lost = nullptr, bool counted = false) {
 	*ok = false;
 	if (h->dbg & 0x10000000u) counted = true;  // rg_debug_set bit 28 (tests)
@@ -2626,6 +2693,12 @@ static int bloom_xor(rg_handle *h, Table &T, uint64_t m_bits, uint64_t keys, boo
 	// the items of this very log and filter, made by k_aggregate while it wrote the log (AggItems): the first level (5 bits) is
 	// done, in runs per workgroup of that kernel
 	const bool from_items = h->held.valid && h->held.log == T.slots && h->held.m_bits == m_bits && h->held.total == keys && !counted && PB - 5 > 8 && PB - 5 <= 16;
+	if (h->pending_compact && T.slots == h->pending_log && !(from_items && keep_lost)) {  // this route reads the log, or admits in place
+		const int rcx = expand_pending_log(h, true);
+		if (rcx) return rcx;
+		T.slots = h->pending_log;
+		return bloom_xor(h, T, m_bits, keys, ok, keep_lost, counted);
+	}
 	if (!from_items) drop_held_items(h);  // (whatever is held belongs to another log or filter)
 	rg_handle::HeldItems held;            // owned here from now on
 	h->stats.items_from_sweep = from_items ? 1 : 0;
@@ -2709,6 +2782,7 @@ static int bloom_xor(rg_handle *h, Table &T, uint64_t m_bits, uint64_t keys, boo
 	if (e != hipSuccess) {
 		(void)hipGetLastError();
 		cleanup();
+		if (h->pending_compact && T.slots == h->pending_log) return fail(h, RG_ERR_NOMEM, "out of device memory for the admission of a compact log");  // (its items went with the cleanup)
 		return RG_OK;
 	}
 #define XTRY(call)                                                                                          \
@@ -2937,6 +3011,7 @@ __global__ __launch_bounds__(256) void k_adopt_entries(const Slot *__restrict__ 
 // exchange calls): the classic merge of the whole log
 static int materialize_pending_log(rg_handle *h) {
 	if (!h->pending_log) return RG_OK;
+	if (int rcx = expand_pending_log(h, true)) return rcx;
 	Table &T = h->tab;
 	int rc = table_reserve(h, T, h->pending_n, C_FILL);
 	if (rc) return rc;
@@ -2996,8 +3071,10 @@ static int collect_histogram(rg_handle *h, const unsigned long long *dense, cons
 // advance from it and counts the vertices, after which the table gets its real capacity.  *presize_failed: a range was too
 // small; nothing was built, the statistics the pass gathered are void and the caller counts first, the classic way.
 static int build_table_ranges(rg_handle *h, const Slot *log, uint64_t n_log, uint64_t retained, bool *done, const uint8_t *lost = nullptr,
-                              const unsigned long long *first_hist = nullptr, bool fused = false, bool *presize_failed = nullptr) {
+                              const unsigned long long *first_hist = nullptr, bool fused = false, bool *presize_failed = nullptr, bool compact_log = false) {
+	// compact_log: 16-byte entries (AggItems::compact), read by the fused first level only
 	*done = false;
+	if (compact_log && (!fused || h->W != 1)) return fail(h, RG_ERR_STATE, "a compact log on a route that does not read one");
 	if (presize_failed) *presize_failed = false;
 	const int dev = h->cfg.device;
 	Table &T = h->tab;
@@ -3090,7 +3167,7 @@ static int build_table_ranges(rg_handle *h, const Slot *log, uint64_t n_log, uin
 	const void *level_in = log;
 	int used_bits = 0, cur = 0;
 	uint64_t stored = retained;  // fused: what the first level counted
-	AdmitStats no_stats = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0};
+	AdmitStats no_stats = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0};
 	for (int level = 0; level < nlev; ++level) {
 		const uint32_t S = (uint32_t)seg_begin.size() - 1;
 		const int db = dbits[level];
@@ -3140,7 +3217,7 @@ static int build_table_ranges(rg_handle *h, const Slot *log, uint64_t n_log, uin
 		if (level == 0 && fused) {
 			TTRY(pool_alloc(dev, (void **)&d_spread, (size_t)ADMIT_SPREAD * 258 * sizeof(unsigned long long)));
 			TTRY(hipMemsetAsync(d_spread, 0, (size_t)ADMIT_SPREAD * 258 * sizeof(unsigned long long), h->stream));
-			st = AdmitStats{h->d_counters, h->d_hist_dense, h->d_hist_ovf, d_lim, d_spread, HIST_DENSE, HIST_OVF_CAP, (int)C_RETAINED, (int)C_INSERTIONS, (int)C_OVF, (int)C_ENT_PRESIZE};
+			st = AdmitStats{h->d_counters, h->d_hist_dense, h->d_hist_ovf, d_lim, d_spread, HIST_DENSE, HIST_OVF_CAP, (int)C_RETAINED, (int)C_INSERTIONS, (int)C_OVF, (int)C_ENT_PRESIZE, compact_log ? 1u : 0u};
 		}
 		{
 			ProfScope ps(h, "k_scatter_entries");
@@ -3471,11 +3548,15 @@ int rg_count_local(rg_handle *h) {
 				if (single && h->log_all_unique && n_log && n_log < (1ull << 32)) {
 					// admission first, insertion afterwards (rg_resolve_admission): only stored vertices reach the table
 					h->pending_log = log;
+					h->pending_compact = h->log_compact;
 					h->pending_n = n_log;
 					h->pending_keys = h->log_keys;
 					rc = sync_counters(h);
 					if (rc) return rc;
 					h->pending_multi = h->h_counters[C_LOG_MULTI];
+				} else if (h->log_compact) {
+					pool_free(h->cfg.device, log);
+					return fail(h, RG_ERR_STATE, "a compact log that cannot be kept");  // (the sweep makes one only where it is)
 				} else if (single) {
 					rc = table_reserve(h, T, n_log ? n_log : 1, fill_counter);
 					if (rc == RG_OK && n_log) {
@@ -3839,6 +3920,15 @@ int rg_resolve_admission(rg_handle *h, uint64_t local_reads_for_bloom) {
 	bool resolved = false;
 	uint8_t *lost_kept = nullptr;             // marks of a Bloom resolution whose admission is deferred to the table build
 	unsigned long long *d_first_hist = nullptr;
+	// a compact log (AggItems::compact) is read by bloom_xor's start from the held items and by the one-pass admission; whatever
+	// else is about to run gets the full form first
+	auto full_log = [&](bool with_stamps) -> int {
+		const int rcx = expand_pending_log(h, with_stamps);
+		logview.slots = h->pending_log;
+		return rcx;
+	};
+	if (m_bits == 0 && h->pending_compact)
+		if (int rcx = full_log(true)) return rcx;
 	if (m_bits > 0) {
 		// keys in the table decide the method: region partitioning when the filter stays sparse
 		// (8 touches per key), dense first-touch stamps otherwise.  rg_debug_set bit 4 forces the
@@ -3864,6 +3954,8 @@ int rg_resolve_admission(rg_handle *h, uint64_t local_reads_for_bloom) {
 			if (rc0) return rc0;
 			if (resolved) h->stats.bloom_partitioned = 2;
 		}
+		if (!resolved && h->pending_compact)
+			if (int rcx = full_log(true)) return rcx;
 		if (!resolved && !(flags & 32u) && ((flags & 16u) || (regions_fit && keys >= (1ull << 20)))) {
 			rc0 = bloom_partitioned(h, T, m_bits, keys, &resolved);
 			if (rc0) return rc0;
@@ -3904,12 +3996,16 @@ int rg_resolve_admission(rg_handle *h, uint64_t local_reads_for_bloom) {
 	// statistics and the histogram and writes into ranges sized in advance -- possible when the stored vertices can be bounded
 	// before it: entries seen twice or more (counted by whoever made the log) + false positives (counted by k_xor_fp).
 	bool fused_built = false, fused_tried = false;
+	auto drop_marks = [&]() {
+		pool_free(h->cfg.device, lost_kept);
+		lost_kept = nullptr;
+	};
 	if (lost_kept && from_log && h->pending_multi != ~0ull && !(h->dbg & 0x800000)) {
 		const uint64_t bound = std::min<uint64_t>(h->pending_keys, h->pending_multi + h->h_counters[C_FP_COUNT]);
 		if (bound >= (1ull << 20) || (h->dbg & 0x400000)) {
 			bool presize_failed = false;
 			fused_tried = true;
-			int rcb = build_table_ranges(h, h->pending_log, h->pending_n, std::max<uint64_t>(bound, 1), &fused_built, lost_kept, nullptr, true, &presize_failed);
+			int rcb = build_table_ranges(h, h->pending_log, h->pending_n, std::max<uint64_t>(bound, 1), &fused_built, lost_kept, nullptr, true, &presize_failed, h->pending_compact);
 			if (rcb) {
 				pool_free(h->cfg.device, lost_kept);
 				return rcb;
@@ -3926,6 +4022,12 @@ int rg_resolve_admission(rg_handle *h, uint64_t local_reads_for_bloom) {
 				}
 				fused_tried = false;
 			}
+		}
+	}
+	if (h->pending_compact && !fused_built) {  // the admission is decided: the routes below read full entries, whose stamps no longer matter
+		if (int rcx = full_log(false)) {
+			drop_marks();
+			return rcx;
 		}
 	}
 	if (lost_kept && !fused_tried) {  // the counting pass of the admission: statistics, histogram, first level of the table partition; the log stays as it is
@@ -3980,6 +4082,7 @@ int rg_resolve_admission(rg_handle *h, uint64_t local_reads_for_bloom) {
 		if (rc == RG_OK) rc = sync_counters(h);
 		pool_free(h->cfg.device, h->pending_log);  // (a borrowed buffer is not the pool's: nothing happens)
 		h->pending_log = nullptr;
+		h->pending_compact = false;
 		h->pending_multi = ~0ull;
 		h->pending_borrowed = false;
 		h->pending_n = 0;

@@ -1319,7 +1319,15 @@ struct AggItems {
 	uint32_t run_cap, n_wg;
 	uint64_t m_mask;
 	int shift1;  // log2(filter bits) - 5
+	// one-word keys only: the log holds 16-byte entries (key, meta) -- the item carries the stamp, which nothing else reads
+	// between here and the table when the admission starts from the items (half the bytes of the log, written and read)
+	uint32_t compact;
 };
+// a compact log's entry (Ent16 of rg_table.h: key, meta)
+__device__ __forceinline__ void log_store(Slot *__restrict__ log, unsigned long long dst, const Slot &e, bool compact) {
+	if (compact) *reinterpret_cast<ulonglong2 *>(reinterpret_cast<uint64_t *>(log) + 2 * dst) = make_ulonglong2(e.k0, e.meta);
+	else log[dst] = e;
+}
 static constexpr uint32_t AGG_ITEM_RUNS = 32;
 
 static constexpr uint32_t AGG_SLOTS = 256;      // the k-mer table of a wavefront ...
@@ -1582,7 +1590,7 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<
 				e.k1 = (W == 2) ? T.k1[sl] : EMPTY;
 				e.stamp = T.stamp[sl];
 				e.meta = (uint64_t)T.cnt[sl] | ((uint64_t)(T.edges[sl] & 0xFFu) << PEND_SHIFT) | mark;
-				log[dst] = e;
+				log_store(log, dst, e, W == 1 && ai.compact);
 				multi_written += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64((uint32_t)e.meta >= 2u));  // (the count is the low 32 bits here)
 				if (ai.items) {
 					const uint64_t o = xor_origin<W>(e.k0, e.k1, ai.m_mask);
@@ -1753,7 +1761,7 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<
 							en.k1 = (W == 2) ? i1 : EMPTY;
 							en.stamp = stamp0 + i;
 							en.meta = (uint64_t)weight | ((uint64_t)em << PEND_SHIFT);
-							log[g] = en;
+							log_store(log, g, en, W == 1 && ai.compact);  // (such a log is not used: the entry is not unique)
 						} else {
 							atomicAdd(&counters[PC_LOG_OVF], 1ull);
 						}
@@ -2060,7 +2068,10 @@ __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<
 	// close the last chunk
 	if (chunk_base != NO_CHUNK)
 		for (uint32_t i = chunk_used + lane; i < LOG_CHUNK; i += 64)
-			if (chunk_base + i < log_cap) log[chunk_base + i].k0 = EMPTY;
+			if (chunk_base + i < log_cap) {
+				if (W == 1 && ai.compact) reinterpret_cast<uint64_t *>(log)[2 * (chunk_base + i)] = EMPTY;
+				else log[chunk_base + i].k0 = EMPTY;
+			}
 	if (ai.items) {
 		__syncthreads();
 		if (threadIdx.x < AGG_ITEM_RUNS) ai.run_count[threadIdx.x * ai.n_wg + blockIdx.x] = s_icur[threadIdx.x] < ai.run_cap ? s_icur[threadIdx.x] : ai.run_cap;

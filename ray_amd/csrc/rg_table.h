@@ -22,6 +22,7 @@
 // the ordinary insert after every range had been written, so there is no free slot between its home and itself.
 #pragma once
 #include "rg_device.h"
+#include "rg_partition.h"
 #include <type_traits>
 
 namespace rg {
@@ -125,7 +126,29 @@ struct AdmitStats {
 	                                 // addresses took 67 ms on C2 with 1 % errors where the counting pass, 2048 workgroups, took 7.6); k_fold_admit_stats sums them
 	uint32_t hist_dense_n, hist_ovf_cap;
 	int c_retained, c_insertions, c_ovf, c_presize;
+	uint32_t compact;                // one-word keys: the log holds 16-byte entries (AggItems::compact)
 };
+
+// A compact log (AggItems::compact) in the full form, for the routes that do not read the compact one: the entries, and -- from
+// the items k_aggregate made beside them, while they are held -- the arrival stamps (without them the stamps are INF_STAMP, which
+// is all the routes behind a decided admission need).
+__global__ __launch_bounds__(256) void k_expand_entries(const Ent16 *__restrict__ in, uint64_t n, Slot *__restrict__ out) {
+	for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+		const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(&in[i]);
+		*reinterpret_cast<ulonglong2 *>(&out[i].k0) = make_ulonglong2(a.x, EMPTY);
+		*reinterpret_cast<ulonglong2 *>(&out[i].stamp) = make_ulonglong2(INF_STAMP, a.y);
+	}
+}
+__global__ __launch_bounds__(256) void k_expand_stamps(const Item16 *__restrict__ items, const uint32_t *__restrict__ run_count, uint32_t run_cap,
+                                                       Slot *__restrict__ out, uint64_t n) {
+	const uint32_t run = blockIdx.x, c = run_count[run];
+	const Item16 *__restrict__ p = items + (uint64_t)run * run_cap;
+	for (uint32_t i = threadIdx.x; i < c; i += 256) {
+		const ulonglong2 it = *reinterpret_cast<const ulonglong2 *>(&p[i]);
+		const uint64_t dst = (it.x & 0x7FFFFFFFull) | ((it.y >> 63) << 31);
+		if (dst < n) out[dst].stamp = it.y & ~(1ull << 63);
+	}
+}
 
 // One partition level of 32-byte entries (see k_scatter for the scheme).  FIRST: the input is the log of the sweep --
 // unused chunk entries and entries that are not admitted are dropped here; lost != nullptr: the log is as the sweep wrote
@@ -172,7 +195,9 @@ __global__ __launch_bounds__(ENT_THREADS) void k_scatter_entries(const std::cond
 		rank[j] = 0;
 		nxt[j] = 0;
 		if (i < end) {
-			Slot v = ent_load(&in[i]);
+			Slot v;
+			if constexpr (FIRST && W == 1) v = st.compact ? ent_load(reinterpret_cast<const Ent16 *>(in) + i) : ent_load(&in[i]);
+			else v = ent_load(&in[i]);
 			bool keep = true;
 			if (FIRST && stats) {  // the admission rule with its statistics (k_admit_lost: MessageProcessor.cpp:741-804)
 				keep = false;

@@ -28,7 +28,7 @@ def assert_records_equal(a, b, what=""):
     assert np.array_equal(a["edges"], b["edges"]), what + ": edge bitmaps differ"
 
 
-def gpu_vs_oracle(ro, packed, offsets, lengths, k, bloom_bits=None, W=None, purge=True, batches=1, tmpdir=None, first_read_id=0,
+def gpu_vs_oracle(ro, packed, offsets, lengths, k, bloom_bits=None, W=None, purge=True, batches=1, tmpdir=None, first_read_id=0, table_slots=0,
                   sweeps=(1 | 16 | (8 << 8) | 0x20000, 1 | 32 | (12 << 8), 1 | 16 | (19 << 8), 1 | 16 | (12 << 8) | 0x10000, 1 | 16 | (19 << 8) | 0x200000, 1 | 32 | (10 << 8) | 0x200000, 1 | 16 | (12 << 8) | 0x400000, 1 | 32 | (8 << 8) | 0x800000, 1 | 16 | 0x2000000, 1 | 32 | (9 << 8) | 0x4000000, 1 | 16 | (17 << 8) | 0x8000000, 1 | 32 | (12 << 8) | 0x8000000 | 0x10000, 1 | 16 | (12 << 8) | 0x40000000, 1 | 32 | 0x2000000 | 0x80000000, 1 | 16 | 8 | (13 << 8), 1 | 32 | 8 | (17 << 8) | 0x100000, 1 | 16 | 8 | 0x2000000, 1 | 32 | 0x80 | (12 << 8), 2 | 32, 2 | 16 | 0x20000)):
     """single-rank parity through the C ABI, once per sweep implementation: the partitioned sweep
     (super-k-mer records + LDS aggregation) with 2^8, 2^12 and 2^19 buckets = one, two and three partition
@@ -43,16 +43,18 @@ def gpu_vs_oracle(ro, packed, offsets, lengths, k, bloom_bits=None, W=None, purg
     returns the oracle outputs"""
     want = oracle_run(ro, packed, offsets, lengths, k, 1, bloom_bits, W, purge)
     for sweep in sweeps:
-        want["builder"] = _gpu_check(ro, want, packed, offsets, lengths, k, bloom_bits, W, purge, batches, tmpdir, sweep, first_read_id)
+        want["builder"] = _gpu_check(ro, want, packed, offsets, lengths, k, bloom_bits, W, purge, batches, tmpdir, sweep, first_read_id, table_slots)
     return want
 
 
-def _gpu_check(ro, want, packed, offsets, lengths, k, bloom_bits, W, purge, batches, tmpdir, sweep, first_read_id=0):
-    """first_read_id: the global id of the first read (a constant added to every arrival stamp changes no result)"""
+def _gpu_check(ro, want, packed, offsets, lengths, k, bloom_bits, W, purge, batches, tmpdir, sweep, first_read_id=0, table_slots=0):
+    """first_read_id: the global id of the first read (a constant added to every arrival stamp changes no result);
+    table_slots: a minimum capacity of the vertex table (2^20 slots or more make a range-by-range build of two levels, the
+    smallest the one-pass admission applies to)"""
     import ray_amd
     from ray_amd.graph import RG_BLOOM_DEFAULT
     b = ray_amd.GraphBuilder(k, bloom_bits=RG_BLOOM_DEFAULT if bloom_bits is None else bloom_bits,
-                             kmer_words=W if W else 0, sweep=sweep, first_read_id=first_read_id)
+                             kmer_words=W if W else 0, sweep=sweep, first_read_id=first_read_id, table_slots=table_slots)
     n = len(lengths)
     cuts = [n * i // batches for i in range(batches + 1)]
     for i in range(batches):

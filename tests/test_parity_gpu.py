@@ -252,8 +252,39 @@ def test_admission_items_made_by_the_aggregation(oracle, k, log2_bits):
     want = gpu_vs_oracle(oracle, packed, offsets, lengths, k, bloom_bits=1 << log2_bits, sweeps=(base, base | 8))
     st = want["builder"].stats()
     assert st["bloom_partitioned"] == 2 and st["items_from_sweep"] == 1
-    want = gpu_vs_oracle(oracle, packed, offsets, lengths, k, bloom_bits=1 << log2_bits, sweeps=(base | 4,))
-    assert want["builder"].stats()["items_from_sweep"] == 0
+    # one-word keys: the log beside the items is written in 16-byte entries; a table this small is not built by the one-pass
+    # admission (one partition level), so the log is expanded once the admission is decided
+    assert st["compact_log"] == (2 if k <= 32 else 0)
+    # ... a table of 2^21 slots is: the 16-byte entries are read as they are
+    want = gpu_vs_oracle(oracle, packed, offsets, lengths, k, bloom_bits=1 << log2_bits, sweeps=(base, base | 8), table_slots=1 << 21)
+    st = want["builder"].stats()
+    assert st["items_from_sweep"] == 1 and st["compact_log"] == (1 if k <= 32 else 0) and st["table_slots"] == 1 << 21
+    want = gpu_vs_oracle(oracle, packed, offsets, lengths, k, bloom_bits=1 << log2_bits, sweeps=(base | 4,), table_slots=1 << 21)
+    st = want["builder"].stats()
+    assert st["items_from_sweep"] == 0 and st["compact_log"] == 0
+    want = gpu_vs_oracle(oracle, packed, offsets, lengths, k, bloom_bits=1 << log2_bits, sweeps=(base | 0x8000000,), table_slots=1 << 21)
+    st = want["builder"].stats()
+    assert st["items_from_sweep"] == 1 and st["compact_log"] == 0
+
+
+@pytest.mark.parametrize("k", [21, 31])
+@pytest.mark.parametrize("route,flags,expanded", [
+    ("key partition from the items, admission in place, classic insert", 0, True),
+    ("admission decided, the table too small for the one-pass admission: counting pass and exact ranges", 0x400000, True),
+    ("never range by range", 0x800000, True),
+    ("Bloom regions of (bit, key) items", 16, True),
+    ("dense first-touch stamps", 32, True),
+    ("key partitions from a histogram pass", 0x10000000, True),
+])
+def test_a_compact_log_is_expanded_for_the_routes_that_read_full_entries(oracle, k, route, flags, expanded):
+    """one-word keys with items made by the aggregation: the log is written in 16-byte entries; every route but the key
+    partition that starts from the items + the one-pass admission gets it expanded first -- with the arrival stamps taken
+    back from the items where the admission is still to be decided"""
+    packed, offsets, lengths = make_reads_numpy(genome=25000, read_len=150, n_reads=7000, seed=77 + k, error=0.02)
+    base = 1 | 0x2000000 | 0x1000000
+    want = gpu_vs_oracle(oracle, packed, offsets, lengths, k, bloom_bits=1 << 28, sweeps=(base | flags,))
+    st = want["builder"].stats()
+    assert st["compact_log"] == (2 if expanded else 1), route
 
 
 @pytest.mark.parametrize("k", [21, 31, 47, 63])
