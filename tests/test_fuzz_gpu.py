@@ -63,6 +63,44 @@ def test_random_case(oracle, seed):
     gpu_vs_oracle(oracle, packed, offsets, lengths, c["k"], bloom_bits=c["bloom_bits"], sweeps=c["sweeps"], batches=c["batches"], W=c["W"])
 
 
+ITEM_FLAG_CHOICES = (0x4, 0x8, 0x80, 16, 32, 0x10000, 0x400000, 0x800000, 0x4000000, 0x8000000, 0x10000000, 0x20000000, 0x40000000, 0x80000000)
+
+
+def _item_case(seed):
+    """the routes of large one-rank inputs on small ones: the partition sized from a record sample, a filter of 2^28 bits or
+    more (the aggregation makes the admission's items and, for one-word keys, a 16-byte log), a table large enough for the
+    one-pass admission half of the time, and a random mix of the switches that turn parts of that off or force another route"""
+    rng = np.random.default_rng(9000 + seed)
+    k = int(rng.choice([17, 21, 27, 31, 31, 33, 47, 63]))
+    big = k > 32
+    read_len = int(rng.integers(120, 260))
+    genome = int(rng.integers(15000, 40000)) * (4 if big else 1)
+    n_reads = int(genome * float(rng.choice([20, 40])) / read_len)
+    sweeps = []
+    for _ in range(2):
+        s = 1 | 0x2000000 | 0x1000000
+        for f in ITEM_FLAG_CHOICES:
+            if rng.random() < 0.2:
+                s |= f
+        if (s & 16) and (s & 32):
+            s &= ~32
+        if (s & 0x400000) and (s & 0x800000):
+            s &= ~0x800000
+        sweeps.append(s)
+    return dict(k=k, read_len=read_len, genome=genome, n_reads=n_reads, error=float(rng.choice([0.0, 0.01, 0.03])), ragged=bool(rng.random() < 0.3),
+                bloom_bits=1 << int(rng.choice([28, 28, 29, 30, 31, 33])), sweeps=tuple(sweeps), batches=int(rng.choice([1, 2])),
+                table_slots=int(rng.choice([0, 1 << 21])), W=2 if (not big and rng.random() < 0.1) else None)
+
+
+# RG_FUZZ_ITEM_SEEDS=N widens the run
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RG_FUZZ_ITEM_SEEDS", "10"))))
+def test_random_case_with_items_from_the_aggregation(oracle, seed):
+    c = _item_case(seed)
+    packed, offsets, lengths = make_reads_numpy(c["genome"], c["read_len"], c["n_reads"], seed=900 + seed, error=c["error"], ragged=c["ragged"])
+    gpu_vs_oracle(oracle, packed, offsets, lengths, c["k"], bloom_bits=c["bloom_bits"], sweeps=c["sweeps"], batches=c["batches"], W=c["W"],
+                  table_slots=c["table_slots"])
+
+
 @pytest.mark.parametrize("k", [21, 31, 47])
 def test_record_header_extremes(oracle, k):
     """what a super-k-mer record's header must hold at its largest: read ids just below 2^33 (the arrival stamps only order
