@@ -1362,6 +1362,9 @@ struct rg_handle {
 	bool pending_borrowed = false;       // the pending log is the caller's buffer (rg_adopt_entries): never freed here
 	bool pending_compact = false;        // the pending log holds 16-byte entries (AggItems::compact): read as such by the one-pass admission, expanded for every other route
 	bool log_compact = false;            // the last sweep's log is such a log
+	uint64_t log_multi = ~0ull;          // its entries seen twice or more, as the sweep's last read of the counters had them
+	std::vector<unsigned long long> hist_stage;  // the dense histogram bins on their way to the host, copied ahead of a wait that was due anyway
+	bool hist_staged = false;
 	uint64_t pending_n = 0, pending_keys = 0;
 	bool merge_started = false;          // rg_merge_entries has been called with entries
 	void *rec_buf = nullptr;             // rg_records_local .. rg_export_records: super-k-mer records of the local reads
@@ -1623,22 +1626,23 @@ struct AggLaunch {
 			                   flag_unique, (const uint32_t *)nullptr, retry, m, rbits);
 		else if (big)
 			hipLaunchKernelGGL((k_aggregate<W, false, AGG_SLOTS_BIG, C>), dim3(grid), dim3(64 * agg_waves<W>()), 0, h->stream, recs, begin, nb, k, log, log_cap, h->d_counters,
-			                   flag_unique, (const uint32_t *)nullptr, retry, m, rbits, items);
+			                   flag_unique, (const uint32_t *)nullptr, retry, m, rbits, items, (const unsigned long long *)nullptr);
 		else
 			hipLaunchKernelGGL((k_aggregate<W, false, AGG_SLOTS, C>), dim3(grid), dim3(64 * agg_waves<W>()), 0, h->stream, recs, begin, nb, k, log, log_cap, h->d_counters, flag_unique,
-			                   (const uint32_t *)nullptr, retry, m, rbits, items);
+			                   (const uint32_t *)nullptr, retry, m, rbits, items, (const unsigned long long *)nullptr);
 	}
+	// list_len: the list's length is on the device (nlist = its upper bound); not for the workgroup-per-bucket kernel
 	void slow(rg_handle *h, unsigned grid, const RM *recs, const unsigned long long *begin, uint32_t nlist, int k, Slot *log, uint64_t log_cap,
-	          uint32_t flag_unique, const uint32_t *list, int m, uint32_t rbits) const {
+	          uint32_t flag_unique, const uint32_t *list, int m, uint32_t rbits, const unsigned long long *list_len = nullptr) const {
 		if (wg)
 			hipLaunchKernelGGL((k_aggregate_wg<W, THREADS, KS, RS, true, C>), dim3(grid), dim3(THREADS), 0, h->stream, recs, begin, nlist, k, log, log_cap, h->d_counters,
 			                   flag_unique, list, (uint32_t *)nullptr, m, rbits);
 		else if (big)
 			hipLaunchKernelGGL((k_aggregate<W, true, AGG_SLOTS_BIG, C>), dim3(grid), dim3(64 * agg_waves<W>()), 0, h->stream, recs, begin, nlist, k, log, log_cap, h->d_counters,
-			                   flag_unique, list, (uint32_t *)nullptr, m, rbits, items);
+			                   flag_unique, list, (uint32_t *)nullptr, m, rbits, items, list_len);
 		else
 			hipLaunchKernelGGL((k_aggregate<W, true, AGG_SLOTS, C>), dim3(grid), dim3(64 * agg_waves<W>()), 0, h->stream, recs, begin, nlist, k, log, log_cap, h->d_counters, flag_unique,
-			                   list, (uint32_t *)nullptr, m, rbits, items);
+			                   list, (uint32_t *)nullptr, m, rbits, items, list_len);
 	}
 };
 
@@ -2192,7 +2196,13 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 			agg.fast(h, agg_grid, level_in, d_begin, (uint32_t)NBUCK, k, log, log_cap, flag_unique, d_retry, m, agg_rbits);
 			e0 = hipGetLastError();
 		}
-		if (e0 == hipSuccess) {
+		if (e0 == hipSuccess && !agg.wg && !mostly_overflowing) {
+			// the buckets whose k-mers did not fit the LDS table, split further: the launch follows at once and reads the length of
+			// the list from the counter the first one left (no wait of the host in between; a log the first launch has filled
+			// stops it at its first chunk)
+			ProfScope ps(h, "k_aggregate_retry");
+			agg.slow(h, agg.grid_for_buckets(NBUCK, n_cu), level_in, d_begin, (uint32_t)NBUCK, k, log, log_cap, flag_unique, d_retry, m, agg_rbits, h->d_counters + PC_AGG_RETRY);
+		} else if (e0 == hipSuccess && !mostly_overflowing) {
 			rc = sync_counters(h);
 			const uint64_t n_retry = rc ? 0 : h->h_counters[PC_AGG_RETRY];
 			// every bucket left over holds more k-mers than the LDS table: if even that many cannot fit, skip the launch
@@ -2254,6 +2264,7 @@ static int sweep_partitioned_t(rg_handle *h, Slot **out_log, uint64_t *out_n, bo
 	h->log_all_unique = flag_unique && h->h_counters[PC_NONUNIQUE] == 0 && h->h_counters[PC_LDS_SPILL] == 0;
 	h->log_keys = h->h_counters[PC_LOG_KEYS];
 	h->log_compact = compact;
+	h->log_multi = h->h_counters[PC_LOG_MULTI];
 	h->stats.compact_log = compact ? 1 : 0;
 	if (with_items) {
 		uint64_t total = 0;
@@ -3033,12 +3044,18 @@ static int materialize_pending_log(rg_handle *h) {
 }
 
 // reads the device histogram (dense bins + overflow list) back and caches it in the handle
-static int collect_histogram(rg_handle *h, const unsigned long long *dense, const uint32_t *ovf) {
-	std::vector<unsigned long long> hd(HIST_DENSE);
-	hipError_t e = hipMemcpyAsync(hd.data(), dense, HIST_DENSE * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream);
-	if (e != hipSuccess) return fail(h, RG_ERR_HIP, "histogram: %s", hipGetErrorString(e));
-	int rc = sync_counters(h);
-	if (rc) return rc;
+// staged: the dense bins are in h->hist_stage and the counters on the host already (build_table_ranges, one-pass admission)
+static int collect_histogram(rg_handle *h, const unsigned long long *dense, const uint32_t *ovf, bool staged = false) {
+	std::vector<unsigned long long> hd_own;
+	hipError_t e = hipSuccess;
+	if (!staged) {
+		hd_own.resize(HIST_DENSE);
+		e = hipMemcpyAsync(hd_own.data(), dense, HIST_DENSE * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream);
+		if (e != hipSuccess) return fail(h, RG_ERR_HIP, "histogram: %s", hipGetErrorString(e));
+		int rc = sync_counters(h);
+		if (rc) return rc;
+	}
+	const std::vector<unsigned long long> &hd = staged ? h->hist_stage : hd_own;
 	const uint64_t novf = h->h_counters[C_OVF];
 	std::vector<uint32_t> ho;
 	if (novf > HIST_OVF_CAP) return fail(h, RG_ERR_CAPACITY, "more than %u vertices with coverage >= %u", HIST_OVF_CAP, HIST_DENSE);
@@ -3294,12 +3311,17 @@ static int build_table_ranges(rg_handle *h, const Slot *log, uint64_t n_log, uin
 		else hipLaunchKernelGGL(k_build_ranges<2>, dim3(grid), dim3(1024), lds, h->stream, (const Ent<2> *)level_in, d_begin, (uint32_t)NR, bits, tab, cap, ovf, ovf_cap, h->d_counters);
 	}
 	TTRY(hipGetLastError());
+	if (fused && h->d_hist_dense) {  // the admission's histogram is complete since the first level: it travels with this wait
+		h->hist_stage.resize(HIST_DENSE);
+		TTRY(hipMemcpyAsync(h->hist_stage.data(), h->d_hist_dense, HIST_DENSE * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+	}
 	int rc = sync_counters(h);
 	if (rc) {
 		cleanup();
 		pool_free(dev, tab);
 		return rc;
 	}
+	h->hist_staged = fused && h->d_hist_dense;
 	const uint64_t n_ovf = h->h_counters[TC_OVF_CURSOR];
 	if (h->h_counters[TC_OVF_LOST]) {  // more entries left their range than the list holds (never seen): build the classic way
 		cleanup();
@@ -3551,9 +3573,7 @@ int rg_count_local(rg_handle *h) {
 					h->pending_compact = h->log_compact;
 					h->pending_n = n_log;
 					h->pending_keys = h->log_keys;
-					rc = sync_counters(h);
-					if (rc) return rc;
-					h->pending_multi = h->h_counters[C_LOG_MULTI];
+					h->pending_multi = h->log_multi;  // (the sweep read the counters after its last launch: no wait for them here)
 				} else if (h->log_compact) {
 					pool_free(h->cfg.device, log);
 					return fail(h, RG_ERR_STATE, "a compact log that cannot be kept");  // (the sweep makes one only where it is)
@@ -3933,7 +3953,7 @@ int rg_resolve_admission(rg_handle *h, uint64_t local_reads_for_bloom) {
 		// keys in the table decide the method: region partitioning when the filter stays sparse
 		// (8 touches per key), dense first-touch stamps otherwise.  rg_debug_set bit 4 forces the
 		// first, bit 5 the second (tests).
-		int rc0 = sync_counters(h);
+		int rc0 = from_log ? RG_OK : sync_counters(h);  // (a log's keys were counted by whoever made it)
 		if (rc0) return rc0;
 		const uint64_t keys = from_log ? h->pending_keys : h->h_counters[C_FILL];
 		const uint32_t flags = (uint32_t)h->dbg & 0xFFu;
@@ -3996,6 +4016,7 @@ int rg_resolve_admission(rg_handle *h, uint64_t local_reads_for_bloom) {
 	// statistics and the histogram and writes into ranges sized in advance -- possible when the stored vertices can be bounded
 	// before it: entries seen twice or more (counted by whoever made the log) + false positives (counted by k_xor_fp).
 	bool fused_built = false, fused_tried = false;
+	h->hist_staged = false;
 	auto drop_marks = [&]() {
 		pool_free(h->cfg.device, lost_kept);
 		lost_kept = nullptr;
@@ -4021,6 +4042,7 @@ int rg_resolve_admission(rg_handle *h, uint64_t local_reads_for_bloom) {
 					return fail(h, RG_ERR_HIP, "admission: %s", hipGetErrorString(ez));
 				}
 				fused_tried = false;
+				h->hist_staged = false;
 			}
 		}
 	}
@@ -4045,7 +4067,11 @@ int rg_resolve_admission(rg_handle *h, uint64_t local_reads_for_bloom) {
 			return fail(h, RG_ERR_HIP, "admission: %s", hipGetErrorString(e));
 		}
 	}
-	int rc = collect_histogram(h, h->d_hist_dense, h->d_hist_ovf);
+	// (built by the one-pass admission: the histogram and the counters came with the build's last wait, and nothing has been
+	// launched since -- none of the three waits below is needed)
+	const bool all_read = fused_built && h->hist_staged;
+	int rc = collect_histogram(h, h->d_hist_dense, h->d_hist_ovf, all_read);
+	h->hist_staged = false;
 	if (rc) {
 		pool_free(h->cfg.device, lost_kept);
 		pool_free(h->cfg.device, d_first_hist);
@@ -4066,7 +4092,7 @@ int rg_resolve_admission(rg_handle *h, uint64_t local_reads_for_bloom) {
 			if (hipGetLastError() != hipSuccess) rc = fail(h, RG_ERR_HIP, "k_admit_lost launch failed");
 		}
 		if (lost_kept) {
-			(void)rg_stream_sync(h);
+			if (!all_read) (void)rg_stream_sync(h);
 			pool_free(h->cfg.device, lost_kept);
 			pool_free(h->cfg.device, d_first_hist);
 			lost_kept = nullptr;
@@ -4079,7 +4105,7 @@ int rg_resolve_admission(rg_handle *h, uint64_t local_reads_for_bloom) {
 			else hipLaunchKernelGGL(k_insert_admitted<2>, dim3(grid_for(h->pending_n)), dim3(BLOCK), 0, h->stream, h->pending_log, h->pending_n, h->tab.slots, h->tab.cap, h->d_counters);
 			if (hipGetLastError() != hipSuccess) rc = fail(h, RG_ERR_HIP, "k_insert_admitted launch failed");
 		}
-		if (rc == RG_OK) rc = sync_counters(h);
+		if (rc == RG_OK && !all_read) rc = sync_counters(h);
 		pool_free(h->cfg.device, h->pending_log);  // (a borrowed buffer is not the pool's: nothing happens)
 		h->pending_log = nullptr;
 		h->pending_compact = false;

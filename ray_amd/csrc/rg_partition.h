@@ -1481,11 +1481,18 @@ constexpr bool agg_anchors() { return W == 2 && !SLOW && SLOTS == 256; }  // (th
 // bucket_list, with sub-passes.  Two instantiations so that the common path carries none of the retry machinery.
 template <int W, bool SLOW, int SLOTS = AGG_SLOTS, bool C = false>
 __global__ __launch_bounds__(64 * agg_waves<W>()) void k_aggregate(const RecMem<W, C> *__restrict__ recs,
-                                                              const unsigned long long *__restrict__ bucket_begin, uint32_t nbuckets,
+                                                              const unsigned long long *__restrict__ bucket_begin, uint32_t nbuckets_max,
                                                               int k, Slot *__restrict__ log, uint64_t log_cap,
                                                               unsigned long long *__restrict__ counters, uint32_t flag_unique,
                                                               const uint32_t *__restrict__ bucket_list, uint32_t *__restrict__ retry_list,
-                                                              int m, uint32_t rbits, AggItems ai) {
+                                                              int m, uint32_t rbits, AggItems ai, const unsigned long long *__restrict__ list_len = nullptr) {
+	// list_len (SLOW): the length of bucket_list is read from there (at most nbuckets_max) -- the launch that retries the
+	// buckets another launch has just listed follows it without the host reading their number in between
+	uint32_t nbuckets = nbuckets_max;
+	if (SLOW && list_len) {
+		const unsigned long long n = *list_len;
+		nbuckets = n < nbuckets_max ? (uint32_t)n : nbuckets_max;
+	}
 	// flag_unique: the caller guarantees that nothing outside this launch's log carries the same keys on their way
 	// to the same table; the entries are then marked LOG_UNIQUE (every k-mer lives in exactly one bucket, see
 	// k_superkmers, and a bucket is flushed once per sub-pass, each sub-pass owning a disjoint share of the k-mers).
