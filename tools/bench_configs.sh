@@ -4,7 +4,7 @@
 TAG=$1
 run() {  # name, then bench.py arguments
   local name=$1; shift
-  RG_DEBUG=1 timeout -k 10 500 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-error-record "$@" > gpurun_out/bench_${TAG}_$name.json 2> gpurun_out/bench_${TAG}_$name.err || exit $?
+  RG_DEBUG=1 timeout -k 10 500 python bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-error-record "$@" > gpurun_out/bench_${TAG}_$name.json 2> gpurun_out/bench_${TAG}_$name.err || exit $?
   echo "== $name ($*)"; python tools/show_bench.py gpurun_out/bench_${TAG}_$name.json | sed -n 1,7p
 }
 run C1_whole --workload C1_ecoli_50x_100bp_k31
