@@ -161,7 +161,7 @@ def main():
     nranks = world * emu
     # bytes per k-mer occurrence on the links: records ~ 24 B per 8.4 occurrences plus one entry per distinct k-mer of the
     # whole job; entries: 32 B per distinct k-mer of ONE rank's reads, i.e. 32 / (that rank's k-mer coverage).  Per-rank
-    # work measured with --emulate-world (C2 shape): records 125 ms at any N; entries 152 / 191 / 282 ms at N = 2 / 4 / 8.
+    # work measured with --emulate-world (C2 shape, round 3): records 66 ms at N = 8; entries 104 ms at N = 2 (round 2: 185 at N = 8).
     local_kmer_cov = cfg["coverage"] * (cfg["read_len"] - k + 1) / cfg["read_len"] / nranks
     route = args.route if args.route != "auto" else ("entries" if local_kmer_cov >= 16 else "records")
     # weak scaling: the genome grows with N.  Emulated records route: a rank receives full-coverage buckets, like N = 1;
