@@ -287,6 +287,16 @@ def test_a_compact_log_is_expanded_for_the_routes_that_read_full_entries(oracle,
     assert st["compact_log"] == (2 if expanded else 1), route
 
 
+def test_a_compact_log_without_the_key_partition(oracle):
+    """items and a 16-byte log were made, but the admission does not take the key partition (too few keys and nothing forces
+    it): the log is expanded with its stamps before the Bloom regions or the dense stamps read it"""
+    packed, offsets, lengths = make_reads_numpy(genome=25000, read_len=150, n_reads=7000, seed=91, error=0.02)
+    for flags in (0, 16, 32):
+        want = gpu_vs_oracle(oracle, packed, offsets, lengths, 31, bloom_bits=1 << 28, sweeps=(1 | 0x2000000 | flags,))
+        st = want["builder"].stats()
+        assert st["compact_log"] == 2 and st["bloom_partitioned"] != 2, flags
+
+
 @pytest.mark.parametrize("k", [21, 31, 47, 63])
 def test_hashes_are_checked_against_the_callers(oracle, k):
     """rg_check_hashes / rg_hash_kmers: the device's hash_function_1 / _2 against the caller's own (here the oracle's, the
